@@ -1,0 +1,162 @@
+/* sage_gs.h — C ABI of libsage_gs.so, the MI355X-native 3D-Gaussian-splatting scene renderer that
+ * stands in for the Isaac Sim render step of Galery23/SAGE-3D_Official.
+ *
+ * The reference has NO FFI for this path: it drives a closed renderer through the Isaac Sim Camera
+ * protocol.  Each entry point below names the reference call site(s) it replaces (paths relative to
+ * the reference root).  Signatures are plain C: pointers, sizes, PODs; no C++ or
+ * torch types, no exceptions.  Every function returns 0 on success or a negative sgs_status; the
+ * message of the last failure on a context is available from sgs_last_error().
+ *
+ * Ownership: the caller owns every input and output buffer.  The library owns only its per-context
+ * scratch (freed by sgs_destroy) and the re-laid-out scene copy (freed by sgs_scene_free).
+ * Threading: a context is bound to one HIP device and is not re-entrant; work is stream-ordered on
+ * the stream passed in (NULL = the device's default stream).  Distinct contexts may be used from
+ * distinct threads/processes (one process per GPU is the intended deployment).
+ *
+ * There is deliberately no CPU backend behind this ABI: sgs_create(…, SGS_BACKEND_CPU, …) fails
+ * with SGS_ERR_BACKEND.  The CPU restatement lives in oracle/ and is test infrastructure only.
+ */
+#ifndef SAGE_GS_H
+#define SAGE_GS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGS_VERSION 100            /* major*100 + minor */
+#define SGS_TILE 16                /* 16x16-pixel tiles (BASELINE.json north_star) */
+
+typedef enum sgs_status {
+    SGS_OK = 0,
+    SGS_ERR_INVALID = -1,          /* bad argument */
+    SGS_ERR_HIP = -2,              /* a HIP runtime call failed */
+    SGS_ERR_OOM = -3,              /* device allocation failed */
+    SGS_ERR_OVERFLOW = -4,         /* more (Gaussian,tile) records than the record capacity */
+    SGS_ERR_BACKEND = -5           /* backend not available (only SGS_BACKEND_HIP exists) */
+} sgs_status;
+
+enum { SGS_BACKEND_CPU = 0, SGS_BACKEND_HIP = 1 };
+
+/* sgs_config.flags */
+enum {
+    SGS_FLAG_ASYNC  = 1u << 0,     /* do not synchronise the stream; collect with sgs_frame_sync() */
+    SGS_FLAG_TIMING = 1u << 1,     /* bracket every stage with HIP events (fills sgs_stats.ms[]) */
+    SGS_FLAG_STATS  = 1u << 2      /* also count D_f (records consumed by the composite) */
+};
+
+/* Pipeline stages, in launch order (index of sgs_stats.ms[] / .bytes[]). */
+enum {
+    SGS_STAGE_PREPROCESS = 0,      /* S1-S3 (+ per-tile counting): SH, EWA projection, AABB   */
+    SGS_STAGE_SCAN       = 1,      /* S4a: exclusive scan of the per-tile counts               */
+    SGS_STAGE_EMIT       = 2,      /* S4b: duplication into per-tile queues                    */
+    SGS_STAGE_SORT       = 3,      /* S5: per-tile radix depth sort                            */
+    SGS_STAGE_COMPOSITE  = 4,      /* S6: front-to-back alpha composite                        */
+    SGS_NUM_STAGES       = 5
+};
+
+typedef struct sgs_ctx sgs_ctx;        /* opaque */
+typedef struct sgs_scene sgs_scene;    /* opaque */
+
+/* Pinhole camera: +Z forward, +X right, +Y down; pixel i covers [i, i+1) so a point on the optical
+ * axis lands at pixel coordinate cx - 0.5.  `view` maps MODEL space to camera space (row-major
+ * 4x4, rigid): the asset's model->world transform (Data/template.usda:115-124, rotateXYZ -90,0,0)
+ * is folded in by the caller.  Replaces Camera(prim_path, frequency, resolution) + focalLength
+ * (simple_env.py:840-844,905; generate_images.py:344-350) and cam.set_world_pose(position,
+ * orientation) (simple_env.py:1284; generate_images.py:419-421). */
+typedef struct sgs_camera {
+    int32_t width, height;
+    float fx, fy, cx, cy;
+    float view[16];
+} sgs_camera;
+
+/* Constants of stages S2-S6; sgs_config_default() fills the canonical values. */
+typedef struct sgs_config {
+    float near_z;          /* 0.2   cull tz <= near_z                                   */
+    float far_z;           /* 1e30  cull tz >  far_z                                    */
+    float dilation;        /* 0.3   px^2 added to the 2-D covariance diagonal           */
+    float clamp;           /* 1.3   frustum clamp factor on t.xy / t.z                  */
+    float alpha_min;       /* 1/255 */
+    float alpha_max;       /* 0.99  */
+    float t_min;           /* 1e-4  */
+    float bg[3];           /* background, linear RGB (Data/template.usda tonemap is NOT applied) */
+    int32_t sh_degree;     /* -1 = the scene's degree                                   */
+    uint32_t flags;        /* SGS_FLAG_*                                                */
+} sgs_config;
+
+typedef struct sgs_stats {
+    int64_t n_gaussians;   /* N                                                          */
+    int64_t n_visible;     /* N_v: survivors of culling                                  */
+    int64_t d_total;       /* D: sum of tiles touched = records sorted                   */
+    int64_t d_fetched;     /* D_f (SGS_FLAG_STATS): records consumed before every pixel of their tile stopped */
+    int64_t n_pixels;      /* pixels written by this call                                */
+    int32_t n_tiles;       /* tiles in [tile_row_begin, tile_row_end)                    */
+    int32_t max_tile_len;  /* longest per-tile queue                                     */
+    int32_t n_spill_tiles; /* tiles whose queue exceeded the LDS sort capacity           */
+    int32_t retries;       /* re-renders after growing the record capacity               */
+    float ms[SGS_NUM_STAGES];      /* per-stage GPU time (SGS_FLAG_TIMING), else 0       */
+    float ms_total;                /* first launch -> last launch (SGS_FLAG_TIMING)      */
+    int64_t bytes[SGS_NUM_STAGES]; /* algorithmic bytes per stage         */
+} sgs_stats;
+
+int sgs_version(void);
+void sgs_config_default(sgs_config* cfg);
+
+/* Replaces SimulationApp({...}) + World() construction (simple_env.py:160-230). */
+int sgs_create(int device_id, int backend, sgs_ctx** out);
+int sgs_destroy(sgs_ctx* ctx);
+const char* sgs_last_error(const sgs_ctx* ctx);    /* ctx may be NULL: last creation error */
+
+/* Record capacity (number of (Gaussian,tile) records the scratch can hold).  Grown automatically
+ * by synchronous renders; asynchronous renders fail with SGS_ERR_OVERFLOW instead. */
+int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
+
+/* Scene load — replaces open_stage(usd_path) resolving /World/gauss (simple_env.py:219;
+ * generate_images.py:320-327).  Inputs are fp32, activations already applied:
+ *   means[N,3], scales[N,3] (linear), quats[N,4] (w,x,y,z; normalised by the library),
+ *   opacities[N] in (0,1), sh[N,(sh_degree+1)^2,3].
+ * on_device != 0: the pointers are device pointers on the context's device. */
+int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means, const float* scales,
+                     const float* quats, const float* opacities, const float* sh, int on_device,
+                     sgs_scene** out);
+int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene);
+
+/* One frame — replaces world.step(render=True) x2..5 + cam.get_rgba() (simple_env.py:1368-1380;
+ * generate_images.py:425-428).  Renders the tile rows [tile_row_begin, tile_row_end) of the frame
+ * (tile_row_end < 0: all rows) into out_rgb, a DEVICE buffer of height*width*3 floats (row-major,
+ * RGB interleaved); rows outside the range are left untouched.  stats may be NULL. */
+int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
+               int tile_row_begin, int tile_row_end, float* out_rgb, sgs_stats* stats,
+               void* hip_stream);
+
+/* B frames of one scene, back to back, one synchronisation at the end — the frame loop of
+ * generate_images.py:408-436.  out_rgb holds B consecutive frames; stats (nullable) B entries. */
+int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
+                     const sgs_config* cfg, int tile_row_begin, int tile_row_end, float* out_rgb,
+                     sgs_stats* stats, void* hip_stream);
+
+/* Completes frames issued with SGS_FLAG_ASYNC: synchronises the stream and reports the status and
+ * statistics of the most recent frame. */
+int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats);
+
+/* fp32 RGB -> uint8 RGBA (alpha 255), the shape cam.get_rgba() returns (simple_env.py:1380-1386;
+ * generate_images.py:428-431).  Both buffers are device buffers. */
+int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int height,
+                   void* hip_stream);
+
+/* Test hook: copy an intermediate buffer of the LAST synchronous frame to host memory.
+ * Returns the number of bytes the buffer holds (copying at most `bytes`), or a negative status. */
+enum {
+    SGS_BUF_TILE_OFFSETS = 0,      /* uint32[T+1]                                                */
+    SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues after S5 (compacted slots)    */
+    SGS_BUF_SLOT_IDS     = 2,      /* uint32[N_v]  Gaussian index of each compacted slot         */
+    SGS_BUF_SPLATS       = 3       /* 12 x 4 B per slot: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 */
+};
+int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_GS_H */

@@ -1,0 +1,513 @@
+// sgs_api.hip — host side of libsage_gs.so: the C ABI of include/sage_gs.h over the gfx950 kernels.
+//
+// A frame is seven stream-ordered launches with no host synchronisation in between (grids that
+// depend on device-side counts are fixed-size and grid-stride); the frame's FrameStatus is copied
+// to pinned host memory at the end and inspected when the caller synchronises.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/sage_gs.h"
+#include "sgs_kernels.h"
+
+namespace {
+
+constexpr int kStatusRing = 256;
+thread_local std::string g_create_error;
+
+struct Scratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace
+
+struct sgs_scene {
+    int64_t n = 0, n_chunks = 0;
+    int sh_degree = 0, sh_rows = 0;
+    float4* geom = nullptr;
+    float4* shq = nullptr;
+};
+
+struct sgs_ctx {
+    int device = 0;
+    std::string err;
+    // per-Gaussian scratch
+    int64_t splat_cap = 0;
+    Splat* splats = nullptr;
+    unsigned* slot_id = nullptr;
+    // per-tile scratch
+    int tile_cap = 0;
+    unsigned *tile_count = nullptr, *tile_offset = nullptr, *tile_fill = nullptr, *class_list = nullptr;
+    // per-record scratch
+    int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
+    unsigned *rec_key = nullptr, *rec_val = nullptr, *alt_key = nullptr, *alt_val = nullptr;
+    // status ring
+    FrameStatus* d_status = nullptr;
+    FrameStatus* h_status = nullptr;
+    int next_slot = 0;
+    // bookkeeping of the most recent frame
+    int last_slot = -1;
+    bool last_timed = false;
+    int64_t last_n = 0, last_pixels = 0;
+    int last_tiles = 0, last_sh_rows = 0, last_T = 0;
+    int last_retries = 0;
+    hipStream_t last_stream = nullptr;
+    hipEvent_t ev[SGS_NUM_STAGES + 1] = {};
+    bool have_events = false;
+};
+
+#define SGS_FAIL(ctx, code, ...)                                  \
+    do {                                                          \
+        char buf_[512];                                           \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);                 \
+        (ctx)->err = buf_;                                        \
+        return (code);                                            \
+    } while (0)
+
+#define SGS_HIP(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            SGS_FAIL(ctx, e_ == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP, "%s: %s", #call, \
+                     hipGetErrorString(e_));                                                   \
+    } while (0)
+
+namespace {
+
+template <class T>
+int grow(sgs_ctx* ctx, T*& p, size_t count) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+    if (count == 0) count = 1;
+    SGS_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    return SGS_OK;
+}
+
+int ensure_splats(sgs_ctx* ctx, int64_t n) {
+    if (n <= ctx->splat_cap) return SGS_OK;
+    const int64_t cap = ((n + 63) / 64) * 64;
+    int rc;
+    if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->slot_id, (size_t)cap)) != SGS_OK) return rc;
+    ctx->splat_cap = cap;
+    return SGS_OK;
+}
+
+int ensure_tiles(sgs_ctx* ctx, int tiles) {
+    if (tiles <= ctx->tile_cap) return SGS_OK;
+    int rc;
+    if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_fill, (size_t)tiles + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->class_list, (size_t)tiles * SGS_SORT_CLASSES)) != SGS_OK) return rc;
+    // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
+    SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
+    ctx->tile_cap = tiles;
+    return SGS_OK;
+}
+
+int ensure_records(sgs_ctx* ctx) {
+    if (ctx->rec_cap >= ctx->rec_cap_wanted && ctx->rec_key) return SGS_OK;
+    const int64_t cap = std::max<int64_t>(ctx->rec_cap_wanted, 1024);
+    if (cap > 0xfffffff0ll) SGS_FAIL(ctx, SGS_ERR_INVALID, "record capacity %lld exceeds 2^32", (long long)cap);
+    int rc;
+    if ((rc = grow(ctx, ctx->rec_key, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->rec_val, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->alt_key, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->alt_val, (size_t)cap)) != SGS_OK) return rc;
+    ctx->rec_cap = cap;
+    return SGS_OK;
+}
+
+int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
+             int& row_begin, int& row_end, const float* out_rgb) {
+    if (!scene || !cam || !out_rgb) SGS_FAIL(ctx, SGS_ERR_INVALID, "null scene / camera / output");
+    if (cam->width <= 0 || cam->height <= 0 || cam->width > 65535 * SGS_TILE || cam->height > 65535 * SGS_TILE)
+        SGS_FAIL(ctx, SGS_ERR_INVALID, "bad resolution %dx%d", cam->width, cam->height);
+    if (!(cam->fx > 0.f) || !(cam->fy > 0.f)) SGS_FAIL(ctx, SGS_ERR_INVALID, "focal lengths must be positive");
+    const int gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    if (row_end < 0 || row_end > gy) row_end = gy;
+    if (row_begin < 0) row_begin = 0;
+    if (row_begin > row_end) SGS_FAIL(ctx, SGS_ERR_INVALID, "tile_row_begin %d > tile_row_end %d", row_begin, row_end);
+    if (cfg && cfg->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d > 3", cfg->sh_degree);
+    return SGS_OK;
+}
+
+void fill_params(FrameParams& P, const sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
+                 const sgs_config& cfg, int row_begin, int row_end) {
+    memset(&P, 0, sizeof P);
+    for (int i = 0; i < 12; ++i) P.view[i] = cam->view[i];
+    const float* V = cam->view;
+    for (int c = 0; c < 3; ++c)
+        P.campos[c] = -((double)V[c] * V[3] + (double)V[4 + c] * V[7] + (double)V[8 + c] * V[11]);
+    P.fx = cam->fx; P.fy = cam->fy; P.cx = cam->cx; P.cy = cam->cy;
+    P.near_z = cfg.near_z; P.far_z = cfg.far_z; P.dilation = cfg.dilation; P.clamp = cfg.clamp;
+    P.alpha_min = cfg.alpha_min; P.alpha_max = cfg.alpha_max; P.t_min = cfg.t_min;
+    for (int c = 0; c < 3; ++c) P.bg[c] = cfg.bg[c];
+    P.width = cam->width; P.height = cam->height;
+    P.gx = (cam->width + SGS_TILE - 1) / SGS_TILE; P.gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    P.row_begin = row_begin; P.row_end = row_end;
+    P.sh_degree = cfg.sh_degree < 0 ? scene->sh_degree : std::min(cfg.sh_degree, scene->sh_degree);
+    P.sh_rows = scene->sh_rows;
+    P.n = scene->n; P.n_chunks = scene->n_chunks;
+    P.rec_capacity = ctx->rec_cap;
+    P.flags = cfg.flags | SGS_FLAG_STATS;
+}
+
+// Enqueue one frame on `stream`; the frame's status lands in ring slot `slot`.
+int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg,
+                  int row_begin, int row_end, float* out_rgb, int slot, hipStream_t stream, bool timed) {
+    int rc;
+    const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE, gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    if ((rc = ensure_splats(ctx, scene->n)) != SGS_OK) return rc;
+    if ((rc = ensure_tiles(ctx, gx * gy)) != SGS_OK) return rc;
+    if ((rc = ensure_records(ctx)) != SGS_OK) return rc;
+    FrameParams P;
+    fill_params(P, ctx, scene, cam, cfg, row_begin, row_end);
+    FrameStatus* st = ctx->d_status + slot;
+    SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+
+    if (scene->n_chunks > 0) {
+        const unsigned grid = (unsigned)((scene->n_chunks + 3) / 4);
+        hipLaunchKernelGGL(sgs::k_preprocess, dim3(grid), dim3(256), 0, stream, P, scene->geom, scene->shq,
+                           ctx->splats, ctx->slot_id, ctx->tile_count, st);
+    }
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
+
+    // the scan copies the counts into tile_fill (k_emit's slot dispenser); tile_count is then cleared
+    // for the next frame
+    hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
+                       ctx->tile_offset, ctx->tile_fill, ctx->class_list, st);
+    SGS_HIP(ctx, hipMemsetAsync(ctx->tile_count, 0, ((size_t)gx * gy + 1) * sizeof(unsigned), stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+
+    if (scene->n_chunks > 0) {
+        const unsigned grid = (unsigned)std::min<int64_t>((scene->n_chunks + 3) / 4, 2048);
+        hipLaunchKernelGGL(sgs::k_emit, dim3(grid), dim3(256), 0, stream, P, ctx->splats, ctx->tile_offset,
+                           ctx->tile_fill, ctx->rec_key, ctx->rec_val, st);
+    }
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+
+    const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
+    if (ntiles > 0 && scene->n_chunks > 0) {
+        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_S, false>), dim3(ntiles), dim3(256), 0, stream, P, 0,
+                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
+                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
+        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_M, false>), dim3(ntiles), dim3(256), 0, stream, P, 1,
+                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
+                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
+        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_L, false>), dim3(ntiles), dim3(256), 0, stream, P, 2,
+                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
+                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
+        hipLaunchKernelGGL((sgs::k_tile_sort<1, true>), dim3(ntiles), dim3(256), 0, stream, P, 3,
+                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
+                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
+    }
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[4], stream));
+
+    if (ntiles > 0) {
+        const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
+        hipLaunchKernelGGL(sgs::k_composite, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset,
+                           ctx->rec_val, ctx->splats, out_rgb, st);
+    }
+    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[5], stream));
+    SGS_HIP(ctx, hipGetLastError());
+    SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
+
+    ctx->last_slot = slot; ctx->last_timed = timed; ctx->last_stream = stream;
+    ctx->last_n = scene->n; ctx->last_tiles = (int)ntiles; ctx->last_sh_rows = scene->sh_rows;
+    ctx->last_T = gx * gy;
+    const int y0 = row_begin * SGS_TILE, y1 = std::min(row_end * SGS_TILE, cam->height);
+    ctx->last_pixels = (int64_t)std::max(0, y1 - y0) * cam->width;
+    return SGS_OK;
+}
+
+// Fill `stats` from the (already synchronised) status of ring slot `slot`.
+void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, int64_t pixels, int sh_rows,
+             bool timed) {
+    if (!stats) return;
+    const FrameStatus& s = ctx->h_status[slot];
+    memset(stats, 0, sizeof *stats);
+    stats->n_gaussians = n;
+    stats->n_visible = s.n_visible;
+    stats->d_total = s.d_total;
+    stats->d_fetched = (int64_t)s.d_fetched;
+    stats->n_pixels = pixels;
+    stats->n_tiles = ntiles;
+    stats->max_tile_len = (int32_t)s.max_tile_len;
+    stats->n_spill_tiles = (int32_t)s.class_count[3];
+    stats->retries = ctx->last_retries;
+    // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
+    const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
+    stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 48 + 4) * nv;
+    stats->bytes[SGS_STAGE_SCAN] = 16 * ((int64_t)ctx->last_T + 1);
+    stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
+    stats->bytes[SGS_STAGE_SORT] = 12 * D;
+    stats->bytes[SGS_STAGE_COMPOSITE] = 40 * Df + 12 * pixels;
+    if (timed) {
+        for (int i = 0; i < SGS_NUM_STAGES; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) stats->ms[i] = ms;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[SGS_NUM_STAGES]) == hipSuccess) stats->ms_total = ms;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgs_version(void) { return SGS_VERSION; }
+
+void sgs_config_default(sgs_config* cfg) {
+    if (!cfg) return;
+    cfg->near_z = 0.2f; cfg->far_z = 1.0e30f; cfg->dilation = 0.3f; cfg->clamp = 1.3f;
+    cfg->alpha_min = 1.0f / 255.0f; cfg->alpha_max = 0.99f; cfg->t_min = 1.0e-4f;
+    cfg->bg[0] = cfg->bg[1] = cfg->bg[2] = 0.f;
+    cfg->sh_degree = -1; cfg->flags = 0;
+}
+
+const char* sgs_last_error(const sgs_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int sgs_create(int device_id, int backend, sgs_ctx** out) {
+    if (!out) { g_create_error = "sgs_create: out is NULL"; return SGS_ERR_INVALID; }
+    *out = nullptr;
+    if (backend != SGS_BACKEND_HIP) {
+        g_create_error = "sgs_create: only SGS_BACKEND_HIP exists; the CPU restatement lives in oracle/ (tests only)";
+        return SGS_ERR_BACKEND;
+    }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_error = std::string("sgs_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return SGS_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= count) { g_create_error = "sgs_create: device_id out of range"; return SGS_ERR_INVALID; }
+    sgs_ctx* ctx = new (std::nothrow) sgs_ctx;
+    if (!ctx) { g_create_error = "sgs_create: out of host memory"; return SGS_ERR_OOM; }
+    ctx->device = device_id;
+    auto fail = [&](const char* what, hipError_t err) {
+        g_create_error = std::string("sgs_create: ") + what + ": " + hipGetErrorString(err);
+        sgs_destroy(ctx);
+        return SGS_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
+    for (auto& ev : ctx->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("hipEventCreate", e);
+    ctx->have_events = true;
+    if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
+        const long long v = atoll(env);
+        if (v > 0) ctx->rec_cap_wanted = v;
+    }
+    *out = ctx;
+    return SGS_OK;
+}
+
+int sgs_destroy(sgs_ctx* ctx) {
+    if (!ctx) return SGS_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->tile_fill, ctx->class_list,
+                    ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+    if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+    delete ctx;
+    return SGS_OK;
+}
+
+int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (max_records <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "max_records must be positive");
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->rec_cap_wanted = max_records;
+    ctx->rec_cap = 0;                 // force reallocation at the requested size
+    return ensure_records(ctx);
+}
+
+int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means, const float* scales,
+                     const float* quats, const float* opacities, const float* sh, int on_device,
+                     sgs_scene** out) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (!out) SGS_FAIL(ctx, SGS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (n < 0 || n > 0x7fffffffll) SGS_FAIL(ctx, SGS_ERR_INVALID, "n = %lld out of range", (long long)n);
+    if (sh_degree < 0 || sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d not in 0..3", sh_degree);
+    if (n > 0 && (!means || !scales || !quats || !opacities || !sh)) SGS_FAIL(ctx, SGS_ERR_INVALID, "null input array");
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    sgs_scene* sc = new (std::nothrow) sgs_scene;
+    if (!sc) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+    const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
+    sc->n = n; sc->n_chunks = (n + 63) / 64; sc->sh_degree = sh_degree; sc->sh_rows = (nf + 3) / 4;
+    const size_t npad = (size_t)std::max<int64_t>(sc->n_chunks, 1) * 64;
+    auto bail = [&](int code) { sgs_scene_free(ctx, sc); return code; };
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&sc->geom), npad * SGS_GEOM_ROWS * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&sc->shq), npad * sc->sh_rows * sizeof(float4))) != hipSuccess) {
+        ctx->err = std::string("sgs_scene_upload: hipMalloc: ") + hipGetErrorString(e);
+        return bail(e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP);
+    }
+    if (n > 0) {
+        const float* src[5] = {means, scales, quats, opacities, sh};
+        const size_t cnt[5] = {(size_t)n * 3, (size_t)n * 3, (size_t)n * 4, (size_t)n, (size_t)n * nf};
+        float* staged[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        const float* dev[5];
+        int rc = SGS_OK;
+        for (int i = 0; i < 5 && rc == SGS_OK; ++i) {
+            if (on_device) { dev[i] = src[i]; continue; }
+            if ((e = hipMalloc(reinterpret_cast<void**>(&staged[i]), cnt[i] * sizeof(float))) != hipSuccess ||
+                (e = hipMemcpy(staged[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
+                ctx->err = std::string("sgs_scene_upload: staging: ") + hipGetErrorString(e);
+                rc = e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
+            }
+            dev[i] = staged[i];
+        }
+        if (rc == SGS_OK) {
+            const unsigned grid = (unsigned)((npad + 255) / 256);
+            hipLaunchKernelGGL(sgs::k_scene_layout, dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows,
+                               dev[0], dev[1], dev[2], dev[3], dev[4], sc->geom, sc->shq);
+            if ((e = hipDeviceSynchronize()) != hipSuccess) {
+                ctx->err = std::string("sgs_scene_upload: k_scene_layout: ") + hipGetErrorString(e);
+                rc = SGS_ERR_HIP;
+            }
+        }
+        for (float* p : staged) if (p) (void)hipFree(p);
+        if (rc != SGS_OK) return bail(rc);
+    }
+    *out = sc;
+    return SGS_OK;
+}
+
+int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene) {
+    if (!scene) return SGS_OK;
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); }
+    if (scene->geom) (void)hipFree(scene->geom);
+    if (scene->shq) (void)hipFree(scene->shq);
+    delete scene;
+    return SGS_OK;
+}
+
+int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (ctx->last_slot < 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "no frame has been issued");
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    SGS_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
+    collect(ctx, ctx->last_slot, stats, ctx->last_n, ctx->last_tiles, ctx->last_pixels, ctx->last_sh_rows, ctx->last_timed);
+    const FrameStatus& s = ctx->h_status[ctx->last_slot];
+    if (s.overflow)
+        SGS_FAIL(ctx, SGS_ERR_OVERFLOW, "frame needs %u records, capacity is %lld (sgs_set_record_capacity)",
+                 s.d_total, (long long)ctx->rec_cap);
+    return SGS_OK;
+}
+
+int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg_in,
+               int tile_row_begin, int tile_row_end, float* out_rgb, sgs_stats* stats, void* hip_stream) {
+    if (!ctx) return SGS_ERR_INVALID;
+    int rc;
+    if ((rc = validate(ctx, scene, cam, cfg_in, tile_row_begin, tile_row_end, out_rgb)) != SGS_OK) return rc;
+    sgs_config cfg;
+    if (cfg_in) cfg = *cfg_in; else sgs_config_default(&cfg);
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    const bool timed = (cfg.flags & SGS_FLAG_TIMING) != 0;
+    ctx->last_retries = 0;
+    for (;;) {
+        const int slot = ctx->next_slot;
+        ctx->next_slot = (ctx->next_slot + 1) % kStatusRing;
+        if ((rc = enqueue_frame(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, timed)) != SGS_OK)
+            return rc;
+        if (cfg.flags & SGS_FLAG_ASYNC) return SGS_OK;
+        rc = sgs_frame_sync(ctx, stats);
+        if (rc != SGS_ERR_OVERFLOW) return rc;
+        // synchronous path: grow the queues to fit and render again
+        const int64_t need = (int64_t)ctx->h_status[slot].d_total;
+        ctx->rec_cap_wanted = std::max<int64_t>(need + need / 4, ctx->rec_cap * 2);
+        ctx->rec_cap = 0;
+        if ((rc = ensure_records(ctx)) != SGS_OK) return rc;
+        if (++ctx->last_retries > 4) SGS_FAIL(ctx, SGS_ERR_OVERFLOW, "record capacity still too small after 4 retries");
+    }
+}
+
+int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
+                     const sgs_config* cfg_in, int tile_row_begin, int tile_row_end, float* out_rgb,
+                     sgs_stats* stats, void* hip_stream) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (n_cams < 0 || (n_cams > 0 && !cams)) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad camera array");
+    sgs_config cfg;
+    if (cfg_in) cfg = *cfg_in; else sgs_config_default(&cfg);
+    cfg.flags &= ~(uint32_t)SGS_FLAG_TIMING;       // per-stage events are a single-frame facility
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    ctx->last_retries = 0;
+    int rc;
+    for (int c0 = 0; c0 < n_cams; c0 += kStatusRing) {
+        const int cn = std::min(kStatusRing, n_cams - c0);
+        int64_t px[kStatusRing]; int tl[kStatusRing];
+        for (int i = 0; i < cn; ++i) {
+            int rb = tile_row_begin, re = tile_row_end;
+            float* out = out_rgb + (size_t)(c0 + i) * cams[c0 + i].width * cams[c0 + i].height * 3;
+            if ((rc = validate(ctx, scene, &cams[c0 + i], &cfg, rb, re, out)) != SGS_OK) return rc;
+            if ((rc = enqueue_frame(ctx, scene, &cams[c0 + i], cfg, rb, re, out, i, stream, false)) != SGS_OK) return rc;
+            px[i] = ctx->last_pixels; tl[i] = ctx->last_tiles;
+        }
+        SGS_HIP(ctx, hipStreamSynchronize(stream));
+        for (int i = 0; i < cn; ++i) {
+            if (stats) collect(ctx, i, stats + c0 + i, scene->n, tl[i], px[i], scene->sh_rows, false);
+            if (ctx->h_status[i].overflow) {
+                // redo this one frame synchronously (grows the queues), then carry on
+                int rb = tile_row_begin, re = tile_row_end;
+                float* out = out_rgb + (size_t)(c0 + i) * cams[c0 + i].width * cams[c0 + i].height * 3;
+                sgs_config c1 = cfg; c1.flags &= ~(uint32_t)SGS_FLAG_ASYNC;
+                if ((rc = sgs_render(ctx, scene, &cams[c0 + i], &c1, rb, re, out, stats ? stats + c0 + i : nullptr, hip_stream)) != SGS_OK)
+                    return rc;
+            }
+        }
+        ctx->next_slot = 0;
+    }
+    return SGS_OK;
+}
+
+int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int height, void* hip_stream) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (!rgb || !rgba || width <= 0 || height <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad pack arguments");
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    const long long n = (long long)width * height;
+    hipLaunchKernelGGL(sgs::k_pack_rgba8, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(hip_stream), rgb, reinterpret_cast<unsigned*>(rgba), n);
+    SGS_HIP(ctx, hipGetLastError());
+    return SGS_OK;
+}
+
+int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (ctx->last_slot < 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "no frame has been rendered");
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    SGS_HIP(ctx, hipDeviceSynchronize());
+    const FrameStatus& s = ctx->h_status[ctx->last_slot];
+    const void* src = nullptr;
+    int64_t have = 0;
+    switch (what) {
+        case SGS_BUF_TILE_OFFSETS: src = ctx->tile_offset; have = ((int64_t)ctx->last_T + 1) * 4; break;
+        case SGS_BUF_SORTED_SLOTS: src = ctx->rec_val; have = (int64_t)s.d_total * 4; break;
+        case SGS_BUF_SLOT_IDS: src = ctx->slot_id; have = (int64_t)s.n_visible * 4; break;
+        case SGS_BUF_SPLATS: src = ctx->splats; have = (int64_t)s.n_visible * (int64_t)sizeof(Splat); break;
+        default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
+    }
+    if (s.overflow && what == SGS_BUF_SORTED_SLOTS) have = 0;
+    const int64_t n = std::min(have, bytes);
+    if (n > 0 && host_dst) SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    return have;
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+// sgs_common.h — types shared by the host side (sgs_api.hip) and the gfx950 kernels (sgs_kernels.h).
+// Data layout in HBM is described in DESIGN.md §3.
+#pragma once
+#include <stdint.h>
+
+#define SGS_WAVE 64                 // CDNA wavefront width; every wave idiom below assumes it
+#define SGS_TILE_PX 16
+#define SGS_GEOM_ROWS 3             // float4 rows per Gaussian in the scene geometry block
+#define SGS_MAX_SH_ROWS 12          // ceil(48 floats / 4) at SH degree 3
+
+// Radix sort (S5)
+#define SGS_RADIX_BITS 8
+#define SGS_RADIX (1 << SGS_RADIX_BITS)
+#define SGS_SORT_CLASSES 4          // S / M / L (LDS-resident) and X (spill: ping-pong in HBM)
+#define SGS_CAP_S 1024
+#define SGS_CAP_M 4096
+#define SGS_CAP_L 9216
+#define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
+
+// Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).
+struct FrameParams {
+    float view[12];                 // rows 0..2 of the model->camera matrix (row-major 3x4)
+    double campos[3];               // camera centre in model space
+    float fx, fy, cx, cy;
+    float near_z, far_z, dilation, clamp;
+    float alpha_min, alpha_max, t_min;
+    float bg[3];
+    int32_t width, height, gx, gy;
+    int32_t row_begin, row_end;     // tile rows rendered by this call
+    int32_t sh_degree;              // degree evaluated
+    int32_t sh_rows;                // float4 rows per Gaussian stored in the scene (by scene degree)
+    int64_t n;                      // Gaussians
+    int64_t n_chunks;               // ceil(n / 64)
+    int64_t rec_capacity;           // records the queues can hold
+    uint32_t flags;
+    uint32_t pad_;
+};
+
+// Device-resident per-frame status; zeroed by a memset node at frame start, copied to pinned host
+// memory at frame end.
+struct FrameStatus {
+    uint32_t n_visible;             // N_v (also the compaction cursor of k_preprocess)
+    uint32_t d_total;               // D
+    uint32_t overflow;              // D > rec_capacity: emit/sort/composite did nothing
+    uint32_t max_tile_len;
+    uint32_t class_count[SGS_SORT_CLASSES];   // tiles per sort class
+    unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
+    uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
+    uint32_t pad_[5];
+};
+
+// One projected Gaussian ("splat"), 48 B, three aligned 16-B words.
+//   a = (x, y, conic_a, conic_b)   b = (conic_c, opacity, r, g)
+//   c = (b, depth bits, rect x0|y0<<16, rect x1|y1<<16)          (last three are bit patterns)
+struct Splat {
+    float ax, ay, aca, acb;
+    float bcc, bo, br, bg;
+    float cb; uint32_t key; uint32_t rect01; uint32_t rect23;
+};

@@ -1,0 +1,658 @@
+// sgs_kernels.h — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the 3DGS forward path.
+//
+// Stage map (BASELINE.json north_star):
+//   k_scene_layout   upload-time re-layout of the scene into wave-chunked float4 rows (A5)
+//   k_preprocess     S1 SH colour, S2 EWA projection (fp64 geometry), S3 AABB -> tile rect,
+//                    wave-ballot compaction of survivors, balanced per-tile counting (S4 part 1)
+//   k_tile_scan      S4: exclusive scan of the per-tile counts, sort-class lists
+//   k_emit           S4: duplication of each splat into the queues of the tiles it touches
+//   k_tile_sort      S5: per-tile LSD radix sort on the fp32 depth bits, LDS-resident, ties -> index
+//   k_composite      S6: front-to-back alpha composite, LDS-staged queue batches
+//   k_pack_rgba8     fp32 RGB -> uint8 RGBA (get_rgba()-shaped surface)
+//
+// None of these has a counterpart in the reference (it has no rasterizer); the
+// arithmetic follows SURVEY.md §8(a) rows S1-S6 and is checked against oracle/ by tests/.
+#pragma once
+#include "sgs_common.h"
+
+namespace sgs {
+
+// ------------------------------------------------------------------------------------------------
+// wave64 helpers
+__device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x, int lane) {
+#pragma unroll
+    for (int d = 1; d < SGS_WAVE; d <<= 1) {
+        unsigned v = __shfl_up(x, d);
+        if (lane >= d) x += v;
+    }
+    return x;
+}
+
+__device__ __forceinline__ unsigned wave_max(unsigned x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v > x ? v : x; }
+    return x;
+}
+__device__ __forceinline__ unsigned wave_min(unsigned x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v < x ? v : x; }
+    return x;
+}
+
+// Balanced duplication: lane l owns `cnt` records laid out row-major over a rect of width w at
+// (x0,y0).  All 64 lanes then walk the wave's concatenated record list 64 at a time, so a Gaussian
+// covering 400 tiles costs the wave the same as 400 Gaussians covering one.  For every record the
+// callback gets (valid, tile index, p0/p1 of the owning lane).  Must be called wave-uniformly.
+template <class F>
+__device__ __forceinline__ void wave_expand(unsigned cnt, unsigned x0, unsigned y0, unsigned w,
+                                            unsigned p0, unsigned p1, int gx, int lane, F&& f) {
+    const unsigned incl = wave_incl_scan(cnt, lane);
+    const unsigned total = __shfl(incl, SGS_WAVE - 1);
+    const unsigned excl = incl - cnt;
+    const float rw = 1.0f / (float)(w ? w : 1u);
+    for (unsigned base = 0; base < total; base += SGS_WAVE) {
+        const unsigned k = base + (unsigned)lane;
+        unsigned lo = 0;                       // number of lanes whose inclusive sum is <= k
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const unsigned v = __shfl(incl, (int)(lo + step - 1));
+            if (v <= k) lo += step;
+        }
+        const int o = (int)(lo & 63u);
+        const unsigned oe = __shfl(excl, o), ow = __shfl(w, o), ox = __shfl(x0, o), oy = __shfl(y0, o);
+        const unsigned op0 = __shfl(p0, o), op1 = __shfl(p1, o);
+        const float orw = __shfl(rw, o);
+        const bool valid = k < total;
+        const unsigned idx = k - oe;
+        // idx / ow without an integer divide: exact for idx < 2^21 (tests/test_kernel_logic.py)
+        const unsigned ty = (unsigned)(((float)idx + 0.5f) * orw);
+        const unsigned tx = idx - ty * ow;
+        f(valid, (oy + ty) * (unsigned)gx + ox + tx, op0, op1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
+// row (64 lanes x 16 B).  geom rows: (mx,my,mz,opacity) (sx,sy,sz,qw) (qx,qy,qz,0).
+// sh rows: the (deg+1)^2*3 floats of a Gaussian, 4 per row, zero padded.
+__global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floats, int sh_rows,
+                                                      const float* __restrict__ means,
+                                                      const float* __restrict__ scales,
+                                                      const float* __restrict__ quats,
+                                                      const float* __restrict__ opac,
+                                                      const float* __restrict__ sh,
+                                                      float4* __restrict__ geom,
+                                                      float4* __restrict__ shq) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n_pad = ((n + SGS_WAVE - 1) / SGS_WAVE) * SGS_WAVE;
+    if (i >= n_pad) return;
+    const long long chunk = i >> 6;
+    const int lane = (int)(i & 63);
+    float4 g0 = make_float4(0.f, 0.f, -1.0e30f, 0.f), g1 = make_float4(1.f, 1.f, 1.f, 1.f),
+           g2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+        g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+        g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
+        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], 0.f);
+    }
+    geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
+    geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
+    geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane] = g2;
+    for (int r = 0; r < sh_rows; ++r) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = 4 * r + c;
+            v[c] = (i < n && k < n_sh_floats) ? sh[i * n_sh_floats + k] : 0.f;
+        }
+        shq[(chunk * sh_rows + r) * SGS_WAVE + lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S1: SH colour.  `row0` points at this lane's float4 in row 0 of its chunk; rows are 64 float4 apart.
+template <int DEG>
+__device__ __forceinline__ void eval_sh(const float4* __restrict__ row0, float x, float y, float z,
+                                        float& out_r, float& out_g, float& out_b) {
+    constexpr int NF = 3 * (DEG + 1) * (DEG + 1);
+    constexpr int ROWS = (NF + 3) / 4;
+    float c[ROWS * 4];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const float4 v = row0[r * SGS_WAVE];
+        c[4 * r] = v.x; c[4 * r + 1] = v.y; c[4 * r + 2] = v.z; c[4 * r + 3] = v.w;
+    }
+    float res[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+#define SGS_S(k) c[3 * (k) + ch]
+        float r = 0.28209479177387814f * SGS_S(0);
+        if (DEG >= 1) {
+            r = r - 0.4886025119029199f * y * SGS_S(1) + 0.4886025119029199f * z * SGS_S(2)
+                  - 0.4886025119029199f * x * SGS_S(3);
+        }
+        if (DEG >= 2) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            r = r + 1.0925484305920792f * xy * SGS_S(4) - 1.0925484305920792f * yz * SGS_S(5)
+                  + 0.31539156525252005f * (2.0f * zz - xx - yy) * SGS_S(6)
+                  - 1.0925484305920792f * xz * SGS_S(7) + 0.5462742152960396f * (xx - yy) * SGS_S(8);
+            if (DEG >= 3) {
+                r = r - 0.5900435899266435f * y * (3.0f * xx - yy) * SGS_S(9)
+                      + 2.890611442640554f * xy * z * SGS_S(10)
+                      - 0.4570457994644658f * y * (4.0f * zz - xx - yy) * SGS_S(11)
+                      + 0.3731763325901154f * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * SGS_S(12)
+                      - 0.4570457994644658f * x * (4.0f * zz - xx - yy) * SGS_S(13)
+                      + 1.445305721320277f * z * (xx - yy) * SGS_S(14)
+                      - 0.5900435899266435f * x * (xx - 3.0f * yy) * SGS_S(15);
+            }
+        }
+#undef SGS_S
+        r += 0.5f;
+        res[ch] = r < 0.f ? 0.f : r;
+    }
+    out_r = res[0]; out_g = res[1]; out_b = res[2];
+}
+
+// floor(v) clamped to [lo, hi]; NaN -> lo.  Mirrors clampi() of oracle/sgs_oracle.c.
+__device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
+    const double f = floor(v);
+    if (!(f > (double)lo)) return lo;
+    if (f > (double)hi) return hi;
+    return (int)f;
+}
+
+// S1-S3 + compaction + per-tile counting.  One lane = one Gaussian, one wave = one 64-Gaussian
+// chunk of the scene (all loads are full 1-KiB rows).  Geometry runs in fp64 (MI355X fp64 vector
+// rate is 1/2 of fp32 and this kernel is HBM-bound), which makes every integer decision (cull,
+// radius, rect, tile counts) agree with the fp64 oracle.
+__global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
+                                                    const float4* __restrict__ geom,
+                                                    const float4* __restrict__ shq,
+                                                    Splat* __restrict__ splats,
+                                                    unsigned* __restrict__ slot_id,
+                                                    unsigned* __restrict__ tile_count,
+                                                    FrameStatus* __restrict__ st) {
+    const int lane = threadIdx.x & 63;
+    const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (chunk >= P.n_chunks) return;                       // wave-uniform
+    const long long id = chunk * SGS_WAVE + lane;
+
+    const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
+    const double mx = g0.x, my = g0.y, mz = g0.z;
+    const double tx = (double)P.view[0] * mx + (double)P.view[1] * my + (double)P.view[2] * mz + (double)P.view[3];
+    const double ty = (double)P.view[4] * mx + (double)P.view[5] * my + (double)P.view[6] * mz + (double)P.view[7];
+    const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
+    const bool front = id < P.n && tz > (double)P.near_z && tz <= (double)P.far_z;
+
+    bool vis = false;
+    unsigned cnt = 0, rx0 = 0, ry0 = 0, rw = 0, rect01 = 0, rect23 = 0;
+    float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    if (front) {
+        const float4 g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
+        const float4 g2 = geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane];
+        // S2: Sigma = R S S^T R^T
+        const double qw0 = g1.w, qx0 = g2.x, qy0 = g2.y, qz0 = g2.z;
+        const double qn = sqrt(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
+        const double w = qw0 / qn, x = qx0 / qn, y = qy0 / qn, z = qz0 / qn;
+        const double s0 = g1.x, s1 = g1.y, s2 = g1.z;
+        const double M00 = (1 - 2 * (y * y + z * z)) * s0, M01 = (2 * (x * y - w * z)) * s1, M02 = (2 * (x * z + w * y)) * s2;
+        const double M10 = (2 * (x * y + w * z)) * s0, M11 = (1 - 2 * (x * x + z * z)) * s1, M12 = (2 * (y * z - w * x)) * s2;
+        const double M20 = (2 * (x * z - w * y)) * s0, M21 = (2 * (y * z + w * x)) * s1, M22 = (1 - 2 * (x * x + y * y)) * s2;
+        const double S00 = M00 * M00 + M01 * M01 + M02 * M02;
+        const double S01 = M00 * M10 + M01 * M11 + M02 * M12;
+        const double S02 = M00 * M20 + M01 * M21 + M02 * M22;
+        const double S11 = M10 * M10 + M11 * M11 + M12 * M12;
+        const double S12 = M10 * M20 + M11 * M21 + M12 * M22;
+        const double S22 = M20 * M20 + M21 * M21 + M22 * M22;
+        // S2: EWA projection, cov' = J W Sigma W^T J^T + dilation I
+        const double fx = P.fx, fy = P.fy;
+        const double limx = (double)P.clamp * (0.5 * (double)P.width / fx);
+        const double limy = (double)P.clamp * (0.5 * (double)P.height / fy);
+        const double txc = fmin(limx, fmax(-limx, tx / tz)) * tz;
+        const double tyc = fmin(limy, fmax(-limy, ty / tz)) * tz;
+        const double j00 = fx / tz, j02 = -fx * txc / (tz * tz);
+        const double j11 = fy / tz, j12 = -fy * tyc / (tz * tz);
+        const double T00 = j00 * (double)P.view[0] + j02 * (double)P.view[8];
+        const double T01 = j00 * (double)P.view[1] + j02 * (double)P.view[9];
+        const double T02 = j00 * (double)P.view[2] + j02 * (double)P.view[10];
+        const double T10 = j11 * (double)P.view[4] + j12 * (double)P.view[8];
+        const double T11 = j11 * (double)P.view[5] + j12 * (double)P.view[9];
+        const double T12 = j11 * (double)P.view[6] + j12 * (double)P.view[10];
+        const double U00 = T00 * S00 + T01 * S01 + T02 * S02;
+        const double U01 = T00 * S01 + T01 * S11 + T02 * S12;
+        const double U02 = T00 * S02 + T01 * S12 + T02 * S22;
+        const double U10 = T10 * S00 + T11 * S01 + T12 * S02;
+        const double U11 = T10 * S01 + T11 * S11 + T12 * S12;
+        const double U12 = T10 * S02 + T11 * S12 + T12 * S22;
+        const double a = U00 * T00 + U01 * T01 + U02 * T02 + (double)P.dilation;
+        const double b = U00 * T10 + U01 * T11 + U02 * T12;
+        const double c = U10 * T10 + U11 * T11 + U12 * T12 + (double)P.dilation;
+        const double det = a * c - b * b;
+        if (det > 0.0) {
+            // S3: 3-sigma radius, pixel AABB -> tile rect (clipped to this call's tile rows)
+            const double mid = 0.5 * (a + c);
+            const double lam = mid + sqrt(fmax(0.1, mid * mid - det));
+            const double radius = ceil(3.0 * sqrt(lam));
+            const double px = fx * tx / tz + (double)P.cx - 0.5;
+            const double py = fy * ty / tz + (double)P.cy - 0.5;
+            const int x0 = tile_clamp((px - radius) / SGS_TILE_PX, 0, P.gx);
+            const int x1 = tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gx);
+            const int y0 = tile_clamp((py - radius) / SGS_TILE_PX, P.row_begin, P.row_end);
+            const int y1 = tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, P.row_begin, P.row_end);
+            const int nt = (x1 - x0) * (y1 - y0);
+            if (nt > 0) {
+                vis = true;
+                cnt = (unsigned)nt; rx0 = (unsigned)x0; ry0 = (unsigned)y0; rw = (unsigned)(x1 - x0);
+                rect01 = (unsigned)x0 | ((unsigned)y0 << 16);
+                rect23 = (unsigned)x1 | ((unsigned)y1 << 16);
+                sx = (float)px; sy = (float)py;
+                ca = (float)(c / det); cb = (float)(-b / det); cc = (float)(a / det);
+            }
+        }
+    }
+
+    // wave-ballot compaction: one atomic per wave hands out a block of slots
+    const unsigned long long vmask = __ballot(vis);
+    const unsigned nvis = (unsigned)__popcll(vmask);
+    if (nvis == 0) return;                                  // wave-uniform: whole chunk culled
+    unsigned base = 0;
+    if (lane == 0) base = atomicAdd(&st->n_visible, nvis);
+    base = __shfl(base, 0);
+    const unsigned slot = base + (unsigned)__popcll(vmask & lanemask_lt(lane));
+
+    if (vis) {
+        // S1: view direction in model space (fp64 difference, fp32 polynomial)
+        const double dx = mx - P.campos[0], dy = my - P.campos[1], dz = mz - P.campos[2];
+        const double dn = sqrt(dx * dx + dy * dy + dz * dz);
+        const float ux = (float)(dx / dn), uy = (float)(dy / dn), uz = (float)(dz / dn);
+        const float4* row0 = shq + (chunk * P.sh_rows) * SGS_WAVE + lane;
+        float r, g, b;
+        switch (P.sh_degree) {
+            case 0: eval_sh<0>(row0, ux, uy, uz, r, g, b); break;
+            case 1: eval_sh<1>(row0, ux, uy, uz, r, g, b); break;
+            case 2: eval_sh<2>(row0, ux, uy, uz, r, g, b); break;
+            default: eval_sh<3>(row0, ux, uy, uz, r, g, b); break;
+        }
+        const float depth = (float)tz;
+        float4* sp = reinterpret_cast<float4*>(splats + slot);
+        sp[0] = make_float4(sx, sy, ca, cb);
+        sp[1] = make_float4(cc, g0.w, r, g);
+        sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
+        slot_id[slot] = (unsigned)id;
+    }
+
+    // S4 part 1: per-tile counts
+    wave_expand(cnt, rx0, ry0, rw, 0u, 0u, P.gx, lane,
+                [&](bool valid, unsigned tile, unsigned, unsigned) {
+                    if (valid) atomicAdd(&tile_count[tile], 1u);
+                });
+}
+
+// ------------------------------------------------------------------------------------------------
+// S4: exclusive scan of tile counts (single workgroup; T <= 32400 at 4K), D, longest queue, and
+// the per-class tile lists the sort launches walk.  tile_fill is set to the queue length so that
+// k_emit can hand out slots with atomicSub.
+#define SGS_SCAN_THREADS 1024
+__global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
+                                                                const unsigned* __restrict__ tile_count,
+                                                                unsigned* __restrict__ tile_offset,
+                                                                unsigned* __restrict__ tile_fill,
+                                                                unsigned* __restrict__ class_list,
+                                                                FrameStatus* __restrict__ st) {
+    __shared__ unsigned s_wsum[SGS_SCAN_THREADS / SGS_WAVE];
+    __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
+    __shared__ unsigned s_class[SGS_SORT_CLASSES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = P.gx * P.gy;
+    const int per = (T + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS;
+    const int beg = tid * per, end = min(T, beg + per);
+    if (tid < SGS_SORT_CLASSES) s_class[tid] = 0;
+    unsigned sum = 0, mx = 0;
+    for (int t = beg; t < end; ++t) { const unsigned c = tile_count[t]; sum += c; mx = c > mx ? c : mx; }
+    const unsigned incl = wave_incl_scan(sum, lane);
+    const unsigned wmx = wave_max(mx);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 0) s_wmax[wave] = wmx;
+    __syncthreads();
+    unsigned wbase = 0, total = 0, tmax = 0;
+    for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) {
+        const unsigned s = s_wsum[w];
+        if (w < wave) wbase += s;
+        total += s;
+        tmax = s_wmax[w] > tmax ? s_wmax[w] : tmax;
+    }
+    unsigned run = wbase + incl - sum;
+    const bool overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity;
+    for (int t = beg; t < end; ++t) {
+        const unsigned c = tile_count[t];
+        tile_offset[t] = run;
+        tile_fill[t] = c;
+        run += c;
+        if (c > 1 && !overflow) {
+            const int cls = c <= SGS_CAP_S ? 0 : (c <= SGS_CAP_M ? 1 : (c <= SGS_CAP_L ? 2 : 3));
+            const unsigned k = atomicAdd(&s_class[cls], 1u);
+            class_list[(size_t)cls * T + k] = (unsigned)t;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        tile_offset[T] = total;
+        st->d_total = total;
+        st->max_tile_len = tmax;
+        st->overflow = overflow ? 1u : 0u;
+    }
+    if (tid < SGS_SORT_CLASSES) st->class_count[tid] = s_class[tid];
+}
+
+// ------------------------------------------------------------------------------------------------
+// S4 part 2: duplication.  Walks the compacted splats 64 at a time (grid-stride over waves), expands
+// each rect into its tiles with the same balanced scheme as the counting pass, and drops
+// (depth bits, slot) into the tile's queue.  Slots inside a queue are handed out by atomics, so the
+// queue order is arbitrary here; k_tile_sort makes it deterministic.
+__global__ __launch_bounds__(256) void k_emit(const FrameParams P, const Splat* __restrict__ splats,
+                                              const unsigned* __restrict__ tile_offset,
+                                              unsigned* __restrict__ tile_fill,
+                                              unsigned* __restrict__ rec_key,
+                                              unsigned* __restrict__ rec_val,
+                                              const FrameStatus* __restrict__ st) {
+    if (st->overflow) return;
+    const int lane = threadIdx.x & 63;
+    const unsigned nvis = st->n_visible;
+    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
+    const unsigned wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    for (unsigned long long c0 = (unsigned long long)wave0 * SGS_WAVE; c0 < nvis;
+         c0 += (unsigned long long)waves_total * SGS_WAVE) {
+        const unsigned s = (unsigned)c0 + (unsigned)lane;
+        unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
+        if (s < nvis) {
+            const float4 c = reinterpret_cast<const float4*>(splats + s)[2];
+            key = __float_as_uint(c.y);
+            const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
+            x0 = r01 & 0xffffu; y0 = r01 >> 16;
+            w = (r23 & 0xffffu) - x0;
+            cnt = w * ((r23 >> 16) - y0);
+        }
+        wave_expand(cnt, x0, y0, w, key, s, P.gx, lane,
+                    [&](bool valid, unsigned tile, unsigned okey, unsigned oslot) {
+                        if (valid) {
+                            const unsigned k = atomicSub(&tile_fill[tile], 1u) - 1u;
+                            const unsigned dst = tile_offset[tile] + k;
+                            rec_key[dst] = okey;
+                            rec_val[dst] = oslot;
+                        }
+                    });
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S5: per-tile LSD radix sort.  One workgroup (4 waves) per tile; the queue lives in LDS (classes
+// S/M/L) or ping-pongs between two HBM buffers (class X, queues longer than SGS_CAP_L).
+//
+// One pass = per-wave digit histogram (LDS atomics) -> scan -> stable scatter.  Each wave owns a
+// contiguous segment of the queue and walks it a row (64 keys) at a time; the lanes of a row that
+// share a digit find each other with 8 wave ballots (one per digit bit), the lowest of them bumps
+// the wave's running offset for that digit and broadcasts it.  No cross-wave traffic inside a pass.
+struct SortShared {
+    unsigned hist[4][SGS_RADIX];
+    unsigned wsum[4];
+    unsigned kmin, kmax, flag;
+};
+
+__device__ __forceinline__ void radix_pass(const unsigned* src_k, const unsigned* src_v,
+                                           unsigned* dst_k, unsigned* dst_v, unsigned n,
+                                           unsigned sub, unsigned shift, SortShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned rows_total = (n + 63u) >> 6;
+    const unsigned rows_per_wave = (rows_total + 3u) >> 2;
+    const unsigned seg_beg = min(n, (unsigned)wave * rows_per_wave * 64u);
+    const unsigned seg_end = min(n, seg_beg + rows_per_wave * 64u);
+    // (1) zero
+#pragma unroll
+    for (int w = 0; w < 4; ++w) sh.hist[w][tid] = 0;
+    __syncthreads();
+    // (2) per-wave digit counts
+    for (unsigned i = seg_beg + lane; i < seg_end; i += 64)
+        atomicAdd(&sh.hist[wave][((src_k[i] - sub) >> shift) & (SGS_RADIX - 1)], 1u);
+    __syncthreads();
+    // (3) exclusive scan over (digit major, wave minor)
+    {
+        const unsigned c0 = sh.hist[0][tid], c1 = sh.hist[1][tid], c2 = sh.hist[2][tid], c3 = sh.hist[3][tid];
+        const unsigned tot = c0 + c1 + c2 + c3;
+        const unsigned incl = wave_incl_scan(tot, lane);
+        if (lane == 63) sh.wsum[wave] = incl;
+        __syncthreads();
+        unsigned ex = incl - tot;
+        for (int w = 0; w < wave; ++w) ex += sh.wsum[w];
+        sh.hist[0][tid] = ex; sh.hist[1][tid] = ex + c0; sh.hist[2][tid] = ex + c0 + c1;
+        sh.hist[3][tid] = ex + c0 + c1 + c2;
+    }
+    __syncthreads();
+    // (4) stable scatter, row by row
+    const unsigned rows_mine = (seg_end - seg_beg + 63u) >> 6;
+    for (unsigned r = 0; r < rows_mine; ++r) {
+        const unsigned i = seg_beg + r * 64u + lane;
+        const bool valid = i < seg_end;
+        const unsigned k = valid ? src_k[i] : 0u;
+        const unsigned v = valid ? src_v[i] : 0u;
+        const unsigned d = ((k - sub) >> shift) & (SGS_RADIX - 1);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < SGS_RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(valid && bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const unsigned rank = (unsigned)__popcll(peers & lanemask_lt(lane));
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        unsigned base = 0;
+        if (valid && rank == 0) base = atomicAdd(&sh.hist[wave][d], (unsigned)__popcll(peers));
+        base = __shfl(base, leader);
+        if (valid) { dst_k[base + rank] = k; dst_v[base + rank] = v; }
+    }
+    __syncthreads();
+}
+
+// Sorts (k,v)[0..n) by ((k - sub) bits [0, nbits)), result back in (a_k, a_v).
+__device__ __forceinline__ void radix_sort_bits(unsigned* a_k, unsigned* a_v, unsigned* b_k, unsigned* b_v,
+                                                unsigned n, unsigned sub, unsigned nbits, SortShared& sh) {
+    unsigned *sk = a_k, *sv = a_v, *dk = b_k, *dv = b_v;
+    for (unsigned shift = 0; shift < nbits; shift += SGS_RADIX_BITS) {
+        radix_pass(sk, sv, dk, dv, n, sub, shift, sh);
+        unsigned* t = sk; sk = dk; dk = t;
+        t = sv; sv = dv; dv = t;
+    }
+    if (sk != a_k) {
+        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) { a_k[i] = sk[i]; a_v[i] = sv[i]; }
+        __syncthreads();
+    }
+}
+
+template <int CAP, bool SPILL>
+__global__ __launch_bounds__(256) void k_tile_sort(const FrameParams P, int cls,
+                                                   const unsigned* __restrict__ tile_offset,
+                                                   const unsigned* __restrict__ class_list,
+                                                   unsigned* rec_key, unsigned* rec_val,
+                                                   unsigned* alt_key, unsigned* alt_val,
+                                                   const unsigned* __restrict__ slot_id,
+                                                   const Splat* __restrict__ splats,
+                                                   FrameStatus* st) {
+    __shared__ SortShared sh;
+    __shared__ unsigned s_buf[SPILL ? 4 : 4 * CAP];
+    if (st->overflow) return;
+    if (blockIdx.x >= st->class_count[cls]) return;
+    const int tid = threadIdx.x;
+    const unsigned tile = class_list[(size_t)cls * (P.gx * P.gy) + blockIdx.x];
+    const unsigned beg = tile_offset[tile];
+    const unsigned n = tile_offset[tile + 1] - beg;
+
+    unsigned *a_k, *a_v, *b_k, *b_v;
+    if (SPILL) { a_k = rec_key + beg; a_v = rec_val + beg; b_k = alt_key + beg; b_v = alt_val + beg; }
+    else { a_k = s_buf; a_v = s_buf + CAP; b_k = s_buf + 2 * CAP; b_v = s_buf + 3 * CAP; }
+
+    if (tid == 0) { sh.kmin = 0xffffffffu; sh.kmax = 0u; sh.flag = 0u; }
+    __syncthreads();
+    // load (LDS classes) and per-tile key range: only the bits that differ inside this tile are sorted
+    unsigned kmn = 0xffffffffu, kmx = 0u;
+    for (unsigned i = tid; i < n; i += 256) {
+        const unsigned k = rec_key[beg + i];
+        if (!SPILL) { a_k[i] = k; a_v[i] = rec_val[beg + i]; }
+        kmn = k < kmn ? k : kmn; kmx = k > kmx ? k : kmx;
+    }
+    kmn = wave_min(kmn); kmx = wave_max(kmx);
+    if ((tid & 63) == 0) { atomicMin(&sh.kmin, kmn); atomicMax(&sh.kmax, kmx); }
+    __syncthreads();
+    const unsigned sub = sh.kmin;
+    const unsigned span = sh.kmax - sub;
+    const unsigned nbits = span ? 32u - (unsigned)__clz((int)span) : 0u;
+    radix_sort_bits(a_k, a_v, b_k, b_v, n, sub, nbits, sh);
+
+    // Equal depth bits must order by Gaussian index.  Runs of equal keys are
+    // contiguous now; short ones are fixed in place by their first lane, a long one flags the tile.
+    for (unsigned i = tid; i + 1 < n; i += 256) {
+        const unsigned k = a_k[i];
+        if (a_k[i + 1] == k && (i == 0 || a_k[i - 1] != k)) {
+            unsigned e = i + 2;
+            while (e < n && a_k[e] == k) ++e;
+            if (e - i > SGS_TIE_RUN_MAX) { atomicOr(&sh.flag, 1u); }
+            else {
+                for (unsigned p = i + 1; p < e; ++p) {
+                    const unsigned v = a_v[p], idv = slot_id[v];
+                    unsigned q = p;
+                    while (q > i && slot_id[a_v[q - 1]] > idv) { a_v[q] = a_v[q - 1]; --q; }
+                    a_v[q] = v;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (sh.flag) {
+        // rare: stable two-key sort — first by Gaussian index, then by depth bits
+        for (unsigned i = tid; i < n; i += 256) a_k[i] = slot_id[a_v[i]];
+        __syncthreads();
+        const unsigned idbits = P.n > 1 ? 64u - (unsigned)__clzll((long long)(P.n - 1)) : 1u;
+        radix_sort_bits(a_k, a_v, b_k, b_v, n, 0u, idbits, sh);
+        for (unsigned i = tid; i < n; i += 256) a_k[i] = splats[a_v[i]].key;
+        __syncthreads();
+        radix_sort_bits(a_k, a_v, b_k, b_v, n, sub, nbits, sh);
+        if (tid == 0) atomicAdd(&st->n_resort_tiles, 1u);
+    }
+    if (!SPILL) {
+        for (unsigned i = tid; i < n; i += 256) rec_val[beg + i] = a_v[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// S6: front-to-back alpha composite.  One workgroup per 16x16 tile, one lane per pixel; each wave
+// owns an 8x8 quadrant.  The tile's sorted queue is streamed through LDS in batches of 256 splats
+// (each lane gathers one 48-B splat), then every lane walks the batch with broadcast LDS reads.
+// Block b is mapped so that consecutive blocks on one XCD (b % 8) render neighbouring tiles, which
+// share most of their splats -> the gathers hit that XCD's L2.
+#define SGS_BATCH 256
+__global__ __launch_bounds__(256) void k_composite(const FrameParams P,
+                                                   const unsigned* __restrict__ tile_offset,
+                                                   const unsigned* __restrict__ rec_val,
+                                                   const Splat* __restrict__ splats,
+                                                   float* __restrict__ out_rgb,
+                                                   FrameStatus* st) {
+    __shared__ float4 s_a[SGS_BATCH];
+    __shared__ float4 s_b[SGS_BATCH];
+    __shared__ float s_c[SGS_BATCH];
+    __shared__ unsigned s_live[2];       // waves with an unfinished pixel, double-buffered by batch parity
+    __shared__ unsigned s_used[4];
+    if (st->overflow) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // XCD-aware remap of the block index over this call's tiles
+    const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
+    const unsigned per_xcd = (ntiles + 7u) / 8u;
+    const unsigned b = blockIdx.x;
+    const unsigned t_local = (b & 7u) * per_xcd + (b >> 3);
+    if (t_local >= ntiles) return;       // workgroup-uniform
+    const unsigned tile = (unsigned)(P.row_begin * P.gx) + t_local;
+    const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
+    const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
+    const unsigned py = tile_y * 16u + (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
+    const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
+    const float fpx = (float)px, fpy = (float)py;
+
+    const unsigned beg = tile_offset[tile];
+    const unsigned n = tile_offset[tile + 1] - beg;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    bool done = !inside;
+    unsigned used = 0;                   // records this pixel examined (D_f bookkeeping)
+
+    if (tid < 2) s_live[tid] = 0;
+    __syncthreads();
+    unsigned it = 0;
+    for (unsigned base = 0; base < n; base += SGS_BATCH, ++it) {
+        const bool wave_live = __ballot(!done) != 0ull;
+        if (lane == 0 && wave_live) atomicAdd(&s_live[it & 1u], 1u);
+        // gather this batch: each lane fetches one 48-B splat
+        const unsigned m = min((unsigned)SGS_BATCH, n - base);
+        if ((unsigned)tid < m) {
+            const unsigned s = rec_val[beg + base + tid];
+            const float4* sp = reinterpret_cast<const float4*>(splats + s);
+            s_a[tid] = sp[0];
+            s_b[tid] = sp[1];
+            s_c[tid] = sp[2].x;
+        }
+        __syncthreads();                 // batch staged, liveness counted
+        if (s_live[it & 1u] == 0) break; // every pixel of the tile has terminated (uniform)
+        if (wave_live) {
+            for (unsigned j = 0; j < m; ++j) {
+                if ((j & 15u) == 0u && __ballot(!done) == 0ull) break;   // wave-uniform early out
+                if (!done) {
+                    const float4 A = s_a[j];
+                    const float4 B = s_b[j];
+                    used = base + j + 1u;
+                    const float dx = A.x - fpx, dy = A.y - fpy;
+                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                    if (power <= 0.0f) {
+                        const float alpha = fminf(P.alpha_max, B.y * __expf(power));
+                        if (alpha >= P.alpha_min) {
+                            const float testT = T * (1.0f - alpha);
+                            if (testT < P.t_min) done = true;
+                            else {
+                                const float wgt = alpha * T;
+                                C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * s_c[j];
+                                T = testT;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                 // batch consumed by every wave; s_live[it&1] read by all
+        if (tid == 0) s_live[it & 1u] = 0;   // next used two batches from now
+    }
+    if (inside) {
+        float* o = out_rgb + ((size_t)py * P.width + px) * 3;
+        o[0] = C0 + T * P.bg[0]; o[1] = C1 + T * P.bg[1]; o[2] = C2 + T * P.bg[2];
+    }
+    if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = max over the tile's pixels
+        const unsigned wu = wave_max(inside ? used : 0u);
+        __syncthreads();
+        if (lane == 0) s_used[wave] = wu;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned u = s_used[0];
+            for (int w = 1; w < 4; ++w) u = s_used[w] > u ? s_used[w] : u;
+            atomicAdd(&st->d_fetched, (unsigned long long)u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 RGB -> uint8 RGBA, alpha 255; values clamped to [0,1], round to nearest.
+__global__ __launch_bounds__(256) void k_pack_rgba8(const float* __restrict__ rgb,
+                                                    unsigned* __restrict__ rgba, long long n_px) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    const float r = fminf(fmaxf(rgb[3 * i], 0.f), 1.f), g = fminf(fmaxf(rgb[3 * i + 1], 0.f), 1.f),
+                b = fminf(fmaxf(rgb[3 * i + 2], 0.f), 1.f);
+    rgba[i] = (unsigned)(r * 255.0f + 0.5f) | ((unsigned)(g * 255.0f + 0.5f) << 8) |
+              ((unsigned)(b * 255.0f + 0.5f) << 16) | 0xff000000u;
+}
+
+}  // namespace sgs

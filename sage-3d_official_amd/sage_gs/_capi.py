@@ -1,0 +1,116 @@
+"""ctypes binding of include/sage_gs.h — plain pointers and PODs, no torch.
+
+The product loads exactly one library: ``sage-3d_official_amd/lib/libsage_gs.so`` (built by
+``__graft_entry__.build()`` with hipcc for gfx950).  If it is missing, import of the renderer fails
+loudly; there is no CPU fallback behind this binding.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+NUM_STAGES = 5
+STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "composite")
+
+FLAG_ASYNC, FLAG_TIMING, FLAG_STATS = 1, 2, 4
+BACKEND_CPU, BACKEND_HIP = 0, 1
+BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS = 0, 1, 2, 3
+
+ERR_NAMES = {-1: "SGS_ERR_INVALID", -2: "SGS_ERR_HIP", -3: "SGS_ERR_OOM", -4: "SGS_ERR_OVERFLOW",
+             -5: "SGS_ERR_BACKEND"}
+
+DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib",
+                           "libsage_gs.so")
+
+# every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
+EXPORTS = ("sgs_version", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
+           "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_free", "sgs_render",
+           "sgs_render_batch", "sgs_frame_sync", "sgs_pack_rgba8", "sgs_debug_read")
+
+
+class SgsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class SgsCamera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("view", C.c_float * 16)]
+
+
+class SgsConfig(C.Structure):
+    _fields_ = [("near_z", C.c_float), ("far_z", C.c_float), ("dilation", C.c_float),
+                ("clamp", C.c_float), ("alpha_min", C.c_float), ("alpha_max", C.c_float),
+                ("t_min", C.c_float), ("bg", C.c_float * 3), ("sh_degree", C.c_int32),
+                ("flags", C.c_uint32)]
+
+
+class SgsStats(C.Structure):
+    _fields_ = [("n_gaussians", C.c_int64), ("n_visible", C.c_int64), ("d_total", C.c_int64),
+                ("d_fetched", C.c_int64), ("n_pixels", C.c_int64), ("n_tiles", C.c_int32),
+                ("max_tile_len", C.c_int32), ("n_spill_tiles", C.c_int32), ("retries", C.c_int32),
+                ("ms", C.c_float * NUM_STAGES), ("ms_total", C.c_float),
+                ("bytes", C.c_int64 * NUM_STAGES)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("ms", "bytes")}
+        d["ms"] = {n: float(self.ms[i]) for i, n in enumerate(STAGE_NAMES)}
+        d["bytes"] = {n: int(self.bytes[i]) for i, n in enumerate(STAGE_NAMES)}
+        return d
+
+
+class Lib:
+    """A loaded libsage_gs.so with typed entry points."""
+
+    def __init__(self, path=None):
+        path = path or os.environ.get("SAGE_GS_LIB") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C sage-3d_official_amd). There is no CPU fallback.")
+        self.path = path
+        lib = self._lib = C.CDLL(path)
+        vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+        lib.sgs_version.restype = i32
+        lib.sgs_config_default.argtypes = [C.POINTER(SgsConfig)]; lib.sgs_config_default.restype = None
+        lib.sgs_create.argtypes = [i32, i32, C.POINTER(vp)]
+        lib.sgs_destroy.argtypes = [vp]
+        lib.sgs_last_error.argtypes = [vp]; lib.sgs_last_error.restype = C.c_char_p
+        lib.sgs_set_record_capacity.argtypes = [vp, i64]
+        lib.sgs_scene_upload.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]
+        lib.sgs_scene_free.argtypes = [vp, vp]
+        lib.sgs_render.argtypes = [vp, vp, C.POINTER(SgsCamera), C.POINTER(SgsConfig), i32, i32, vp,
+                                   C.POINTER(SgsStats), vp]
+        lib.sgs_render_batch.argtypes = [vp, vp, C.POINTER(SgsCamera), i32, C.POINTER(SgsConfig), i32,
+                                         i32, vp, C.POINTER(SgsStats), vp]
+        lib.sgs_frame_sync.argtypes = [vp, C.POINTER(SgsStats)]
+        lib.sgs_pack_rgba8.argtypes = [vp, vp, vp, i32, i32, vp]
+        lib.sgs_debug_read.argtypes = [vp, i32, vp, i64]; lib.sgs_debug_read.restype = i64
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+    def check(self, rc, ctx=None):
+        if rc < 0:
+            msg = self._lib.sgs_last_error(ctx)
+            raise SgsError(int(rc), (msg or b"").decode("utf-8", "replace"))
+        return rc
+
+    def version(self):
+        return int(self._lib.sgs_version())
+
+    def default_config(self):
+        cfg = SgsConfig()
+        self._lib.sgs_config_default(C.byref(cfg))
+        return cfg
+
+
+def make_camera(width, height, fx, fy, cx, cy, view):
+    cam = SgsCamera(int(width), int(height), float(fx), float(fy), float(cx), float(cy))
+    flat = [float(v) for row in view for v in (row if hasattr(row, "__len__") else [row])]
+    if len(flat) != 16:
+        raise ValueError("view must be 4x4")
+    for i in range(16):
+        cam.view[i] = flat[i]
+    return cam

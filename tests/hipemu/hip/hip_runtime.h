@@ -1,0 +1,261 @@
+// tests/hipemu/hip/hip_runtime.h — a wave64 SIMT *emulator* for unit-testing kernel logic on a host
+// without a GPU.  TEST INFRASTRUCTURE ONLY: it is not a backend, it is never built into or loaded by
+// the product (libsage_gs.so is compiled by hipcc against the real <hip/hip_runtime.h>), and
+// nothing under sage-3d_official_amd/ refers to it.  tests/ compile the product's own
+// csrc/sgs_api.hip + csrc/sgs_kernels.h against this header with g++ so that the CPU test-suite can
+// exercise the exact kernel source (ballot/shuffle compaction, LDS radix sort, composite) against
+// the oracle before a GPU box is involved.
+//
+// Execution model: every workgroup runs its threads as ucontext fibers on one OS thread; a fiber
+// runs until it reaches a workgroup barrier or a wave collective and then yields.  Collectives
+// rendezvous over the lanes of a wave that are still alive (as the hardware's exec mask does for
+// wave-uniform control flow — the only way the kernels use them).  Workgroups run in parallel on
+// OpenMP threads, so global atomics are real atomics.
+#pragma once
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <time.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define SGS_HIPEMU 1
+
+// ---- language surface ---------------------------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+namespace hipemu {
+
+constexpr size_t kStackBytes = 256 * 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    char* stack = nullptr;
+    bool finished = true;
+    dim3 tid;
+};
+
+struct WaveState {
+    unsigned long long vals[2][64];
+    unsigned long long part[2];
+    unsigned long long cur_mask = 0;
+    int arrived = 0, alive = 0;
+    unsigned gen = 0;
+};
+
+struct BlockExec {
+    std::vector<Fiber> fibers;
+    std::vector<WaveState> waves;
+    ucontext_t sched;
+    int cur = 0, nthreads = 0, alive = 0, bar_arrived = 0;
+    unsigned bar_gen = 0;
+    dim3 bid, bdim, gdim;
+    const std::function<void()>* body = nullptr;
+};
+
+inline BlockExec*& exec() { static thread_local BlockExec* e = nullptr; return e; }
+
+inline void yield() { BlockExec* e = exec(); swapcontext(&e->fibers[e->cur].ctx, &e->sched); }
+
+inline void wave_release(WaveState& w) {
+    const int p = w.gen & 1;
+    w.part[p] = w.cur_mask; w.cur_mask = 0; w.arrived = 0; w.gen++;
+}
+
+// Rendezvous of the wave's live lanes; returns the parity slot holding everybody's value.
+inline int collective(unsigned long long v) {
+    BlockExec* e = exec();
+    const unsigned t = e->fibers[e->cur].tid.x;
+    WaveState& w = e->waves[t >> 6];
+    const int lane = t & 63;
+    const unsigned g = w.gen;
+    const int p = g & 1;
+    w.vals[p][lane] = v;
+    w.cur_mask |= 1ull << lane;
+    if (++w.arrived == w.alive) wave_release(w);
+    else while (w.gen == g) yield();
+    return p;
+}
+
+inline void fiber_exit_bookkeeping(BlockExec* e) {
+    Fiber& f = e->fibers[e->cur];
+    f.finished = true;
+    e->alive--;
+    WaveState& w = e->waves[f.tid.x >> 6];
+    w.alive--;
+    if (w.alive > 0 && w.arrived == w.alive) wave_release(w);
+    if (e->alive > 0 && e->bar_arrived == e->alive) { e->bar_arrived = 0; e->bar_gen++; }
+}
+
+inline void fiber_entry() {
+    BlockExec* e = exec();
+    (*e->body)();
+    fiber_exit_bookkeeping(e);
+    swapcontext(&e->fibers[e->cur].ctx, &e->sched);
+}
+
+inline void run_block(BlockExec* e, dim3 bid, dim3 bdim, dim3 gdim, const std::function<void()>& body) {
+    const int n = (int)bdim.x;
+    if ((int)e->fibers.size() < n) {
+        const size_t old = e->fibers.size();
+        e->fibers.resize(n);
+        for (size_t i = old; i < (size_t)n; ++i) {
+            e->fibers[i].stack = (char*)mmap(nullptr, kStackBytes, PROT_READ | PROT_WRITE,
+                                             MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            if (e->fibers[i].stack == (char*)MAP_FAILED) { perror("hipemu: mmap"); abort(); }
+        }
+    }
+    e->waves.assign((n + 63) / 64, WaveState());
+    e->nthreads = n; e->alive = n; e->bar_arrived = 0; e->bar_gen = 0;
+    e->bid = bid; e->bdim = bdim; e->gdim = gdim; e->body = &body;
+    for (int i = 0; i < n; ++i) {
+        Fiber& f = e->fibers[i];
+        f.finished = false; f.tid = dim3((unsigned)i);
+        e->waves[i >> 6].alive++;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStackBytes; f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+    }
+    long spins = 0;
+    while (e->alive > 0) {
+        for (int i = 0; i < n; ++i) {
+            if (e->fibers[i].finished) continue;
+            e->cur = i;
+            swapcontext(&e->sched, &e->fibers[i].ctx);
+        }
+        if (++spins > 50000000L) { fprintf(stderr, "hipemu: deadlock (divergent collective/barrier?)\n"); abort(); }
+    }
+}
+
+inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
+    const long nblocks = (long)grid.x * grid.y * grid.z;
+#pragma omp parallel
+    {
+        static thread_local BlockExec* mine = nullptr;
+        if (!mine) mine = new BlockExec;
+        exec() = mine;
+#pragma omp for schedule(dynamic, 1)
+        for (long b = 0; b < nblocks; ++b)
+            run_block(mine, dim3((unsigned)(b % grid.x), (unsigned)((b / grid.x) % grid.y), (unsigned)(b / ((long)grid.x * grid.y))),
+                      block, grid, body);
+    }
+}
+
+inline Fiber& me() { BlockExec* e = exec(); return e->fibers[e->cur]; }
+template <class T> inline unsigned long long bits(T v) { unsigned long long b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template <class T> inline T unbits(unsigned long long b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+template <class T> inline T shfl_from(T v, int src) {
+    BlockExec* e = exec();
+    const unsigned t = e->fibers[e->cur].tid.x;
+    const int p = collective(bits(v));
+    WaveState& w = e->waves[t >> 6];
+    if (src < 0 || src > 63 || !((w.part[p] >> src) & 1ull)) return v;
+    return unbits<T>(w.vals[p][src]);
+}
+
+}  // namespace hipemu
+
+#define threadIdx (hipemu::me().tid)
+#define blockIdx (hipemu::exec()->bid)
+#define blockDim (hipemu::exec()->bdim)
+#define gridDim (hipemu::exec()->gdim)
+
+// ---- device intrinsics used by the kernels ------------------------------------------------------
+static inline void __syncthreads() {
+    hipemu::BlockExec* e = hipemu::exec();
+    const unsigned g = e->bar_gen;
+    if (++e->bar_arrived == e->alive) { e->bar_arrived = 0; e->bar_gen++; }
+    else while (e->bar_gen == g) hipemu::yield();
+}
+static inline unsigned long long __ballot(bool pred) {
+    hipemu::BlockExec* e = hipemu::exec();
+    const unsigned t = e->fibers[e->cur].tid.x;
+    const int p = hipemu::collective(pred ? 1ull : 0ull);
+    hipemu::WaveState& w = e->waves[t >> 6];
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l)
+        if (((w.part[p] >> l) & 1ull) && w.vals[p][l]) m |= 1ull << l;
+    return m;
+}
+template <class T> static inline T __shfl(T v, int src) { return hipemu::shfl_from(v, src & 63); }
+template <class T> static inline T __shfl_up(T v, int d) { return hipemu::shfl_from(v, (int)(hipemu::me().tid.x & 63) - d); }
+template <class T> static inline T __shfl_xor(T v, int d) { return hipemu::shfl_from(v, (int)((hipemu::me().tid.x & 63) ^ (unsigned)d)); }
+
+static inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicSub(unsigned* p, unsigned v) { return __atomic_fetch_sub(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+static inline unsigned atomicMin(unsigned* p, unsigned v) {
+    unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+#define __expf(x) expf(x)
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline unsigned max(unsigned a, unsigned b) { return a > b ? a : b; }
+
+// ---- host runtime surface used by sgs_api.hip ---------------------------------------------------
+typedef enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorInvalidValue = 1 } hipError_t;
+typedef enum { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3 } hipMemcpyKind;
+typedef void* hipStream_t;
+typedef struct hipemu_event { double t; }* hipEvent_t;
+
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = aligned_alloc(256, ((n + 255) / 256) * 256);
+    if (*p) memset(*p, 0xCD, n);            // poison: uninitialised reads show up
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipemu_event{0.0}; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); e->t = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; return hipSuccess;
+}
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
