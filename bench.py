@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py — frames/sec of the 3DGS scene-render hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one frame: one pass of the hot path (SH -> projection -> AABB -> binning -> per-tile sort
+-> composite) over the whole scene for one camera of the seeded pose list, scene already resident in
+HBM (uploaded once per scene, as the reference loads a stage once — generate_images.py:320-327).
+Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on — a ~3 M-Gaussian
+synthetic InteriorGS-like scene, SH degree 3, 1920x1080 (InteriorGS itself is not available offline).
+N > 1: the frame is sharded by tile row across the ranks and gathered to rank 0 over RCCL/xGMI
+(configs[3]); total work per frame is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0 with the contract's fields plus `roofline` (dominant kernel, measured
+live with HIP events on the launch stream) and `cpu_baseline` (the oracle's C port on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=3_000_000, help="scene size (default: BASELINE configs[2])")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--shard", choices=("rows", "cameras"), default="rows",
+                    help="N>1: tile-row shards + RCCL gather (default, BASELINE configs[3]) or camera shards")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, cams, budget_s):
+    """The oracle's C port (fp32 build, OpenMP over all host cores) on a bounded sample of the SAME
+    workload: whole frames of the same scene/poses until the budget is spent (>= 1, <= 4 frames)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle_c
+    import oracle_np
+    oracle_c.build()
+    cores = oracle_c.max_threads()
+    n, t_total = 0, 0.0
+    for cam in cams[:4]:
+        view = (np.asarray(cam.view) @ scene.model_to_world).astype(np.float32)
+        ocam = oracle_np.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+        t0 = time.perf_counter()
+        oracle_c.render(*scene.as_tuple(), ocam, threads=0, real="f32", want="image")
+        t_total += time.perf_counter() - t0
+        n += 1
+        if t_total >= budget_s:
+            break
+    return {"value": n / t_total, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} full frame(s) of the same scene and pose list (oracle/sgs_oracle.c, fp32 build, "
+                      f"OpenMP x{cores}), {t_total:.1f} s"}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from sage_gs import Renderer, scenes
+    from sage_gs._capi import STAGE_NAMES
+    from sage_gs.dist import ShardedRenderer, shard_cameras
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- workload: deterministic synthetic scene + pose list (identical on every rank) ---------------
+    scene = scenes.make_room(args.gaussians, seed=2)
+    cams = scenes.room_cameras(scene, args.width, args.height, n_positions=4, n_yaw=64, seed=2)
+    r = Renderer(device, record_capacity=96 << 20)
+    gs = r.upload(scenes.to_gaussians(scene, device))
+    K, W = args.steps, args.warmup
+    timing = not args.no_events
+
+    sharded = ShardedRenderer(r, args.height, args.width) if (world > 1 and args.shard == "rows") else None
+    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device)
+
+    issued = [0]
+
+    def step(i, timed):
+        cam = cams[i % len(cams)]
+        if sharded is not None:
+            r0, r1 = sharded.g.band
+            if r1 > r0:
+                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=(r0, r1), sync=False, timing=timed)
+                issued[0] += 1
+            sharded.g.gather()
+        elif world > 1:                      # camera shards: rank renders every world-th frame of the sweep
+            if i % world == rank:
+                r.render(cam, gs, out=frame, sync=False, timing=timed)
+                issued[0] += 1
+        else:
+            r.render(cam, gs, out=frame, sync=False, timing=timed)
+            issued[0] += 1
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(W):
+        step(i, False)
+    if issued[0]:
+        r.sync()                                          # also grows nothing: capacity is fixed up front
+    issued[0] = 0
+    fence()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(W + i, timing)
+    fence()
+    elapsed = time.perf_counter() - t0
+    avg = r.sync() if issued[0] else None                 # checks EVERY frame of the region for overflow
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-frame algorithmic bytes of the same K frames (deterministic; outside the timed region) --
+    stage_bytes = {n: 0 for n in STAGE_NAMES}
+    counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
+    if rank == 0:
+        rows = None if sharded is None else sharded.g.band
+        for i in range(K):
+            if world > 1 and args.shard == "cameras" and (W + i) % world != rank:
+                continue
+            cam = cams[(W + i) % len(cams)]
+            if rows is None:
+                r.render(cam, gs, out=frame)
+            else:
+                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=rows)
+            st = r.last_stats
+            for n in STAGE_NAMES:
+                stage_bytes[n] += st["bytes"][n]
+            for k in ("n_visible", "d_total", "d_fetched"):
+                counts[k] += st[k]
+            counts["max_tile_len"] = max(counts["max_tile_len"], st["max_tile_len"])
+            counts["n_spill_tiles"] += st["n_spill_tiles"]
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        frames_here = K if not (world > 1 and args.shard == "cameras") else len(range(rank, K, world))
+        out = {
+            "metric": "frames/sec, 3M-Gaussian InteriorGS-like scene @1080p (+ achieved HBM GB/s in roofline)",
+            "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+            "scaling": "strong" if (world == 1 or args.shard == "rows") else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[2]: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
+                                   f"SH deg 3, {args.width}x{args.height}, reference lens (8/20.955), 256-pose yaw sweep",
+                       "parallelism": "1 GPU" if world == 1 else
+                                      (f"tile-row shard x{world} + RCCL gather to rank 0" if args.shard == "rows"
+                                       else f"camera shard x{world}"),
+                       "per_frame": {k: (v / max(1, frames_here) if k not in ("max_tile_len",) else v) for k, v in counts.items()}},
+        }
+        if avg is not None and timing and frames_here > 0:
+            ms = avg["ms"]
+            stages = {}
+            for n in STAGE_NAMES:
+                b = stage_bytes[n] / frames_here
+                stages[n] = {"ms": ms[n], "alg_bytes": b, "GBps": (b / (ms[n] * 1e-3) / 1e9) if ms[n] > 0 else None}
+            dom = max(STAGE_NAMES, key=lambda n: ms[n])
+            ach = stages[dom]["GBps"] or 0.0
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(dom)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                               "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
+                               "stages": stages, "gpu_ms_per_frame": avg["ms_total"]}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, cams[W:], args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -52,6 +52,12 @@ class Config:
     background: tuple = (0.0, 0.0, 0.0)   # A7: black, linear, un-tonemapped
     sh_degree: int = -1          # -1: use the scene's degree
 
+    def f32(self):
+        """The ABI carries these constants as fp32 (sgs_config); evaluate with the rounded values."""
+        r = lambda v: float(np.float32(v))
+        return Config(r(self.near), r(self.far), r(self.dilation), r(self.clamp), r(self.alpha_min),
+                      r(self.alpha_max), r(self.t_min), tuple(r(b) for b in self.background), self.sh_degree)
+
 
 @dataclass
 class Camera:
@@ -110,6 +116,7 @@ def preprocess(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg:
     `visible[i]` is False when the Gaussian is culled (tz <= near, tz > far, det <= 0, or its tile
     rect — clipped to tile rows [tile_row_begin, tile_row_end) — is empty).
     """
+    cfg = cfg.f32()
     means = np.asarray(means, np.float64)
     scales = np.asarray(scales, np.float64)
     quats = np.asarray(quats, np.float64)
@@ -117,7 +124,7 @@ def preprocess(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg:
     gx, gy = cam.grid
     if tile_row_end is None:
         tile_row_end = gy
-    V = np.asarray(cam.view, np.float64)
+    V = np.asarray(cam.view, np.float32).astype(np.float64)      # the ABI carries the view as fp32
     R, tvec = V[:3, :3], V[:3, 3]
 
     # world(model) -> view
@@ -138,16 +145,17 @@ def preprocess(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg:
     Sigma = M @ np.transpose(M, (0, 2, 1))      # R S S^T R^T
 
     # S2: EWA projection
-    tan_x = 0.5 * cam.width / cam.fx
-    tan_y = 0.5 * cam.height / cam.fy
+    fx, fy, cx, cy = (float(np.float32(v)) for v in (cam.fx, cam.fy, cam.cx, cam.cy))
+    tan_x = 0.5 * cam.width / fx
+    tan_y = 0.5 * cam.height / fy
     limx, limy = cfg.clamp * tan_x, cfg.clamp * tan_y
     txc = np.clip(t[:, 0] / tzs, -limx, limx) * tzs
     tyc = np.clip(t[:, 1] / tzs, -limy, limy) * tzs
     J = np.zeros((N, 2, 3))
-    J[:, 0, 0] = cam.fx / tzs
-    J[:, 0, 2] = -cam.fx * txc / (tzs * tzs)
-    J[:, 1, 1] = cam.fy / tzs
-    J[:, 1, 2] = -cam.fy * tyc / (tzs * tzs)
+    J[:, 0, 0] = fx / tzs
+    J[:, 0, 2] = -fx * txc / (tzs * tzs)
+    J[:, 1, 1] = fy / tzs
+    J[:, 1, 2] = -fy * tyc / (tzs * tzs)
     T = J @ R                                   # 2x3
     cov = T @ Sigma @ np.transpose(T, (0, 2, 1))
     a = cov[:, 0, 0] + cfg.dilation
@@ -162,8 +170,8 @@ def preprocess(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg:
     mid = 0.5 * (a + c)
     lam = mid + np.sqrt(np.maximum(0.1, mid * mid - det))
     radius = np.ceil(3.0 * np.sqrt(lam))
-    px = cam.fx * t[:, 0] / tzs + cam.cx - 0.5
-    py = cam.fy * t[:, 1] / tzs + cam.cy - 0.5
+    px = fx * t[:, 0] / tzs + cx - 0.5
+    py = fy * t[:, 1] / tzs + cy - 0.5
 
     def _tile(v, lo, hi):
         return np.clip(np.floor(v / TILE), lo, hi).astype(np.int64)
@@ -224,10 +232,12 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
 
     Returns dict(image[H,W,3], final_T[H,W], n_contrib[H,W] (index+1 of the last blended record),
     consumed[T] (records any pixel of the tile examined = the D_f term), margin[H,W]).
-    `margin` is the smallest relative distance of any examined (pixel, Gaussian) pair to one of the
-    path's discontinuities (alpha == alpha_min, T(1-alpha) == t_min): fp32 and fp64 evaluations may
-    legitimately decide differently there, and the blend then jumps by up to alpha_min*T*c.
+    `margin` is the smallest relative distance |alpha/alpha_min - 1| of any examined (pixel,
+    Gaussian) pair to the alpha cut-off: fp32 and fp64 evaluations may legitimately decide
+    differently there, and the blend then jumps by up to alpha_min*T*c.  (The other discontinuity,
+    T(1-alpha) == t_min, moves a pixel by at most t_min*c = 1e-4*c and needs no special care.)
     """
+    cfg = cfg.f32()
     gx, gy = cam.grid
     if tile_row_end is None:
         tile_row_end = gy
@@ -260,7 +270,6 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
                 mg = np.where(live, np.minimum(mg, np.abs(alpha / cfg.alpha_min - 1.0)), mg)
                 hit = live & (alpha >= cfg.alpha_min)
                 testT = T * (1.0 - alpha)
-                mg = np.where(hit, np.minimum(mg, np.abs(testT / cfg.t_min - 1.0)), mg)
                 stop = hit & (testT < cfg.t_min)
                 blend = hit & ~stop
                 C = np.where(blend[..., None], C + (alpha * T)[..., None] * rgb[g], C)

@@ -52,6 +52,7 @@ typedef struct {
     /* per pixel */
     float* image; float* final_T; int32_t* n_contrib;
     int32_t width, height;
+    float* margin;               /* per pixel: min |alpha/alpha_min - 1| over examined pairs (checker build) */
 } orc_frame;
 
 static const double C0 = 0.28209479177387814, C1 = 0.4886025119029199;
@@ -178,6 +179,7 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
         for (int px = tx * TILE; px < (tx + 1) * TILE && px < f->width; ++px) {
             real T = 1, C[3] = {0, 0, 0};
             int32_t nc = 0; int64_t k;
+            double mg = 1e30;
             for (k = 0; k < n; ++k) {
                 int32_t g = q[k];
                 real dx = (real)f->xy[2 * g] - (real)px, dy = (real)f->xy[2 * g + 1] - (real)py;
@@ -187,6 +189,9 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
                 real e = sizeof(real) == 4 ? (real)expf((float)power) : (real)exp((double)power);
                 real alpha = (real)f->opacity[g] * e;
                 if (alpha > (real)cfg->alpha_max) alpha = (real)cfg->alpha_max;
+#ifdef ORC_MARGIN
+                { double m1 = fabs((double)alpha / (double)cfg->alpha_min - 1.0); if (m1 < mg) mg = m1; }
+#endif
                 if (alpha < (real)cfg->alpha_min) continue;
                 real testT = T * (1 - alpha);
                 if (testT < (real)cfg->t_min) { ++k; break; }
@@ -199,7 +204,7 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
             f->image[3 * p] = (float)(C[0] + T * (real)cfg->bg[0]);
             f->image[3 * p + 1] = (float)(C[1] + T * (real)cfg->bg[1]);
             f->image[3 * p + 2] = (float)(C[2] + T * (real)cfg->bg[2]);
-            f->final_T[p] = (float)T; f->n_contrib[p] = nc;
+            f->final_T[p] = (float)T; f->n_contrib[p] = nc; f->margin[p] = (float)mg;
         }
     f->consumed[t] = used_max;
 }
@@ -208,7 +213,7 @@ void orc_frame_free(orc_frame* f) {
     if (!f) return;
     free(f->depth_bits); free(f->rect); free(f->tiles); free(f->xy); free(f->conic); free(f->opacity);
     free(f->rgb); free(f->offsets); free(f->ids); free(f->consumed); free(f->image); free(f->final_T);
-    free(f->n_contrib); free(f);
+    free(f->n_contrib); free(f->margin); free(f);
 }
 
 int orc_real_bytes(void) { return (int)sizeof(real); }
@@ -241,7 +246,7 @@ orc_frame* orc_render(int64_t N, int sh_degree, const float* means, const float*
     f->depth_bits = calloc(n1, 4); f->rect = calloc(n1 * 4, 4); f->tiles = calloc(n1, 4);
     f->xy = calloc(n1 * 2, 4); f->conic = calloc(n1 * 3, 4); f->opacity = calloc(n1, 4); f->rgb = calloc(n1 * 3, 4);
     f->offsets = calloc(ntile + 1, 8); f->consumed = calloc(ntile, 8);
-    f->image = calloc(P * 3 + 1, 4); f->final_T = calloc(P + 1, 4); f->n_contrib = calloc(P + 1, 4);
+    f->image = calloc(P * 3 + 1, 4); f->final_T = calloc(P + 1, 4); f->n_contrib = calloc(P + 1, 4); f->margin = calloc(P + 1, 4);
     int K = (sh_degree + 1) * (sh_degree + 1);
     int deg = cfg->sh_degree < 0 ? sh_degree : (cfg->sh_degree < sh_degree ? cfg->sh_degree : sh_degree);
     const float* V = cam->view;

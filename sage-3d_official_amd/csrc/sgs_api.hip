@@ -59,8 +59,11 @@ struct sgs_ctx {
     int last_tiles = 0, last_sh_rows = 0, last_T = 0;
     int last_retries = 0;
     hipStream_t last_stream = nullptr;
-    hipEvent_t ev[SGS_NUM_STAGES + 1] = {};
-    bool have_events = false;
+    // frames issued since the last synchronisation (ring slots pending_begin .. +pending_count)
+    int pending_begin = 0, pending_count = 0;
+    // per-slot event sets for SGS_FLAG_TIMING, created on first use
+    hipEvent_t (*ev)[SGS_NUM_STAGES + 1] = nullptr;
+    bool slot_timed[256] = {};
 };
 
 #define SGS_FAIL(ctx, code, ...)                                  \
@@ -172,28 +175,39 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     fill_params(P, ctx, scene, cam, cfg, row_begin, row_end);
     FrameStatus* st = ctx->d_status + slot;
     SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[0], stream));
+    hipEvent_t* ev = nullptr;
+    if (timed) {
+        if (!ctx->ev) {
+            ctx->ev = new (std::nothrow) hipEvent_t[kStatusRing][SGS_NUM_STAGES + 1];
+            if (!ctx->ev) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+            for (int i = 0; i < kStatusRing; ++i)
+                for (int j = 0; j <= SGS_NUM_STAGES; ++j) SGS_HIP(ctx, hipEventCreate(&ctx->ev[i][j]));
+        }
+        ev = ctx->ev[slot];
+    }
+    ctx->slot_timed[slot] = timed;
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
     if (scene->n_chunks > 0) {
         const unsigned grid = (unsigned)((scene->n_chunks + 3) / 4);
         hipLaunchKernelGGL(sgs::k_preprocess, dim3(grid), dim3(256), 0, stream, P, scene->geom, scene->shq,
                            ctx->splats, ctx->slot_id, ctx->tile_count, st);
     }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[1], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     // the scan copies the counts into tile_fill (k_emit's slot dispenser); tile_count is then cleared
     // for the next frame
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
                        ctx->tile_offset, ctx->tile_fill, ctx->class_list, st);
     SGS_HIP(ctx, hipMemsetAsync(ctx->tile_count, 0, ((size_t)gx * gy + 1) * sizeof(unsigned), stream));
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[2], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (scene->n_chunks > 0) {
         const unsigned grid = (unsigned)std::min<int64_t>((scene->n_chunks + 3) / 4, 2048);
         hipLaunchKernelGGL(sgs::k_emit, dim3(grid), dim3(256), 0, stream, P, ctx->splats, ctx->tile_offset,
                            ctx->tile_fill, ctx->rec_key, ctx->rec_val, st);
     }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[3], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0 && scene->n_chunks > 0) {
@@ -210,14 +224,14 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
                            ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
                            ctx->alt_val, ctx->slot_id, ctx->splats, st);
     }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[4], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
 
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
         hipLaunchKernelGGL(sgs::k_composite, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset,
                            ctx->rec_val, ctx->splats, out_rgb, st);
     }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ctx->ev[5], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[5], stream));
     SGS_HIP(ctx, hipGetLastError());
     SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
 
@@ -251,13 +265,14 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
     stats->bytes[SGS_STAGE_SORT] = 12 * D;
     stats->bytes[SGS_STAGE_COMPOSITE] = 40 * Df + 12 * pixels;
-    if (timed) {
+    if (timed && ctx->ev) {
+        hipEvent_t* ev = ctx->ev[slot];
         for (int i = 0; i < SGS_NUM_STAGES; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]) == hipSuccess) stats->ms[i] = ms;
+            if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) stats->ms[i] = ms;
         }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[SGS_NUM_STAGES]) == hipSuccess) stats->ms_total = ms;
+        if (hipEventElapsedTime(&ms, ev[0], ev[SGS_NUM_STAGES]) == hipSuccess) stats->ms_total = ms;
     }
 }
 
@@ -302,9 +317,6 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
-    for (auto& ev : ctx->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return fail("hipEventCreate", e);
-    ctx->have_events = true;
     if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
         const long long v = atoll(env);
         if (v > 0) ctx->rec_cap_wanted = v;
@@ -321,7 +333,11 @@ int sgs_destroy(sgs_ctx* ctx) {
                     ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
-    if (ctx->have_events) for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+    if (ctx->ev) {
+        for (int i = 0; i < kStatusRing; ++i)
+            for (int j = 0; j <= SGS_NUM_STAGES; ++j) (void)hipEventDestroy(ctx->ev[i][j]);
+        delete[] ctx->ev;
+    }
     delete ctx;
     return SGS_OK;
 }
@@ -404,10 +420,29 @@ int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats) {
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     SGS_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     collect(ctx, ctx->last_slot, stats, ctx->last_n, ctx->last_tiles, ctx->last_pixels, ctx->last_sh_rows, ctx->last_timed);
-    const FrameStatus& s = ctx->h_status[ctx->last_slot];
-    if (s.overflow)
-        SGS_FAIL(ctx, SGS_ERR_OVERFLOW, "frame needs %u records, capacity is %lld (sgs_set_record_capacity)",
-                 s.d_total, (long long)ctx->rec_cap);
+    // every frame issued since the previous synchronisation is checked, not just the last one
+    int bad = -1, n_bad = 0;
+    double ms_sum[SGS_NUM_STAGES + 1] = {};
+    int n_timed = 0;
+    for (int k = 0; k < ctx->pending_count; ++k) {
+        const int slot = (ctx->pending_begin + k) % kStatusRing;
+        if (ctx->h_status[slot].overflow) { bad = slot; ++n_bad; }
+        if (ctx->slot_timed[slot] && ctx->ev) {
+            float ms = 0.f;
+            for (int i = 0; i < SGS_NUM_STAGES; ++i)
+                if (hipEventElapsedTime(&ms, ctx->ev[slot][i], ctx->ev[slot][i + 1]) == hipSuccess) ms_sum[i] += ms;
+            if (hipEventElapsedTime(&ms, ctx->ev[slot][0], ctx->ev[slot][SGS_NUM_STAGES]) == hipSuccess) ms_sum[SGS_NUM_STAGES] += ms;
+            ++n_timed;
+        }
+    }
+    if (stats && n_timed > 1) {          // several pipelined frames: report the per-frame average
+        for (int i = 0; i < SGS_NUM_STAGES; ++i) stats->ms[i] = (float)(ms_sum[i] / n_timed);
+        stats->ms_total = (float)(ms_sum[SGS_NUM_STAGES] / n_timed);
+    }
+    ctx->pending_begin = ctx->next_slot; ctx->pending_count = 0;
+    if (n_bad)
+        SGS_FAIL(ctx, SGS_ERR_OVERFLOW, "%d frame(s) overflowed the record capacity %lld (one needed %u records); "
+                 "call sgs_set_record_capacity", n_bad, (long long)ctx->rec_cap, ctx->h_status[bad].d_total);
     return SGS_OK;
 }
 
@@ -423,8 +458,13 @@ int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
     const bool timed = (cfg.flags & SGS_FLAG_TIMING) != 0;
     ctx->last_retries = 0;
     for (;;) {
+        if (ctx->pending_count == kStatusRing) {        // the status ring is full: drain it first
+            if ((rc = sgs_frame_sync(ctx, nullptr)) != SGS_OK) return rc;
+        }
         const int slot = ctx->next_slot;
         ctx->next_slot = (ctx->next_slot + 1) % kStatusRing;
+        if (ctx->pending_count == 0) ctx->pending_begin = slot;
+        ctx->pending_count++;
         if ((rc = enqueue_frame(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, timed)) != SGS_OK)
             return rc;
         if (cfg.flags & SGS_FLAG_ASYNC) return SGS_OK;
@@ -451,6 +491,7 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     ctx->last_retries = 0;
     int rc;
+    if (ctx->pending_count > 0 && (rc = sgs_frame_sync(ctx, nullptr)) != SGS_OK) return rc;
     for (int c0 = 0; c0 < n_cams; c0 += kStatusRing) {
         const int cn = std::min(kStatusRing, n_cams - c0);
         int64_t px[kStatusRing]; int tl[kStatusRing];
@@ -473,7 +514,7 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
                     return rc;
             }
         }
-        ctx->next_slot = 0;
+        ctx->next_slot = 0; ctx->pending_begin = 0; ctx->pending_count = 0;
     }
     return SGS_OK;
 }

@@ -1,0 +1,301 @@
+"""`render(camera, gaussians)` — the Python call surface of the MI355X 3DGS scene renderer.
+
+Host code stays Python on PyTorch-ROCm (device memory, streams); every frame is one call into the
+C ABI of ``libsage_gs.so`` (include/sage_gs.h) with raw device pointers.  This module stands where the
+reference's Isaac Sim render step stood:
+
+    reference                                             here
+    ----------------------------------------------------  ---------------------------------------
+    open_stage(usd)  (simple_env.py:219)                   Renderer.upload(gaussians) -> Scene
+    cam.set_world_pose(position, orientation) (:1284)      Camera(view=...) / camera.from_isaac_pose
+    world.step(render=True)x2 ; cam.get_rgba() (:1368-80)  Renderer.render(camera, scene)
+    frame loop (generate_images.py:408-436)                Renderer.render_batch(cameras, scene)
+
+There is no CPU fallback: importing this module needs the built HIP library, rendering needs a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _capi
+
+
+@dataclass
+class Camera:
+    """Pinhole camera, +Z forward / +X right / +Y down.  `view` is world->camera (4x4, rigid)."""
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    view: np.ndarray = field(default_factory=lambda: np.eye(4))
+
+    @property
+    def tile_rows(self) -> int:
+        return (self.height + 15) // 16
+
+    @property
+    def tile_cols(self) -> int:
+        return (self.width + 15) // 16
+
+
+@dataclass
+class RenderConfig:
+    """Constants of stages S2-S6; defaults are the canonical values."""
+    near: float = 0.2
+    far: float = 1.0e30
+    dilation: float = 0.3
+    clamp: float = 1.3
+    alpha_min: float = 1.0 / 255.0
+    alpha_max: float = 0.99
+    t_min: float = 1.0e-4
+    background: Sequence[float] = (0.0, 0.0, 0.0)
+    sh_degree: int = -1
+
+
+@dataclass
+class Gaussians:
+    """A 3DGS scene with activations applied: linear scales, (w,x,y,z) quaternions,
+    opacities in (0,1), SH coefficients [N,(d+1)^2,3].  `model_to_world` is the asset transform of
+    Data/template.usda:115-124 (rotateXYZ -90,0,0 for SAGE-3D scenes); it is applied by moving the
+    camera into model space, which is exact for rigid transforms."""
+    means: torch.Tensor
+    scales: torch.Tensor
+    quats: torch.Tensor
+    opacities: torch.Tensor
+    sh: torch.Tensor
+    sh_degree: int
+    model_to_world: Optional[np.ndarray] = None
+
+    def __len__(self):
+        return int(self.means.shape[0])
+
+
+class Scene:
+    """Device-resident, re-laid-out copy of a Gaussians object (wave-chunked float4 rows)."""
+
+    def __init__(self, renderer: "Renderer", handle, n, sh_degree, model_to_world):
+        self._r, self.handle, self.n, self.sh_degree = renderer, handle, n, sh_degree
+        self.model_to_world = None if model_to_world is None else np.asarray(model_to_world, np.float64)
+
+    def free(self):
+        if self.handle:
+            self._r._lib.sgs_scene_free(self._r._ctx, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _as_f32(t: torch.Tensor, device, shape_tail):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(np.asarray(t, np.float32))
+    t = t.to(device=device, dtype=torch.float32).contiguous()
+    if tuple(t.shape[1:]) != tuple(shape_tail):
+        raise ValueError(f"expected [N,{','.join(map(str, shape_tail))}], got {tuple(t.shape)}")
+    return t
+
+
+class Renderer:
+    """One rendering context bound to one GPU (one process per GPU is the intended deployment)."""
+
+    def __init__(self, device=None, record_capacity: Optional[int] = None, lib: Optional[_capi.Lib] = None):
+        self._lib = lib or _capi.Lib()
+        if not torch.cuda.is_available():
+            raise RuntimeError("sage_gs.Renderer needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.type != "cuda":
+            raise ValueError("device must be a cuda (ROCm) device")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        ctx = C.c_void_p()
+        self._lib.check(self._lib.sgs_create(index, _capi.BACKEND_HIP, C.byref(ctx)))
+        self._ctx = ctx
+        if record_capacity:
+            self._lib.check(self._lib.sgs_set_record_capacity(ctx, int(record_capacity)), ctx)
+        self.last_stats = None
+
+    # -- scene ------------------------------------------------------------------------------------
+    def upload(self, g: Gaussians) -> Scene:
+        n = len(g)
+        k = (g.sh_degree + 1) ** 2
+        with torch.cuda.device(self.device):
+            means = _as_f32(g.means, self.device, (3,))
+            scales = _as_f32(g.scales, self.device, (3,))
+            quats = _as_f32(g.quats, self.device, (4,))
+            opac = _as_f32(g.opacities.reshape(n), self.device, ())
+            sh = _as_f32(g.sh.reshape(n, k, 3), self.device, (k, 3))
+            torch.cuda.synchronize(self.device)
+            h = C.c_void_p()
+            self._lib.check(self._lib.sgs_scene_upload(self._ctx, n, int(g.sh_degree), means.data_ptr(),
+                                                       scales.data_ptr(), quats.data_ptr(), opac.data_ptr(),
+                                                       sh.data_ptr(), 1, C.byref(h)), self._ctx)
+        return Scene(self, h, n, int(g.sh_degree), g.model_to_world)
+
+    def _scene_of(self, g):
+        if isinstance(g, Scene):
+            return g
+        cached = getattr(g, "_sgs_scene", None)
+        if cached is None or cached._r is not self or cached.handle is None:
+            cached = self.upload(g)
+            g._sgs_scene = cached
+        return cached
+
+    # -- camera / config marshalling ---------------------------------------------------------------
+    @staticmethod
+    def _c_camera(cam: Camera, scene: Scene) -> _capi.SgsCamera:
+        view = np.asarray(cam.view.detach().cpu().numpy() if isinstance(cam.view, torch.Tensor) else cam.view,
+                          np.float64).reshape(4, 4)
+        if scene.model_to_world is not None:
+            view = view @ scene.model_to_world.reshape(4, 4)
+        return _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
+                                 view.astype(np.float32).tolist())
+
+    def _c_config(self, cfg: Optional[RenderConfig], flags=0) -> _capi.SgsConfig:
+        k = self._lib.default_config()
+        if cfg is not None:
+            k.near_z, k.far_z, k.dilation, k.clamp = cfg.near, cfg.far, cfg.dilation, cfg.clamp
+            k.alpha_min, k.alpha_max, k.t_min = cfg.alpha_min, cfg.alpha_max, cfg.t_min
+            for i in range(3):
+                k.bg[i] = float(cfg.background[i])
+            k.sh_degree = int(cfg.sh_degree)
+        k.flags = flags
+        return k
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- frames -----------------------------------------------------------------------------------
+    def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
+               out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
+               tile_rows=None, timing=False, sync=True) -> torch.Tensor:
+        """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
+
+        tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
+        of `out` are left untouched.  With `out_band` (a [>=band rows, W, 3] slab) only the band is
+        stored, at the top of the slab, and the slab is returned.  sync=False enqueues on the current
+        stream without waiting (collect with .sync())."""
+        scene = self._scene_of(gaussians)
+        r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        if out_band is not None:
+            if tile_rows is None:
+                raise ValueError("out_band needs tile_rows")
+            y0, y1 = r0 * 16, min(r1 * 16, camera.height)
+            if (out_band.device != self.device or out_band.dtype != torch.float32 or not out_band.is_contiguous()
+                    or out_band.dim() != 3 or out_band.shape[0] < y1 - y0
+                    or tuple(out_band.shape[1:]) != (camera.width, 3)):
+                raise ValueError("out_band must be a contiguous float32 [>=band rows, W, 3] tensor on the device")
+            # the ABI takes the address of pixel (0,0); only the band's rows are ever dereferenced
+            ptr, ret = out_band.data_ptr() - y0 * camera.width * 3 * 4, out_band
+        else:
+            if out is None:
+                out = torch.zeros((camera.height, camera.width, 3), dtype=torch.float32, device=self.device)
+            elif (out.device != self.device or out.dtype != torch.float32 or not out.is_contiguous()
+                  or tuple(out.shape) != (camera.height, camera.width, 3)):
+                raise ValueError("out must be a contiguous float32 [H,W,3] tensor on the renderer's device")
+            ptr, ret = out.data_ptr(), out
+        flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0)
+        cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
+        self._lib.check(self._lib.sgs_render(self._ctx, scene.handle, C.byref(cam), C.byref(cfg), r0, r1,
+                                             ptr, C.byref(st), self._stream()), self._ctx)
+        self.last_stats = st.as_dict() if sync else None
+        return ret
+
+    def sync(self):
+        """Complete frames issued with sync=False; returns the statistics of the last one."""
+        st = _capi.SgsStats()
+        self._lib.check(self._lib.sgs_frame_sync(self._ctx, C.byref(st)), self._ctx)
+        self.last_stats = st.as_dict()
+        return self.last_stats
+
+    def render_batch(self, cameras: Sequence[Camera], gaussians, *, config: Optional[RenderConfig] = None,
+                     out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False):
+        """B frames of one scene back to back with a single synchronisation (camera-sweep batch)."""
+        scene = self._scene_of(gaussians)
+        b = len(cameras)
+        if b == 0:
+            raise ValueError("no cameras")
+        h, w = cameras[0].height, cameras[0].width
+        if any(c.height != h or c.width != w for c in cameras):
+            raise ValueError("all cameras of a batch must share a resolution")
+        if out is None:
+            out = torch.zeros((b, h, w, 3), dtype=torch.float32, device=self.device)
+        arr = (_capi.SgsCamera * b)(*[self._c_camera(c, scene) for c in cameras])
+        stats = (_capi.SgsStats * b)() if want_stats else None
+        r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+        cfg = self._c_config(config)
+        self._lib.check(self._lib.sgs_render_batch(self._ctx, scene.handle, arr, b, C.byref(cfg), r0, r1,
+                                                   out.data_ptr(), stats, self._stream()), self._ctx)
+        if want_stats:
+            return out, [s.as_dict() for s in stats]
+        return out
+
+    def pack_rgba8(self, rgb: torch.Tensor) -> torch.Tensor:
+        """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns."""
+        h, w = int(rgb.shape[0]), int(rgb.shape[1])
+        out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        self._lib.check(self._lib.sgs_pack_rgba8(self._ctx, rgb.contiguous().data_ptr(), out.data_ptr(), w, h,
+                                                 self._stream()), self._ctx)
+        return out
+
+    # -- test hooks -------------------------------------------------------------------------------
+    def debug_buffer(self, what, dtype):
+        have = self._lib.sgs_debug_read(self._ctx, what, None, 0)
+        if have < 0:
+            self._lib.check(int(have), self._ctx)
+        buf = np.zeros(int(have) // np.dtype(dtype).itemsize, dtype)
+        if have:
+            self._lib.sgs_debug_read(self._ctx, what, buf.ctypes.data, have)
+        return buf
+
+    def intermediates(self):
+        """(tile_offsets, per-tile sorted Gaussian ids, Gaussian id of each slot, splat words [N_v,12])."""
+        off = self.debug_buffer(_capi.BUF_TILE_OFFSETS, np.uint32).astype(np.int64)
+        slots = self.debug_buffer(_capi.BUF_SORTED_SLOTS, np.uint32)
+        ids = self.debug_buffer(_capi.BUF_SLOT_IDS, np.uint32).astype(np.int64)
+        splats = self.debug_buffer(_capi.BUF_SPLATS, np.uint32).reshape(-1, 12)
+        return off, ids[slots], ids, splats
+
+    def set_record_capacity(self, n: int):
+        self._lib.check(self._lib.sgs_set_record_capacity(self._ctx, int(n)), self._ctx)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.sgs_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default = {}
+
+
+def default_renderer(device=None) -> Renderer:
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key not in _default:
+        _default[key] = Renderer(torch.device("cuda", key))
+    return _default[key]
+
+
+def render(camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The drop-in call surface named by BASELINE.json: one frame, float32 [H,W,3] on the scene's GPU."""
+    dev = gaussians.means.device if isinstance(gaussians, Gaussians) else None
+    if dev is not None and dev.type != "cuda":
+        dev = None
+    return default_renderer(dev).render(camera, gaussians, config=config, out=out)

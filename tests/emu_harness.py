@@ -85,6 +85,9 @@ class EmuRenderer:
                                            out.ctypes.data, C.byref(st), None), self.ctx)
         return out, st.as_dict()
 
+    def set_record_capacity(self, n):
+        self.lib.check(self.lib.sgs_set_record_capacity(self.ctx, int(n)), self.ctx)
+
     def debug(self, what, dtype, count_hint=None):
         have = self.lib.sgs_debug_read(self.ctx, what, None, 0)
         if have < 0:

@@ -1,0 +1,214 @@
+"""Parity cases, written once and run twice: under the wave64 emulator on CPU (test_emu_parity.py,
+kernel LOGIC) and on a real MI355X through the C ABI (test_gpu_parity.py, the parity tests proper).
+
+A `drv` offers: upload(means, scales, quats, opac, sh, deg); render(cam, cfg=None, rows=(0,-1))
+-> (image ndarray, stats dict); intermediates() -> (tile_offsets, sorted ids, slot ids, splat words).
+Cameras/configs are oracle_np.Camera / oracle_np.Config objects.
+"""
+import math
+
+import numpy as np
+
+import oracle_c
+import oracle_np as onp
+from conftest import assert_frame_close
+
+
+def random_scene(n, seed, deg=0, box=((-2, 2), (-2, 2), (2, 8)), scale=(0.02, 0.2), opac_mu=0.0):
+    rng = np.random.default_rng(seed)
+    means = np.stack([rng.uniform(*box[0], n), rng.uniform(*box[1], n), rng.uniform(*box[2], n)], 1)
+    scales = np.exp(rng.uniform(math.log(scale[0]), math.log(scale[1]), (n, 3)))
+    quats = rng.normal(size=(n, 4)) + 1e-3
+    opac = 1.0 / (1.0 + np.exp(-rng.normal(opac_mu, 1.5, n)))
+    k = (deg + 1) ** 2
+    sh = 0.5 * rng.normal(size=(n, k, 3))
+    if k > 1:
+        sh[:, 1:] *= 0.3
+    f = lambda a: np.ascontiguousarray(a, np.float32)
+    return f(means), f(scales), f(quats), f(opac), f(sh), deg
+
+
+def look_at_view(eye, target, down=(0, 1, 0)):
+    """A rigid model->camera matrix (+Z forward, +Y roughly `down`, +X right)."""
+    eye, target, down = (np.asarray(v, float) for v in (eye, target, down))
+    z = target - eye; z /= np.linalg.norm(z)
+    x = np.cross(down, z); x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z])
+    V = np.eye(4); V[:3, :3] = R; V[:3, 3] = -R @ eye
+    return V.astype(np.float32)
+
+
+def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True, cmax=None):
+    """Full comparison of one frame: counts and queues bit-exact, splat attributes to fp32 rounding,
+    image within the parity tolerance."""
+    drv.upload(*scene)
+    img, st = drv.render(cam, cfg, rows)
+    ref, aux = oracle_c.render(*scene, cam, cfg, rows[0], rows[1])
+    assert st["n_visible"] == aux["n_visible"], (what, st["n_visible"], aux["n_visible"])
+    assert st["d_total"] == aux["D"], (what, st["d_total"], aux["D"])
+    off, ids, slot_ids, splats = drv.intermediates()
+    assert (off == aux["offsets"]).all(), f"{what}: tile offsets differ"
+    if queues:
+        assert (ids == aux["ids"]).all(), f"{what}: per-tile queue order differs from (depth bits, index) order"
+    # splat table, keyed by Gaussian index
+    vis = np.nonzero(aux["tiles"] > 0)[0]
+    assert (np.sort(slot_ids) == vis).all(), f"{what}: set of visible Gaussians differs"
+    sp = splats[np.argsort(slot_ids)]
+    f = sp.view(np.float32)
+    assert (sp[:, 9] == aux["depth_bits"][vis]).all(), f"{what}: depth bits differ"
+    r = aux["rect"][vis]
+    assert ((sp[:, 10] & 0xffff) == r[:, 0]).all() and ((sp[:, 10] >> 16) == r[:, 1]).all() and \
+           ((sp[:, 11] & 0xffff) == r[:, 2]).all() and ((sp[:, 11] >> 16) == r[:, 3]).all(), f"{what}: tile rects differ"
+    assert np.abs(f[:, 0:2] - aux["xy"][vis]).max(initial=0) <= 1e-3 * 2 ** -10, f"{what}: mean2D"      # fp32 ulp at ~2k px
+    rel = np.abs(np.stack([f[:, 2], f[:, 3], f[:, 4]], 1) - aux["conic"][vis]) / (np.abs(aux["conic"][vis]) + 1e-12)
+    assert rel.max(initial=0) < 1e-5, f"{what}: conic {rel.max():.2e}"
+    assert (f[:, 5] == aux["opacity"][vis]).all(), f"{what}: opacity"
+    rgb = np.stack([f[:, 6], f[:, 7], f[:, 8]], 1)
+    assert np.abs(rgb - aux["rgb"][vis]).max(initial=0) < 2e-5, f"{what}: SH colour"
+    cm = float(max(1.0, aux["rgb"][vis].max(initial=0))) if cmax is None else cmax
+    worst = assert_frame_close(img, ref, aux["margin"], cmax=cm, what=what)
+    if "d_fetched" in st and st["d_fetched"]:
+        # D_f only differs from the oracle's where a pixel sat on the termination threshold
+        assert abs(st["d_fetched"] - aux["D_f"]) <= max(8, 2e-3 * aux["D_f"]), (what, st["d_fetched"], aux["D_f"])
+    return img, st, aux, worst
+
+
+# ------------------------------------------------------------------------------------------------
+def case_config1(drv, n=10_000):
+    scene, cam = onp.config1_scene(n=n, seed=0)
+    return check_against_oracle(drv, scene, cam, what=f"config1 n={n}")
+
+
+def case_sh_degrees(drv, n=1500):
+    for deg in (0, 1, 2, 3):
+        scene = random_scene(n, 20 + deg, deg, box=((-3, 3), (-2, 2), (-3, 3)))
+        view = look_at_view((4.0, 0.5, 5.0), (0.0, 0.0, 0.0))
+        cam = onp.Camera(160, 128, 110.0, 105.0, 81.2, 60.7, view)
+        check_against_oracle(drv, scene, cam, what=f"sh degree {deg}")
+        if deg == 3:     # evaluate a degree-3 scene at lower degrees
+            for d in (0, 2):
+                check_against_oracle(drv, scene, cam, onp.Config(sh_degree=d), what=f"deg3 scene at degree {d}")
+
+
+def case_ragged(drv):
+    for n, (w, h) in ((1, (16, 16)), (63, (40, 24)), (65, (100, 70)), (129, (33, 17)), (1000, (250, 130))):
+        scene = random_scene(n, 100 + n, 1, scale=(0.05, 0.4))
+        cam = onp.Camera(w, h, 0.7 * w, 0.7 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+        check_against_oracle(drv, scene, cam, what=f"ragged n={n} {w}x{h}")
+
+
+def case_empty(drv):
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32),
+             np.zeros((0,), np.float32), np.zeros((0, 1, 3), np.float32), 0)
+    cam = onp.Camera(48, 32, 40.0, 40.0, 24.0, 16.0, np.eye(4, dtype=np.float32))
+    drv.upload(*empty)
+    img, st = drv.render(cam, onp.Config(background=(0.25, 0.5, 0.75)))
+    assert st["n_visible"] == 0 and st["d_total"] == 0
+    assert np.allclose(img, [0.25, 0.5, 0.75], atol=1e-7)
+    # everything culled (all behind the camera)
+    scene = random_scene(300, 1, 0, box=((-1, 1), (-1, 1), (-8, -2)))
+    drv.upload(*scene)
+    img, st = drv.render(cam)
+    assert st["n_visible"] == 0 and st["d_total"] == 0 and (img == 0).all()
+
+
+def case_tile_rows(drv, n=2500, res=(208, 150)):
+    """Tile-row shards: each band equals the oracle's band; their union equals the full frame bit-exactly."""
+    scene = random_scene(n, 7, 2, scale=(0.03, 0.3))
+    w, h = res
+    cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    full, st_full = drv.render(cam)
+    gy = (h + 15) // 16
+    cuts = [0, gy // 3, gy // 3 + 1, gy]
+    union = np.full_like(full, -1.0)
+    d_sum = 0
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        out = np.full_like(full, -1.0)
+        img, st = drv.render(cam, None, (r0, r1), out=out)
+        y0, y1 = r0 * 16, min(r1 * 16, h)
+        assert (img[:y0] == -1).all() and (img[y1:] == -1).all(), "rows outside the band must be untouched"
+        ref, aux = oracle_c.render(*scene, cam, None, r0, r1)
+        assert st["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"]
+        union[y0:y1] = img[y0:y1]
+        d_sum += st["d_total"]
+    assert (union == full).all(), "union of tile-row bands != full frame"
+    assert d_sum == st_full["d_total"]
+
+
+def case_depth_ties(drv):
+    """Equal fp32 depths inside a tile must order by Gaussian index: short runs (in-place fix-up) and
+    a run longer than SGS_TIE_RUN_MAX (the (index, depth) resort)."""
+    rng = np.random.default_rng(5)
+    n = 240
+    means = np.zeros((n, 3), np.float32)
+    means[:, 0] = rng.uniform(-0.15, 0.15, n); means[:, 1] = rng.uniform(-0.15, 0.15, n)
+    depth = np.full(n, 3.0, np.float32)
+    depth[:60] = 2.5                                   # one run of 60 (> 32) ...
+    depth[60:120] = np.repeat(np.linspace(2.6, 2.9, 20, dtype=np.float32), 3)    # ... twenty runs of 3
+    depth[120:] = np.linspace(3.0, 4.0, 120, dtype=np.float32)                   # ... and distinct keys
+    means[:, 2] = depth
+    perm = rng.permutation(n)
+    means = means[perm]
+    scales = np.full((n, 3), 0.05, np.float32)
+    quats = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))
+    opac = np.full(n, 0.05, np.float32)
+    sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
+    cam = onp.Camera(64, 64, 64.0, 64.0, 32.0, 32.0, np.eye(4, dtype=np.float32))
+    check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what="depth ties")
+
+
+def case_sort_classes(drv, sizes=(700, 2500, 6000, 9500)):
+    """Queue lengths that land in each sort class: S (<=1024), M (<=4096), L (<=9216, all in LDS)
+    and X (spill: ping-pong in HBM)."""
+    for n in sizes:
+        rng = np.random.default_rng(n)
+        means = np.stack([rng.uniform(-0.2, 0.2, n), rng.uniform(-0.2, 0.2, n), rng.uniform(1.0, 30.0, n)], 1).astype(np.float32)
+        scales = np.full((n, 3), 2.0, np.float32) * means[:, 2:3]          # every splat covers all four tiles
+        quats = rng.normal(size=(n, 4)).astype(np.float32)
+        opac = rng.uniform(0.005, 0.012, n).astype(np.float32)            # faint, but clear of the 1/255 cut-off
+        sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
+        cam = onp.Camera(32, 32, 32.0, 32.0, 16.0, 16.0, np.eye(4, dtype=np.float32))
+        img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what=f"sort class n={n}")
+        assert st["max_tile_len"] == n
+        assert st["n_spill_tiles"] == (4 if n > 9216 else 0)
+
+
+def case_full_grid_splat(drv, res=(1920, 1080)):
+    """One huge splat covering every tile of a 1080p grid (120x68 = 8160 records from one lane) plus
+    small ones: exercises the balanced duplication's row-major expansion over a wide rect."""
+    w, h = res
+    rng = np.random.default_rng(3)
+    n = 40
+    means = np.stack([rng.uniform(-1, 1, n), rng.uniform(-0.5, 0.5, n), rng.uniform(2, 4, n)], 1).astype(np.float32)
+    scales = np.full((n, 3), 0.01, np.float32)
+    means[17] = [0.0, 0.0, 1.0]; scales[17] = [4.0, 4.0, 0.5]
+    quats = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))
+    opac = np.full(n, 0.3, np.float32); opac[17] = 0.003             # below 1/255 everywhere: binned but never blended
+    sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
+    cam = onp.Camera(w, h, 0.38 * w, 0.38 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+    img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what="full-grid splat")
+    assert aux["tiles"][17] == ((w + 15) // 16) * ((h + 15) // 16)
+
+
+def case_overflow_retry(drv):
+    scene = random_scene(1200, 9, 0, scale=(0.1, 0.5))
+    cam = onp.Camera(96, 96, 80.0, 80.0, 48.0, 48.0, np.eye(4, dtype=np.float32))
+    drv.set_record_capacity(1024)
+    img, st, aux, _ = check_against_oracle(drv, scene, cam, what="overflow -> grow -> retry")
+    assert st["d_total"] > 1024 and st["retries"] >= 1
+    # and once grown, no more retries
+    img2, st2 = drv.render(cam)
+    assert st2["retries"] == 0 and (img2 == img).all()
+
+
+def case_determinism(drv, n=4000):
+    scene = random_scene(n, 31, 1, scale=(0.03, 0.3))
+    cam = onp.Camera(176, 144, 120.0, 120.0, 88.0, 72.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    a, _ = drv.render(cam)
+    ids_a = drv.intermediates()[1].copy()
+    b, _ = drv.render(cam)
+    ids_b = drv.intermediates()[1]
+    assert (a == b).all() and (ids_a == ids_b).all(), "two renders of the same frame differ"

@@ -1,0 +1,73 @@
+"""The C-ABI library built by __graft_entry__.build(): loads on a CPU-only box, exports every symbol
+include/sage_gs.h declares, and refuses — loudly — to run without a GPU or with a CPU backend."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from sage_gs import _capi
+    return _capi.Lib()
+
+
+def test_header_and_binding_agree(lib):
+    from sage_gs import _capi
+    hdr = open(os.path.join(ROOT, "include", "sage_gs.h")).read()
+    declared = set(re.findall(r"\b(sgs_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"sgs_status"}
+    assert declared == set(_capi.EXPORTS), declared ^ set(_capi.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None          # dlsym succeeds for every declared entry point
+
+
+def test_version_and_default_config(lib):
+    assert lib.version() == 100
+    cfg = lib.default_config()
+    assert abs(cfg.near_z - 0.2) < 1e-7 and abs(cfg.dilation - 0.3) < 1e-7 and abs(cfg.alpha_min - 1 / 255) < 1e-9
+    assert abs(cfg.alpha_max - 0.99) < 1e-7 and abs(cfg.t_min - 1e-4) < 1e-10 and cfg.sh_degree == -1
+
+
+def test_struct_layouts_match_the_header(lib):
+    from sage_gs import _capi
+    assert C.sizeof(_capi.SgsCamera) == 2 * 4 + 4 * 4 + 16 * 4
+    assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4
+    assert C.sizeof(_capi.SgsStats) == 5 * 8 + 4 * 4 + 5 * 4 + 4 + 5 * 8
+
+
+def test_no_cpu_backend_and_no_silent_fallback(lib):
+    from sage_gs import _capi
+    ctx = C.c_void_p()
+    rc = lib.sgs_create(0, _capi.BACKEND_CPU, C.byref(ctx))
+    assert rc == -5 and not ctx.value
+    assert b"oracle" in lib.sgs_last_error(None)
+    import torch
+    if not torch.cuda.is_available():
+        rc = lib.sgs_create(0, _capi.BACKEND_HIP, C.byref(ctx))
+        assert rc == -2 and not ctx.value               # no HIP device: loud failure, not a fallback
+        from sage_gs import Renderer
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            Renderer()
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from sage_gs import _capi
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _capi.Lib(str(tmp_path / "libsage_gs.so"))
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under the product package may import, link or open oracle/ or the emulator."""
+    pkg = os.path.join(ROOT, "sage-3d_official_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                for bad in ("oracle_np", "oracle_c", "liborc", "hipemu", "import oracle", "from oracle"):
+                    assert bad not in txt, (f, bad)

@@ -1,0 +1,70 @@
+"""Kernel LOGIC under the wave64 emulator (CPU; see tests/hipemu/hip/hip_runtime.h): the product's
+own kernel source, compiled for the host, must reproduce the oracle — queues bit-exactly, images within
+the parity tolerance.  The same cases run on the real GPU in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import emu_harness
+import oracle_np as onp
+import parity_cases as pc
+
+
+@pytest.fixture(scope="module")
+def drv():
+    d = emu_harness.EmuRenderer(record_capacity=1 << 21)
+    yield d
+    d.close()
+
+
+def test_config1(drv):
+    pc.case_config1(drv, n=10_000)
+
+
+def test_sh_degrees(drv):
+    pc.case_sh_degrees(drv, n=600)
+
+
+def test_ragged_sizes(drv):
+    pc.case_ragged(drv)
+
+
+def test_empty_and_all_culled(drv):
+    pc.case_empty(drv)
+
+
+def test_tile_row_bands(drv):
+    pc.case_tile_rows(drv, n=1200, res=(112, 100))
+
+
+def test_depth_ties(drv):
+    pc.case_depth_ties(drv)
+
+
+def test_sort_classes(drv):
+    pc.case_sort_classes(drv, sizes=(700, 2500, 9500))
+
+
+def test_full_grid_splat(drv):
+    pc.case_full_grid_splat(drv, res=(640, 368))
+
+
+def test_determinism(drv):
+    pc.case_determinism(drv, n=1500)
+
+
+def test_overflow_retry():
+    d = emu_harness.EmuRenderer(record_capacity=1 << 16)
+    try:
+        pc.case_overflow_retry(d)
+    finally:
+        d.close()
+
+
+def test_float_reciprocal_division_is_exact():
+    """wave_expand() replaces idx / w by (unsigned)((idx + 0.5f) * (1.0f / w)); exact over every
+    rect a 16384x16384 frame can produce (w <= 1024 tiles, idx < 2^20)."""
+    for w in range(1, 1025):
+        idx = np.arange(0, min(1 << 20, w * 1024), dtype=np.uint32)
+        rw = np.float32(1.0) / np.float32(w)
+        q = ((idx.astype(np.float32) + np.float32(0.5)) * rw).astype(np.uint32)
+        assert (q == idx // w).all(), w

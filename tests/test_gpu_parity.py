@@ -1,0 +1,221 @@
+"""Parity tests proper: the HIP path on a real MI355X, called through the C ABI (via the Python
+host side), against the oracle — same cases as the emulator run plus full-size scenes and
+size-independent properties at BASELINE.json's sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_c
+import oracle_np as onp
+import parity_cases as pc
+from conftest import assert_frame_close
+
+
+class GpuDriver:
+    """Adapts sage_gs.Renderer (torch tensors, C ABI underneath) to the parity_cases driver shape."""
+
+    def __init__(self):
+        import torch
+        from sage_gs import Renderer
+        assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+        self.torch = torch
+        self.r = Renderer("cuda:0")
+        self.scene = None
+
+    def upload(self, means, scales, quats, opac, sh, deg):
+        from sage_gs import Gaussians
+        t = lambda a: self.torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        if self.scene is not None:
+            self.scene.free()
+        self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
+
+    def render(self, cam, cfg=None, rows=(0, -1), out=None):
+        from sage_gs import Camera, RenderConfig
+        c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
+        k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
+                                                  cfg.alpha_max, cfg.t_min, cfg.background, cfg.sh_degree)
+        o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
+        img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows)
+        return img.cpu().numpy(), self.r.last_stats
+
+    def intermediates(self):
+        return self.r.intermediates()
+
+    def set_record_capacity(self, n):
+        self.r.set_record_capacity(n)
+
+    def close(self):
+        if self.scene is not None:
+            self.scene.free()
+        self.r.close()
+
+
+@pytest.fixture(scope="module")
+def drv():
+    d = GpuDriver()
+    yield d
+    d.close()
+
+
+def test_library_is_the_hip_build(drv):
+    """The GPU tests must run the in-tree HIP library, not anything else."""
+    import os
+    assert os.path.basename(drv.r._lib.path) == "libsage_gs.so"
+    assert "sage-3d_official_amd/lib" in drv.r._lib.path.replace("\\", "/")
+    assert drv.r._lib.version() == 100
+
+
+def test_config1(drv):
+    pc.case_config1(drv, n=10_000)
+
+
+def test_sh_degrees(drv):
+    pc.case_sh_degrees(drv, n=3000)
+
+
+def test_ragged_sizes(drv):
+    pc.case_ragged(drv)
+
+
+def test_empty_and_all_culled(drv):
+    pc.case_empty(drv)
+
+
+def test_tile_row_bands(drv):
+    pc.case_tile_rows(drv, n=6000, res=(400, 300))
+
+
+def test_depth_ties(drv):
+    pc.case_depth_ties(drv)
+
+
+def test_sort_classes(drv):
+    pc.case_sort_classes(drv, sizes=(700, 2500, 6000, 9500, 20000))
+
+
+def test_full_grid_splat(drv):
+    pc.case_full_grid_splat(drv, res=(1920, 1080))
+    pc.case_full_grid_splat(drv, res=(3840, 2160))
+
+
+def test_determinism(drv):
+    pc.case_determinism(drv, n=50_000)
+
+
+def test_overflow_retry():
+    d = GpuDriver()
+    try:
+        pc.case_overflow_retry(d)
+    finally:
+        d.close()
+
+
+# ---- room scenes at 1080p against the C oracle -----------------------------------------------------
+def _room(n, seed):
+    from sage_gs import scenes
+    sc = scenes.make_room(n, seed=seed)
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=2, n_yaw=8, seed=seed)
+    return sc, cams
+
+
+@pytest.mark.parametrize("n,seed,cam_ids", [(120_000, 1, (0, 3, 5)), (400_000, 2, (9,))])
+def test_room_1080p_vs_oracle(drv, n, seed, cam_ids):
+    sc, cams = _room(n, seed)
+    for ci in cam_ids:
+        cam = cams[ci]
+        view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
+        ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+        pc.check_against_oracle(drv, sc.as_tuple(), ocam, what=f"room n={n} cam {ci}")
+
+
+# ---- BASELINE.json full sizes: size-independent properties ------------------------------------------
+@pytest.fixture(scope="module")
+def big_scene():
+    from sage_gs import scenes
+    sc = scenes.make_room(3_000_000, seed=2)
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=2, n_yaw=4, seed=2)
+    return sc, cams
+
+
+def test_3m_scene_properties(drv, big_scene):
+    sc, cams = big_scene
+    drv.upload(*sc.as_tuple())
+    for cam in (cams[0], cams[5]):
+        view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
+        ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+        full, st = drv.render(ocam)
+        assert np.isfinite(full).all() and full.min() >= 0.0
+        assert 0 < st["n_visible"] <= 3_000_000 and st["d_total"] >= st["n_visible"] and st["d_fetched"] <= st["d_total"]
+        off, ids, slot_ids, splats = drv.intermediates()
+        # (1) every queue is sorted by (depth bits, index); the offsets are a partition of D
+        assert off[-1] == st["d_total"] and (np.diff(off) >= 0).all()
+        key_of = np.zeros(3_000_000, np.uint64); key_of[slot_ids] = splats[:, 9].astype(np.uint64)
+        comp = (key_of[ids] << np.uint64(32)) | ids.astype(np.uint64)
+        tile_of = np.repeat(np.arange(len(off) - 1), np.diff(off))
+        same = tile_of[1:] == tile_of[:-1]
+        assert (comp[1:][same] > comp[:-1][same]).all(), "a queue is not strictly ordered by (depth, index)"
+        # (2) D == sum of rect areas of the visible splats (a checksum of the binning)
+        x0, y0 = splats[:, 10] & 0xffff, splats[:, 10] >> 16
+        x1, y1 = splats[:, 11] & 0xffff, splats[:, 11] >> 16
+        assert int(((x1 - x0).astype(np.int64) * (y1 - y0)).sum()) == st["d_total"]
+        # (3) tile-row bands reproduce the full frame bit-exactly (the multi-GPU sharding property)
+        union = np.zeros_like(full)
+        for r0, r1 in ((0, 9), (9, 18), (18, 27), (27, 36), (36, 44), (44, 52), (52, 60), (60, 68)):
+            band, _ = drv.render(ocam, None, (r0, r1))
+            union[r0 * 16:min(r1 * 16, 1080)] = band[r0 * 16:min(r1 * 16, 1080)]
+        assert (union == full).all()
+        # (4) idempotence / determinism
+        again, _ = drv.render(ocam)
+        assert (again == full).all()
+
+
+def test_3m_scene_crop_vs_oracle(drv, big_scene):
+    """Full-size scene, oracle-checked on a band of tile rows (the oracle finishes a band in seconds)."""
+    sc, cams = big_scene
+    cam = cams[2]
+    view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
+    ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+    drv.upload(*sc.as_tuple())
+    r0, r1 = 30, 34
+    img, st = drv.render(ocam, None, (r0, r1))
+    ref, aux = oracle_c.render(*sc.as_tuple(), ocam, None, r0, r1, want="image")
+    assert st["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"]
+    sl = slice(r0 * 16, r1 * 16)
+    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="3M scene band")
+
+
+def test_batch_equals_single_frames(drv):
+    from sage_gs import Camera, scenes
+    sc = scenes.make_room(60_000, seed=4)
+    cams = scenes.room_cameras(sc, 640, 480, n_positions=1, n_yaw=6, seed=4)
+    g = scenes.to_gaussians(sc, "cuda:0")
+    scene = drv.r.upload(g)
+    batch, stats = drv.r.render_batch(cams, scene, want_stats=True)
+    for i, c in enumerate(cams):
+        single = drv.r.render(c, scene)
+        assert (batch[i] == single).all()
+        assert stats[i]["d_total"] == drv.r.last_stats["d_total"]
+    scene.free()
+
+
+def test_pack_rgba8(drv):
+    import torch
+    rgb = torch.rand((37, 53, 3), device="cuda:0") * 1.4 - 0.2
+    out = drv.r.pack_rgba8(rgb).cpu().numpy()
+    exp = (np.clip(rgb.cpu().numpy(), 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert (out[..., :3] == exp).all() and (out[..., 3] == 255).all()
+
+
+def test_render_function_surface():
+    """render(camera, gaussians) — the drop-in call named by BASELINE.json."""
+    import torch
+    from sage_gs import Camera, render, scenes
+    sc = scenes.config1(2000)
+    g = scenes.to_gaussians(sc, "cuda:0")
+    cam = Camera(256, 256, 128.0, 128.0, 128.0, 128.0, np.eye(4))
+    img = render(cam, g)
+    assert isinstance(img, torch.Tensor) and img.shape == (256, 256, 3) and img.dtype == torch.float32 and img.is_cuda
+    ocam = onp.Camera(256, 256, 128.0, 128.0, 128.0, 128.0, np.eye(4, dtype=np.float32))
+    ref, aux = oracle_c.render(*sc.as_tuple(), ocam)
+    assert_frame_close(img.cpu().numpy(), ref, aux["margin"], cmax=2.5, what="render()")

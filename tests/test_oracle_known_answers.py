@@ -1,0 +1,246 @@
+"""Pins the oracle (both restatements) with closed-form known answers — SURVEY.md §8c (iii)/(iv).
+
+The reference holds no golden vectors for this path ("parity unpinned"), so these analytic cases —
+each derived by hand from the stage definitions S1-S6 — are what anchors the oracle, and the NumPy
+and C restatements must agree with each other on random scenes.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import oracle_c
+import oracle_np as onp
+
+C0, C1 = onp.SH_C0, onp.SH_C1
+
+
+def _scene(means, scales, opac, dc, quats=None, sh=None, deg=0):
+    n = len(means)
+    means = np.asarray(means, np.float32).reshape(n, 3)
+    scales = np.asarray(scales, np.float32).reshape(n, 3)
+    quats = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1)) if quats is None else np.asarray(quats, np.float32)
+    opac = np.asarray(opac, np.float32).reshape(n)
+    if sh is None:
+        sh = np.asarray(dc, np.float32).reshape(n, 1, 3)
+    return means, scales, quats, opac, np.asarray(sh, np.float32), deg
+
+
+def _cam(w=64, h=64, f=64.0, cx=None, cy=None, view=None):
+    # cx = 32.5 puts the optical axis exactly on pixel 32 (pixel centres are integers)
+    return onp.Camera(w, h, f, f, 32.5 if cx is None else cx, 32.5 if cy is None else cy,
+                      np.eye(4, dtype=np.float32) if view is None else np.asarray(view, np.float32))
+
+
+def _render(which, scene, cam, cfg=None, rows=(0, None)):
+    if which == "numpy":
+        img, aux = onp.render(*scene, cam, cfg or onp.Config(), rows[0], rows[1])
+        return np.asarray(img), aux
+    img, aux = oracle_c.render(*scene, cam, cfg, rows[0], -1 if rows[1] is None else rows[1])
+    return img.astype(np.float64), aux
+
+
+BOTH = pytest.mark.parametrize("which", ["numpy", "c"])
+
+
+@BOTH
+def test_single_isotropic_gaussian_profile(which):
+    s, z, o, dc, f = 0.1, 4.0, 0.8, 0.6, 64.0
+    img, aux = _render(which, _scene([[0, 0, z]], [[s, s, s]], [o], [[dc, dc / 2, -dc]]), _cam(f=f))
+    var = (f * s / z) ** 2 + 0.3
+    col = np.maximum(0.0, 0.5 + C0 * np.array([dc, dc / 2, -dc]))
+    yy, xx = np.mgrid[0:64, 0:64]
+    r2 = (xx - 32.0) ** 2 + (yy - 32.0) ** 2
+    alpha = np.minimum(0.99, o * np.exp(-r2 / (2 * var)))
+    alpha = np.where(alpha >= 1 / 255.0, alpha, 0.0)
+    # outside the 3-sigma tile rect the Gaussian is not binned at all
+    rad = math.ceil(3 * math.sqrt(var + math.sqrt(0.1)))
+    x0, x1 = (32 - rad) // 16, (32 + rad + 15) // 16
+    inrect = (xx // 16 >= x0) & (xx // 16 < x1) & (yy // 16 >= x0) & (yy // 16 < x1)
+    expect = np.where(inrect, alpha, 0.0)[..., None] * col
+    assert np.abs(img - expect).max() < 2e-6
+    assert aux["D"] == (x1 - x0) ** 2 and aux["n_visible"] == 1
+
+
+@BOTH
+def test_front_to_back_order_two_gaussians(which):
+    sc = _scene([[0, 0, 5.0], [0, 0, 3.0]], [[0.2] * 3, [0.15] * 3], [0.6, 0.5], [[1.0, 0, 0], [0, 1.0, 0]])
+    img, aux = _render(which, sc, _cam())
+    v1, v2 = (64 * 0.15 / 3.0) ** 2 + 0.3, (64 * 0.2 / 5.0) ** 2 + 0.3     # nearer one first
+    a1, a2 = 0.5, 0.6                                                       # at the centre pixel r = 0
+    c1 = np.maximum(0, 0.5 + C0 * np.array([0, 1.0, 0])); c2 = np.maximum(0, 0.5 + C0 * np.array([1.0, 0, 0]))
+    assert np.allclose(img[32, 32], a1 * c1 + (1 - a1) * a2 * c2, atol=2e-6)
+    r2 = 9.0
+    b1, b2 = 0.5 * math.exp(-r2 / (2 * v1)), 0.6 * math.exp(-r2 / (2 * v2))
+    assert np.allclose(img[32, 35], b1 * c1 + (1 - b1) * b2 * c2, atol=2e-6)
+
+
+@BOTH
+def test_alpha_clamp_and_cutoff(which):
+    img, aux = _render(which, _scene([[0, 0, 2.0]], [[0.05] * 3], [1.0], [[2.0, 2.0, 2.0]]), _cam())
+    col = 0.5 + C0 * 2.0
+    assert abs(img[32, 32, 0] - 0.99 * col) < 2e-6                          # alpha clamped to 0.99
+    var = (64 * 0.05 / 2.0) ** 2 + 0.3
+    yy, xx = np.mgrid[0:64, 0:64]
+    alpha = np.exp(-((xx - 32.0) ** 2 + (yy - 32.0) ** 2) / (2 * var))
+    assert (img[alpha < 0.999 / 255.0] == 0).all()                          # below 1/255: contributes nothing
+    assert (img[(alpha > 1.001 / 255.0) & (alpha < 0.5)][:, 0] > 0).all()
+
+
+@BOTH
+def test_transmittance_termination(which):
+    # five coincident splats of opacity 0.95: T = .05, .0025, 1.25e-4, then 6.25e-6 < 1e-4 stops the pixel
+    n = 5
+    means = [[0, 0, 2.0 + 0.1 * i] for i in range(n)]
+    dc = [[1.0, 1.0, 1.0]] * 3 + [[-1.0, 3.0, 0.0]] * 2                      # the last two must stay unseen
+    img, aux = _render(which, _scene(means, [[0.5] * 3] * n, [0.95] * n, dc), _cam())
+    col = 0.5 + C0 * 1.0
+    expect = col * (0.95 + 0.05 * 0.95 + 0.0025 * 0.95)
+    assert np.allclose(img[32, 32], expect, atol=3e-6)
+    assert aux["n_contrib"][32, 32] == 3
+    assert abs(aux["final_T"][32, 32] - 1.25e-4) < 1e-9
+    t = (32 // 16) * 4 + 32 // 16
+    assert aux["consumed"][t] >= 4                                           # the stopping record was examined
+
+
+@BOTH
+def test_sh_degree0_and_degree1_signs(which):
+    sh = np.zeros((1, 4, 3), np.float32)
+    sh[0, 0] = [0.3, 0.3, 0.3]; sh[0, 1] = [0.2, 0, 0]; sh[0, 2] = [0, 0.2, 0]; sh[0, 3] = [0, 0, 0.2]
+    def centre(view, mean):
+        sc = _scene([mean], [[0.2] * 3], [0.5], None, sh=sh, deg=1)
+        img, _ = _render(which, sc, _cam(view=view))
+        return img[32, 32] / 0.5
+    base = 0.5 + C0 * 0.3
+    # looking down +z: dir = (0,0,1) -> + C1 * z * sh[2]
+    assert np.allclose(centre(np.eye(4), [0, 0, 3.0]), [base, base + C1 * 0.2, base], atol=3e-6)
+    # camera looking down world +x (cam z = world x, cam x = world -z... any rigid frame): dir = (1,0,0) -> - C1 * x * sh[3]
+    vx = np.array([[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, 0], [0, 0, 0, 1]], np.float32)
+    assert np.allclose(centre(vx, [3.0, 0, 0]), [base, base, base - C1 * 0.2], atol=3e-6)
+    # camera looking down world +y: dir = (0,1,0) -> - C1 * y * sh[1]
+    vy = np.array([[0, 0, 1, 0], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 0, 1]], np.float32)
+    assert np.allclose(centre(vy, [0, 3.0, 0]), [base - C1 * 0.2, base, base], atol=3e-6)
+    # looking down -z (rotate pi about y): dir = (0,0,-1)
+    vz = np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32)
+    assert np.allclose(centre(vz, [0, 0, -3.0]), [base, base - C1 * 0.2, base], atol=3e-6)
+    # degree-0 evaluation of the same scene ignores band 1
+    sc = _scene([[0, 0, 3.0]], [[0.2] * 3], [0.5], None, sh=sh, deg=1)
+    img0, _ = _render(which, sc, _cam(), onp.Config(sh_degree=0) if which == "numpy" else oracle_c.make_config(sh_degree=0))
+    assert np.allclose(img0[32, 32] / 0.5, [base] * 3, atol=3e-6)
+
+
+@BOTH
+def test_culling(which):
+    def nvis(mean, **kw):
+        _, aux = _render(which, _scene([mean], [[0.05] * 3], [0.9], [[1, 1, 1]]), _cam(**kw))
+        return aux["n_visible"], aux["D"]
+    assert nvis([0, 0, 0.2]) == (0, 0)                    # tz <= 0.2 is culled
+    assert nvis([0, 0, 0.2001])[0] == 1
+    assert nvis([0, 0, -1.0]) == (0, 0)                   # behind the camera
+    assert nvis([50.0, 0, 2.0]) == (0, 0)                 # in front but far off-screen: empty tile rect
+    far = oracle_c.make_config(far=10.0) if which == "c" else onp.Config(far=10.0)
+    _, aux = _render(which, _scene([[0, 0, 10.5]], [[0.05] * 3], [0.9], [[1, 1, 1]]), _cam(), far)
+    assert aux["n_visible"] == 0
+
+
+@BOTH
+def test_aabb_tile_rect_and_duplicate_count(which):
+    s, z, f = 0.3, 3.0, 64.0
+    cam = _cam(w=128, h=96, f=f, cx=70.5, cy=40.5)       # mean2D = (70, 40)
+    _, aux = _render(which, _scene([[0, 0, z]], [[s] * 3], [0.9], [[1, 1, 1]]), cam)
+    var = (f * s / z) ** 2 + 0.3
+    rad = math.ceil(3 * math.sqrt(var + math.sqrt(0.1)))
+    x0, x1 = max(0, (70 - rad) // 16), min(8, (70 + rad + 15) // 16)
+    y0, y1 = max(0, (40 - rad) // 16), min(6, (40 + rad + 15) // 16)
+    rect = aux["pre"]["rect"][0] if which == "numpy" else aux["rect"][0]
+    assert tuple(rect) == (x0, y0, x1, y1)
+    assert aux["D"] == (x1 - x0) * (y1 - y0)
+    off = aux["offsets"]
+    cnt = np.diff(off).reshape(6, 8)
+    expect = np.zeros((6, 8), int); expect[y0:y1, x0:x1] = 1
+    assert (cnt == expect).all()
+
+
+@BOTH
+def test_equal_depth_breaks_ties_on_index(which):
+    a = 0.5
+    c_red = np.maximum(0, 0.5 + C0 * np.array([2.0, -2.0, -2.0])); c_blue = np.maximum(0, 0.5 + C0 * np.array([-2.0, -2.0, 2.0]))
+    sc = _scene([[0, 0, 3.0], [0, 0, 3.0]], [[0.3] * 3] * 2, [a, a], [[2.0, -2, -2], [-2.0, -2, 2.0]])
+    img, aux = _render(which, sc, _cam())
+    assert np.allclose(img[32, 32], a * c_red + (1 - a) * a * c_blue, atol=2e-6)      # index 0 in front
+    sc = _scene([[0, 0, 3.0], [0, 0, 3.0]], [[0.3] * 3] * 2, [a, a], [[-2.0, -2, 2.0], [2.0, -2, -2]])
+    img, _ = _render(which, sc, _cam())
+    assert np.allclose(img[32, 32], a * c_blue + (1 - a) * a * c_red, atol=2e-6)
+
+
+@BOTH
+def test_background_and_empty_scene(which):
+    cfg = onp.Config(background=(0.2, 0.4, 0.6)) if which == "numpy" else oracle_c.make_config(background=(0.2, 0.4, 0.6))
+    empty = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32),
+             np.zeros((0,), np.float32), np.zeros((0, 1, 3), np.float32), 0)
+    img, aux = _render(which, empty, _cam(), cfg)
+    assert np.allclose(img, [0.2, 0.4, 0.6], atol=1e-7) and aux["D"] == 0
+    img, _ = _render(which, _scene([[0, 0, 3.0]], [[0.3] * 3], [0.5], [[0, 0, 0]]), _cam(), cfg)
+    assert np.allclose(img[32, 32], 0.5 * 0.5 + 0.5 * np.array([0.2, 0.4, 0.6]), atol=2e-6)
+
+
+@BOTH
+def test_tile_row_partition_is_exact(which):
+    scene, cam = onp.config1_scene(n=1500, seed=3)
+    cam = onp.Camera(96, 80, 60.0, 60.0, 48.0, 40.0, np.eye(4, dtype=np.float32))   # 5 tile rows
+    full, aux = _render(which, scene, cam)
+    parts = np.zeros_like(full)
+    D = 0
+    for r0, r1 in ((0, 2), (2, 3), (3, 5)):
+        img, a = _render(which, scene, cam, rows=(r0, r1))
+        parts[r0 * 16:r1 * 16] = img[r0 * 16:r1 * 16]
+        assert (img[:r0 * 16] == 0).all() and (img[r1 * 16:] == 0).all()
+        D += a["D"]
+    assert (parts == full).all()
+    assert D == aux["D"]
+
+
+def test_numpy_and_c_restatements_agree():
+    """The two independently written restatements: integers bit-exact, image to float32 rounding."""
+    for seed, n, deg in ((0, 3000, 0), (5, 1200, 3), (7, 800, 2), (9, 500, 1)):
+        rng = np.random.default_rng(seed)
+        scene, cam = onp.config1_scene(n=n, seed=seed)
+        k = (deg + 1) ** 2
+        sh = (0.3 * rng.normal(size=(n, k, 3))).astype(np.float32)
+        scene = scene[:4] + (sh, deg)
+        cam = onp.Camera(160, 112, 90.0, 85.0, 77.3, 58.1, np.eye(4, dtype=np.float32))
+        a_img, a = onp.render(*scene, cam)
+        c_img, c = oracle_c.render(*scene, cam)
+        pre = a["pre"]
+        assert (pre["tiles"] == c["tiles"]).all()
+        assert (pre["rect"][pre["visible"]] == c["rect"][pre["visible"]]).all()
+        assert (pre["depth"].view(np.uint32) == c["depth_bits"]).all()
+        assert (a["offsets"] == c["offsets"]).all() and (a["ids"] == c["ids"]).all()
+        assert (a["n_contrib"] == c["n_contrib"]).all() and (a["consumed"] == c["consumed"]).all()
+        assert np.abs(a_img - c_img).max() < 5e-7
+        assert np.abs(pre["rgb"][pre["visible"]] - c["rgb"][pre["visible"]]).max() < 1e-6
+
+
+def test_permutation_invariance_and_rigid_motion():
+    """shuffling the Gaussians, or moving scene and camera together, leaves a
+    degree-0 image unchanged (up to re-association / rounding of the fp32 inputs)."""
+    scene, cam = onp.config1_scene(n=2500, seed=11)
+    base, _ = oracle_c.render(*scene, cam)
+    rng = np.random.default_rng(1)
+    perm = rng.permutation(2500)
+    shuf, _ = oracle_c.render(*[a[perm] for a in scene[:5]], 0, cam)
+    assert np.abs(shuf - base).max() < 1e-6
+    # rigid motion G: x' = R x + t ; camera view' = view G^-1 ; Gaussian orientation q' = qR * q
+    ang = 0.7
+    R = np.array([[math.cos(ang), -math.sin(ang), 0], [math.sin(ang), math.cos(ang), 0], [0, 0, 1.0]])
+    t = np.array([0.4, -1.1, 0.3])
+    means, scales, quats, opac, sh, deg = scene
+    qr = np.array([math.cos(ang / 2), 0, 0, math.sin(ang / 2)])
+    w1, x1, y1, z1 = qr; w2, x2, y2, z2 = quats.T.astype(np.float64)
+    q2 = np.stack([w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2, w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                   w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2, w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2], 1)
+    G = np.eye(4); G[:3, :3] = R; G[:3, 3] = t
+    cam2 = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, (np.eye(4) @ np.linalg.inv(G)).astype(np.float32))
+    moved, _ = oracle_c.render((means @ R.T + t).astype(np.float32), scales, q2.astype(np.float32), opac, sh, deg, cam2)
+    assert np.abs(moved - base).max() < 2e-3          # fp32 re-rounding of means/quats/view moves a few pixels slightly
+    assert np.abs(moved - base).mean() < 2e-5
