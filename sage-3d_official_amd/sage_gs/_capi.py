@@ -70,6 +70,11 @@ class Lib:
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
                 "g.build()' or make -C sage-3d_official_amd). There is no CPU fallback.")
         self.path = path
+        # One HIP runtime per process: libsage_gs.so needs libamdhip64.so.7, and PyTorch ships its own
+        # copy under the same SONAME.  Importing torch FIRST makes the loader hand that already-loaded
+        # copy to our library, so device pointers and streams are shared with torch (loading ours first
+        # pulls /opt/rocm's copy in and the second runtime then finds no device).
+        import torch  # noqa: F401
         lib = self._lib = C.CDLL(path)
         vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
         lib.sgs_version.restype = i32
