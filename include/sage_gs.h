@@ -150,9 +150,9 @@ int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int
  * Returns the number of bytes the buffer holds (copying at most `bytes`), or a negative status. */
 enum {
     SGS_BUF_TILE_OFFSETS = 0,      /* uint32[T+1]                                                */
-    SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues after S5 (compacted slots)    */
-    SGS_BUF_SLOT_IDS     = 2,      /* uint32[N_v]  Gaussian index of each compacted slot         */
-    SGS_BUF_SPLATS       = 3       /* 12 x 4 B per slot: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 */
+    SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues after S5 (slot numbers)        */
+    SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    Gaussian index of each slot, 0xFFFFFFFF = dead; S = ceil(N/1024)*1024 */
+    SGS_BUF_SPLATS       = 3       /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
 };
 int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);
 

@@ -44,7 +44,13 @@ struct sgs_ctx {
     unsigned* slot_id = nullptr;
     // per-tile scratch
     int tile_cap = 0;
-    unsigned *tile_count = nullptr, *tile_offset = nullptr, *tile_fill = nullptr, *class_list = nullptr;
+    unsigned *tile_count = nullptr, *tile_offset = nullptr, *class_list = nullptr;
+    // binning scratch: live slots per range, per-workgroup (tile, base) lists
+    int64_t range_cap = 0;
+    unsigned* range_nvis = nullptr;
+    int64_t blk_list_cap = 0;
+    uint2* blk_list = nullptr;
+    unsigned* blk_len = nullptr;
     // per-record scratch
     int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
     unsigned *rec_key = nullptr, *rec_val = nullptr, *alt_key = nullptr, *alt_val = nullptr;
@@ -93,12 +99,24 @@ int grow(sgs_ctx* ctx, T*& p, size_t count) {
 }
 
 int ensure_splats(sgs_ctx* ctx, int64_t n) {
-    if (n <= ctx->splat_cap) return SGS_OK;
-    const int64_t cap = ((n + 63) / 64) * 64;
+    if (n <= ctx->splat_cap && ctx->blk_len) return SGS_OK;
+    const int64_t ranges = std::max<int64_t>(1, (n + SGS_RANGE - 1) / SGS_RANGE);
+    const int64_t cap = ranges * SGS_RANGE;          // slots are compacted per range
     int rc;
     if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->slot_id, (size_t)cap)) != SGS_OK) return rc;
-    ctx->splat_cap = cap;
+    if ((rc = grow(ctx, ctx->range_nvis, (size_t)ranges)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS)) != SGS_OK) return rc;
+    ctx->splat_cap = cap; ctx->range_cap = ranges;
+    return SGS_OK;
+}
+
+int ensure_blk_list(sgs_ctx* ctx, int n_windows) {
+    const int64_t need = (int64_t)SGS_BIN_BLOCKS * n_windows * SGS_WT;
+    if (need <= ctx->blk_list_cap) return SGS_OK;
+    int rc;
+    if ((rc = grow(ctx, ctx->blk_list, (size_t)need)) != SGS_OK) return rc;
+    ctx->blk_list_cap = need;
     return SGS_OK;
 }
 
@@ -107,7 +125,6 @@ int ensure_tiles(sgs_ctx* ctx, int tiles) {
     int rc;
     if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->tile_fill, (size_t)tiles + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->class_list, (size_t)tiles * SGS_SORT_CLASSES)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
@@ -139,6 +156,11 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     if (row_begin < 0) row_begin = 0;
     if (row_begin > row_end) SGS_FAIL(ctx, SGS_ERR_INVALID, "tile_row_begin %d > tile_row_end %d", row_begin, row_end);
     if (cfg && cfg->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d > 3", cfg->sh_degree);
+    const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
+    if (gx > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "width %d exceeds %d tiles per row", cam->width, SGS_WT);
+    const int win_rows = std::max(1, SGS_WT / gx);
+    if ((row_end - row_begin + win_rows - 1) / win_rows > SGS_MAX_WINDOWS)
+        SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d binning windows", row_end - row_begin, gx, SGS_MAX_WINDOWS);
     return SGS_OK;
 }
 
@@ -159,6 +181,9 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const sgs_scene* scene, con
     P.sh_degree = cfg.sh_degree < 0 ? scene->sh_degree : std::min(cfg.sh_degree, scene->sh_degree);
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
+    P.n_ranges = (int32_t)((scene->n + SGS_RANGE - 1) / SGS_RANGE);
+    P.win_rows = std::max(1, SGS_WT / P.gx);
+    P.n_windows = (row_end - row_begin + P.win_rows - 1) / P.win_rows;
     P.rec_capacity = ctx->rec_cap;
     P.flags = cfg.flags | SGS_FLAG_STATS;
 }
@@ -173,6 +198,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if ((rc = ensure_records(ctx)) != SGS_OK) return rc;
     FrameParams P;
     fill_params(P, ctx, scene, cam, cfg, row_begin, row_end);
+    if ((rc = ensure_blk_list(ctx, std::max(1, P.n_windows))) != SGS_OK) return rc;
     FrameStatus* st = ctx->d_status + slot;
     SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
     hipEvent_t* ev = nullptr;
@@ -188,25 +214,23 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     ctx->slot_timed[slot] = timed;
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
-    if (scene->n_chunks > 0) {
-        const unsigned grid = (unsigned)((scene->n_chunks + 3) / 4);
-        hipLaunchKernelGGL(sgs::k_preprocess, dim3(grid), dim3(256), 0, stream, P, scene->geom, scene->shq,
-                           ctx->splats, ctx->slot_id, ctx->tile_count, st);
-    }
+    const unsigned bin_blocks = (unsigned)std::min<int64_t>(SGS_BIN_BLOCKS, P.n_ranges);
+    if (P.n_ranges > 0)
+        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)P.n_ranges), dim3(256), 0, stream, P, scene->geom,
+                           scene->shq, ctx->splats, ctx->slot_id, ctx->range_nvis);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
-    // the scan copies the counts into tile_fill (k_emit's slot dispenser); tile_count is then cleared
-    // for the next frame
+    if (P.n_ranges > 0 && P.n_windows > 0)
+        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
+                           ctx->range_nvis, ctx->tile_count, ctx->blk_list, ctx->blk_len, st);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
-                       ctx->tile_offset, ctx->tile_fill, ctx->class_list, st);
-    SGS_HIP(ctx, hipMemsetAsync(ctx->tile_count, 0, ((size_t)gx * gy + 1) * sizeof(unsigned), stream));
+                       ctx->tile_offset, ctx->class_list, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
-    if (scene->n_chunks > 0) {
-        const unsigned grid = (unsigned)std::min<int64_t>((scene->n_chunks + 3) / 4, 2048);
-        hipLaunchKernelGGL(sgs::k_emit, dim3(grid), dim3(256), 0, stream, P, ctx->splats, ctx->tile_offset,
-                           ctx->tile_fill, ctx->rec_key, ctx->rec_val, st);
-    }
+    if (P.n_ranges > 0 && P.n_windows > 0)
+        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
+                           ctx->range_nvis, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec_key,
+                           ctx->rec_val, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
@@ -261,7 +285,7 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
     stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 48 + 4) * nv;
-    stats->bytes[SGS_STAGE_SCAN] = 16 * ((int64_t)ctx->last_T + 1);
+    stats->bytes[SGS_STAGE_SCAN] = 16 * nv + 16 * ((int64_t)ctx->last_T + 1);   // rect re-read + counters
     stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
     stats->bytes[SGS_STAGE_SORT] = 12 * D;
     stats->bytes[SGS_STAGE_COMPOSITE] = 40 * Df + 12 * pixels;
@@ -329,8 +353,8 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->tile_fill, ctx->class_list,
-                    ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
+    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->class_list, ctx->range_nvis,
+                    ctx->blk_list, ctx->blk_len, ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev) {
@@ -536,18 +560,35 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     SGS_HIP(ctx, hipDeviceSynchronize());
     const FrameStatus& s = ctx->h_status[ctx->last_slot];
+    const int64_t n_ranges = (ctx->last_n + SGS_RANGE - 1) / SGS_RANGE;
+    const int64_t n_slots = n_ranges * SGS_RANGE;
     const void* src = nullptr;
-    int64_t have = 0;
+    int64_t have = 0, elem = 0;
     switch (what) {
         case SGS_BUF_TILE_OFFSETS: src = ctx->tile_offset; have = ((int64_t)ctx->last_T + 1) * 4; break;
-        case SGS_BUF_SORTED_SLOTS: src = ctx->rec_val; have = (int64_t)s.d_total * 4; break;
-        case SGS_BUF_SLOT_IDS: src = ctx->slot_id; have = (int64_t)s.n_visible * 4; break;
-        case SGS_BUF_SPLATS: src = ctx->splats; have = (int64_t)s.n_visible * (int64_t)sizeof(Splat); break;
+        case SGS_BUF_SORTED_SLOTS: src = ctx->rec_val; have = s.overflow ? 0 : (int64_t)s.d_total * 4; break;
+        case SGS_BUF_SLOT_IDS: src = ctx->slot_id; elem = 4; have = n_slots * elem; break;
+        case SGS_BUF_SPLATS: src = ctx->splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
     }
-    if (s.overflow && what == SGS_BUF_SORTED_SLOTS) have = 0;
     const int64_t n = std::min(have, bytes);
-    if (n > 0 && host_dst) SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    if (n <= 0 || !host_dst) return have;
+    SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    if (elem) {
+        // slots are compacted per 1024-Gaussian range; blank the dead tail of every range
+        // (slot ids -> 0xFFFFFFFF, splats -> 0) so stale data of earlier frames cannot be mistaken for live
+        unsigned* nvis = (unsigned*)malloc((size_t)std::max<int64_t>(1, n_ranges) * 4);
+        if (!nvis) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+        hipError_t e = hipMemcpy(nvis, ctx->range_nvis, (size_t)n_ranges * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(nvis); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+        char* dst = (char*)host_dst;
+        for (int64_t r = 0; r < n_ranges; ++r) {
+            const int64_t b0 = (r * SGS_RANGE + nvis[r]) * elem, b1 = (r + 1) * SGS_RANGE * elem;
+            if (b0 >= n) break;
+            memset(dst + b0, what == SGS_BUF_SLOT_IDS ? 0xFF : 0, (size_t)(std::min(b1, n) - b0));
+        }
+        free(nvis);
+    }
     return have;
 }
 

@@ -8,6 +8,14 @@
 #define SGS_GEOM_ROWS 3             // float4 rows per Gaussian in the scene geometry block
 #define SGS_MAX_SH_ROWS 12          // ceil(48 floats / 4) at SH degree 3
 
+// Compaction / binning (S4)
+#define SGS_RANGE 1024              // Gaussians per compaction range: one k_preprocess workgroup, 16 chunks
+#define SGS_RANGE_CHUNKS (SGS_RANGE / SGS_WAVE)
+#define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB)
+#define SGS_BIN_THREADS 512
+#define SGS_BIN_BLOCKS 512          // binning workgroups (2 per CU); each owns ranges b, b+B, b+2B, ...
+#define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)
+
 // Radix sort (S5)
 #define SGS_RADIX_BITS 8
 #define SGS_RADIX (1 << SGS_RADIX_BITS)
@@ -31,6 +39,10 @@ struct FrameParams {
     int32_t sh_rows;                // float4 rows per Gaussian stored in the scene (by scene degree)
     int64_t n;                      // Gaussians
     int64_t n_chunks;               // ceil(n / 64)
+    int32_t n_ranges;               // ceil(n / SGS_RANGE)
+    int32_t win_rows;               // tile rows per binning window = max(1, SGS_WT / gx)
+    int32_t n_windows;              // ceil((row_end - row_begin) / win_rows)
+    int32_t pad0_;
     int64_t rec_capacity;           // records the queues can hold
     uint32_t flags;
     uint32_t pad_;
@@ -39,7 +51,7 @@ struct FrameParams {
 // Device-resident per-frame status; zeroed by a memset node at frame start, copied to pinned host
 // memory at frame end.
 struct FrameStatus {
-    uint32_t n_visible;             // N_v (also the compaction cursor of k_preprocess)
+    uint32_t n_visible;             // N_v
     uint32_t d_total;               // D
     uint32_t overflow;              // D > rec_capacity: emit/sort/composite did nothing
     uint32_t max_tile_len;

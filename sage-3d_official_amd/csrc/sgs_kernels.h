@@ -3,9 +3,10 @@
 // Stage map (BASELINE.json north_star):
 //   k_scene_layout   upload-time re-layout of the scene into wave-chunked float4 rows (A5)
 //   k_preprocess     S1 SH colour, S2 EWA projection (fp64 geometry), S3 AABB -> tile rect,
-//                    wave-ballot compaction of survivors, balanced per-tile counting (S4 part 1)
+//                    wave-ballot compaction of survivors inside 1024-Gaussian ranges
 //   k_tile_scan      S4: exclusive scan of the per-tile counts, sort-class lists
-//   k_emit           S4: duplication of each splat into the queues of the tiles it touches
+//   k_bin_count      S4: per-workgroup LDS tile histograms -> one global atomic per touched tile
+//   k_bin_emit       S4: duplication of each splat into the queues of the tiles it touches
 //   k_tile_sort      S5: per-tile LSD radix sort on the fp32 depth bits, LDS-resident, ties -> index
 //   k_composite      S6: front-to-back alpha composite, LDS-staged queue batches
 //   k_pack_rgba8     fp32 RGB -> uint8 RGBA (get_rgba()-shaped surface)
@@ -163,20 +164,11 @@ __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
     return (int)f;
 }
 
-// S1-S3 + compaction + per-tile counting.  One lane = one Gaussian, one wave = one 64-Gaussian
-// chunk of the scene (all loads are full 1-KiB rows).  Geometry runs in fp64 (MI355X fp64 vector
-// rate is 1/2 of fp32 and this kernel is HBM-bound), which makes every integer decision (cull,
-// radius, rect, tile counts) agree with the fp64 oracle.
-__global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
-                                                    const float4* __restrict__ geom,
-                                                    const float4* __restrict__ shq,
-                                                    Splat* __restrict__ splats,
-                                                    unsigned* __restrict__ slot_id,
-                                                    unsigned* __restrict__ tile_count,
-                                                    FrameStatus* __restrict__ st) {
-    const int lane = threadIdx.x & 63;
-    const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (chunk >= P.n_chunks) return;                       // wave-uniform
+// One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
+__device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const float4* __restrict__ geom,
+                                                 const float4* __restrict__ shq, Splat* __restrict__ splats,
+                                                 unsigned* __restrict__ slot_id, long long chunk,
+                                                 unsigned slot_base, unsigned* range_cursor, int lane) {
     const long long id = chunk * SGS_WAVE + lane;
 
     const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
@@ -187,7 +179,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
     const bool front = id < P.n && tz > (double)P.near_z && tz <= (double)P.far_z;
 
     bool vis = false;
-    unsigned cnt = 0, rx0 = 0, ry0 = 0, rw = 0, rect01 = 0, rect23 = 0;
+    unsigned rect01 = 0, rect23 = 0;
     float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     if (front) {
         const float4 g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
@@ -244,7 +236,6 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
                 vis = true;
-                cnt = (unsigned)nt; rx0 = (unsigned)x0; ry0 = (unsigned)y0; rw = (unsigned)(x1 - x0);
                 rect01 = (unsigned)x0 | ((unsigned)y0 << 16);
                 rect23 = (unsigned)x1 | ((unsigned)y1 << 16);
                 sx = (float)px; sy = (float)py;
@@ -253,14 +244,14 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
         }
     }
 
-    // wave-ballot compaction: one atomic per wave hands out a block of slots
+    // wave-ballot compaction inside the range: one LDS atomic per wave hands out a block of slots
     const unsigned long long vmask = __ballot(vis);
     const unsigned nvis = (unsigned)__popcll(vmask);
     if (nvis == 0) return;                                  // wave-uniform: whole chunk culled
     unsigned base = 0;
-    if (lane == 0) base = atomicAdd(&st->n_visible, nvis);
+    if (lane == 0) base = atomicAdd(range_cursor, nvis);
     base = __shfl(base, 0);
-    const unsigned slot = base + (unsigned)__popcll(vmask & lanemask_lt(lane));
+    const unsigned slot = slot_base + base + (unsigned)__popcll(vmask & lanemask_lt(lane));
 
     if (vis) {
         // S1: view direction in model space (fp64 difference, fp32 polynomial)
@@ -283,22 +274,43 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
         slot_id[slot] = (unsigned)id;
     }
 
-    // S4 part 1: per-tile counts
-    wave_expand(cnt, rx0, ry0, rw, 0u, 0u, P.gx, lane,
-                [&](bool valid, unsigned tile, unsigned, unsigned) {
-                    if (valid) atomicAdd(&tile_count[tile], 1u);
-                });
+}
+
+// S1-S3 + compaction.  One lane = one Gaussian, one wave = one 64-Gaussian chunk of the scene (all
+// loads are full 1-KiB rows), one workgroup = one RANGE of 1024 Gaussians.  Geometry runs in fp64
+// (MI355X fp64 vector rate is 1/2 of fp32 and this kernel is HBM-bound), which makes every integer
+// decision (cull, radius, rect, tile counts) agree with the fp64 oracle.
+// Survivors are compacted inside their range: slot = range * 1024 + (arrival order in the range),
+// handed out by wave ballot + one LDS atomic per wave.  No device-scope atomic is issued here (a
+// single global cursor serialises at ~12 ns per wave on MI355X); range_nvis[range] tells the
+// consumers how many slots of the range are live.
+__global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
+                                                    const float4* __restrict__ geom,
+                                                    const float4* __restrict__ shq,
+                                                    Splat* __restrict__ splats,
+                                                    unsigned* __restrict__ slot_id,
+                                                    unsigned* __restrict__ range_nvis) {
+    __shared__ unsigned s_cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long range = blockIdx.x;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    for (int round = 0; round < SGS_RANGE_CHUNKS / 4; ++round) {
+        const long long chunk = range * SGS_RANGE_CHUNKS + round * 4 + wave;
+        if (chunk < P.n_chunks) preprocess_chunk(P, geom, shq, splats, slot_id, chunk, (unsigned)(range * SGS_RANGE), &s_cnt, lane);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) range_nvis[range] = s_cnt;
 }
 
 // ------------------------------------------------------------------------------------------------
 // S4: exclusive scan of tile counts (single workgroup; T <= 32400 at 4K), D, longest queue, and
-// the per-class tile lists the sort launches walk.  tile_fill is set to the queue length so that
-// k_emit can hand out slots with atomicSub.
+// the per-class tile lists the sort launches walk.  Every count is cleared once consumed, so the
+// counters are ready for the next frame without a memset.
 #define SGS_SCAN_THREADS 1024
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
-                                                                const unsigned* __restrict__ tile_count,
+                                                                unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
-                                                                unsigned* __restrict__ tile_fill,
                                                                 unsigned* __restrict__ class_list,
                                                                 FrameStatus* __restrict__ st) {
     __shared__ unsigned s_wsum[SGS_SCAN_THREADS / SGS_WAVE];
@@ -328,7 +340,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     for (int t = beg; t < end; ++t) {
         const unsigned c = tile_count[t];
         tile_offset[t] = run;
-        tile_fill[t] = c;
+        tile_count[t] = 0;
         run += c;
         if (c > 1 && !overflow) {
             const int cls = c <= SGS_CAP_S ? 0 : (c <= SGS_CAP_M ? 1 : (c <= SGS_CAP_L ? 2 : 3));
@@ -347,42 +359,120 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4 part 2: duplication.  Walks the compacted splats 64 at a time (grid-stride over waves), expands
-// each rect into its tiles with the same balanced scheme as the counting pass, and drops
-// (depth bits, slot) into the tile's queue.  Slots inside a queue are handed out by atomics, so the
-// queue order is arbitrary here; k_tile_sort makes it deterministic.
-__global__ __launch_bounds__(256) void k_emit(const FrameParams P, const Splat* __restrict__ splats,
-                                              const unsigned* __restrict__ tile_offset,
-                                              unsigned* __restrict__ tile_fill,
-                                              unsigned* __restrict__ rec_key,
-                                              unsigned* __restrict__ rec_val,
-                                              const FrameStatus* __restrict__ st) {
-    if (st->overflow) return;
-    const int lane = threadIdx.x & 63;
-    const unsigned nvis = st->n_visible;
-    const unsigned waves_total = gridDim.x * (blockDim.x >> 6);
-    const unsigned wave0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    for (unsigned long long c0 = (unsigned long long)wave0 * SGS_WAVE; c0 < nvis;
-         c0 += (unsigned long long)waves_total * SGS_WAVE) {
-        const unsigned s = (unsigned)c0 + (unsigned)lane;
-        unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
-        if (s < nvis) {
-            const float4 c = reinterpret_cast<const float4*>(splats + s)[2];
-            key = __float_as_uint(c.y);
-            const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
-            x0 = r01 & 0xffffu; y0 = r01 >> 16;
-            w = (r23 & 0xffffu) - x0;
-            cnt = w * ((r23 >> 16) - y0);
+// S4 binning, part 1 (count) and part 2 (emit).  Both walk the compacted splats range by range
+// (workgroup b owns ranges b, b+B, b+2B, ...: a uniform sample of the scene, so the static split is
+// balanced) and expand every rect into its tiles with wave_expand().
+//
+// Device-scope atomics on MI355X execute in the fabric and serialise per address (~12 ns each), so
+// one atomic per (splat, tile) record is hopeless for a tile that receives 20 k records.  Instead
+// each workgroup keeps the counters of a WINDOW of SGS_WT tiles in LDS (32 KB; a 1080p frame is
+// one window, 4K is four), counts its records there with LDS atomics, and then issues ONE global
+// atomicAdd per tile it touched: the returned value is the workgroup's base inside that tile's queue.
+// The (tile, base) pairs go to a per-workgroup list; after the scan, k_bin_emit reloads them as
+// absolute cursors into LDS and writes every record with an LDS atomic only.
+struct BinTraversal {
+    int wr0, wr1;                       // tile rows of the current window
+};
+
+// Calls f(valid, local tile index, depth bits, slot) for every record of this workgroup's splats
+// that falls into tile rows [wr0, wr1).  Returns the number of live slots seen (first lane valid).
+template <class F>
+__device__ __forceinline__ unsigned bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
+                                             const unsigned* __restrict__ range_nvis, int wr0, int wr1, F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    unsigned seen = 0;
+    for (int r = blockIdx.x; r < P.n_ranges; r += gridDim.x) {
+        const unsigned nv = range_nvis[r];
+        seen += nv;
+        for (unsigned s0 = (unsigned)wave * SGS_WAVE; s0 < nv; s0 += (unsigned)nwaves * SGS_WAVE) {
+            const unsigned s = s0 + (unsigned)lane;
+            const unsigned slot = (unsigned)r * SGS_RANGE + s;
+            unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
+            if (s < nv) {
+                const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
+                key = __float_as_uint(c.y);
+                const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
+                x0 = r01 & 0xffffu;
+                w = (r23 & 0xffffu) - x0;
+                const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+                if (yb > ya) { y0 = (unsigned)(ya - wr0); cnt = w * (unsigned)(yb - ya); }
+            }
+            wave_expand(cnt, x0, y0, w, key, slot, P.gx, lane, f);
         }
-        wave_expand(cnt, x0, y0, w, key, s, P.gx, lane,
-                    [&](bool valid, unsigned tile, unsigned okey, unsigned oslot) {
-                        if (valid) {
-                            const unsigned k = atomicSub(&tile_fill[tile], 1u) - 1u;
-                            const unsigned dst = tile_offset[tile] + k;
-                            rec_key[dst] = okey;
-                            rec_val[dst] = oslot;
-                        }
-                    });
+    }
+    return seen;
+}
+
+__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
+                                                               const Splat* __restrict__ splats,
+                                                               const unsigned* __restrict__ range_nvis,
+                                                               unsigned* __restrict__ tile_count,
+                                                               uint2* __restrict__ blk_list,
+                                                               unsigned* __restrict__ blk_len,
+                                                               FrameStatus* __restrict__ st) {
+    __shared__ unsigned s_cnt[SGS_WT];
+    __shared__ unsigned short s_list[SGS_WT];
+    __shared__ unsigned s_nlist;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SGS_WT; i += SGS_BIN_THREADS) s_cnt[i] = 0;
+    for (int w = 0; w < P.n_windows; ++w) {
+        const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
+        if (tid == 0) s_nlist = 0;
+        __syncthreads();
+        const unsigned seen = bin_walk(P, splats, range_nvis, wr0, wr1,
+                                       [&](bool valid, unsigned tl, unsigned, unsigned) {
+                                           if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
+                                               s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
+                                       });
+        __syncthreads();
+        // flush: one device-scope atomic per touched tile; its return value is our base in the queue
+        const unsigned nl = s_nlist;
+        uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
+        for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
+            const unsigned tl = s_list[i];
+            const unsigned c = s_cnt[tl];
+            s_cnt[tl] = 0;                                     // ready for the next window
+            const unsigned base = atomicAdd(&tile_count[(unsigned)wr0 * (unsigned)P.gx + tl], c);
+            out[i] = make_uint2(tl, base);
+        }
+        if (tid == 0) {
+            blk_len[blockIdx.x * SGS_MAX_WINDOWS + w] = nl;
+            if (w == 0 && seen) atomicAdd(&st->n_visible, seen);    // one per workgroup
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams P,
+                                                              const Splat* __restrict__ splats,
+                                                              const unsigned* __restrict__ range_nvis,
+                                                              const unsigned* __restrict__ tile_offset,
+                                                              const uint2* __restrict__ blk_list,
+                                                              const unsigned* __restrict__ blk_len,
+                                                              unsigned* __restrict__ rec_key,
+                                                              unsigned* __restrict__ rec_val,
+                                                              const FrameStatus* __restrict__ st) {
+    __shared__ unsigned s_next[SGS_WT];
+    if (st->overflow) return;
+    const int tid = threadIdx.x;
+    for (int w = 0; w < P.n_windows; ++w) {
+        const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
+        const unsigned nl = blk_len[blockIdx.x * SGS_MAX_WINDOWS + w];
+        const uint2* in = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
+        for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
+            const uint2 e = in[i];
+            s_next[e.x] = tile_offset[(unsigned)wr0 * (unsigned)P.gx + e.x] + e.y;
+        }
+        __syncthreads();
+        bin_walk(P, splats, range_nvis, wr0, wr1,
+                 [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
+                     if (valid) {
+                         const unsigned dst = atomicAdd(&s_next[tl], 1u);
+                         rec_key[dst] = okey;
+                         rec_val[dst] = oslot;
+                     }
+                 });
+        __syncthreads();
     }
 }
 

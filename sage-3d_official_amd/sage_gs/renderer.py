@@ -262,9 +262,10 @@ class Renderer:
         """(tile_offsets, per-tile sorted Gaussian ids, Gaussian id of each slot, splat words [N_v,12])."""
         off = self.debug_buffer(_capi.BUF_TILE_OFFSETS, np.uint32).astype(np.int64)
         slots = self.debug_buffer(_capi.BUF_SORTED_SLOTS, np.uint32)
-        ids = self.debug_buffer(_capi.BUF_SLOT_IDS, np.uint32).astype(np.int64)
+        ids = self.debug_buffer(_capi.BUF_SLOT_IDS, np.uint32)
         splats = self.debug_buffer(_capi.BUF_SPLATS, np.uint32).reshape(-1, 12)
-        return off, ids[slots], ids, splats
+        live = ids != 0xFFFFFFFF
+        return off, ids[slots].astype(np.int64), ids[live].astype(np.int64), splats[live]
 
     def set_record_capacity(self, n: int):
         self._lib.check(self._lib.sgs_set_record_capacity(self._ctx, int(n)), self._ctx)

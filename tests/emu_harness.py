@@ -102,7 +102,8 @@ class EmuRenderer:
         slots = self.debug(_capi.BUF_SORTED_SLOTS, np.uint32)
         ids = self.debug(_capi.BUF_SLOT_IDS, np.uint32)
         splats = self.debug(_capi.BUF_SPLATS, np.uint32).reshape(-1, 12)
-        return off.astype(np.int64), ids[slots].astype(np.int64), ids.astype(np.int64), splats
+        live = ids != 0xFFFFFFFF
+        return off.astype(np.int64), ids[slots].astype(np.int64), ids[live].astype(np.int64), splats[live]
 
     def close(self):
         if self.scene is not None:

@@ -48,6 +48,11 @@ def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(640, 368))
 
 
+def test_two_binning_windows(drv):
+    # 129 x 65 = 8385 tiles > SGS_WT (8192): the binning kernels walk two LDS windows
+    pc.case_full_grid_splat(drv, res=(2064, 1040))
+
+
 def test_determinism(drv):
     pc.case_determinism(drv, n=1500)
 
