@@ -635,11 +635,25 @@ __global__ __launch_bounds__(256) void k_tile_sort(const FrameParams P, int cls,
 
 // ------------------------------------------------------------------------------------------------
 // S6: front-to-back alpha composite.  One workgroup per 16x16 tile, one lane per pixel; each wave
-// owns an 8x8 quadrant.  The tile's sorted queue is streamed through LDS in batches of 256 splats
-// (each lane gathers one 48-B splat), then every lane walks the batch with broadcast LDS reads.
+// owns an 8x8 quadrant.  The tile's sorted queue is streamed through LDS in batches of 256 splats:
+//   * every lane gathers one 48-B splat of the NEXT batch into registers while the current batch is
+//     being blended (global latency hidden behind the VALU work);
+//   * when staging a batch, the gathering lane tests its splat against the four quadrants (the
+//     axis-aligned extent of the alpha >= 1/255 ellipse, padded) and the four ballots are stored in LDS,
+//     so each wave walks only the splats that can touch ITS 64 pixels, with scalar bit scans;
+//   * the per-pixel body is branch-free (predicated), and the LDS reads of splat k+1 are issued
+//     before the arithmetic of splat k.
 // Block b is mapped so that consecutive blocks on one XCD (b % 8) render neighbouring tiles, which
 // share most of their splats -> the gathers hit that XCD's L2.
 #define SGS_BATCH 256
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ __launch_bounds__(256) void k_composite(const FrameParams P,
                                                    const unsigned* __restrict__ tile_offset,
                                                    const unsigned* __restrict__ rec_val,
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameParams P,
     __shared__ float4 s_a[SGS_BATCH];
     __shared__ float4 s_b[SGS_BATCH];
     __shared__ float s_c[SGS_BATCH];
+    __shared__ unsigned long long s_ball[2][4][4];   // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_live[2];       // waves with an unfinished pixel, double-buffered by batch parity
     __shared__ unsigned s_used[4];
     if (st->overflow) return;
@@ -665,62 +680,111 @@ __global__ __launch_bounds__(256) void k_composite(const FrameParams P,
     const unsigned py = tile_y * 16u + (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     const float fpx = (float)px, fpy = (float)py;
+    const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(tile_y * 16u);
+    const float amin = P.alpha_min, amax = P.alpha_max, tmin = P.t_min;
+    const float k_cut = -2.0f * __logf(amin);          // alpha >= amin  <=>  d^T Q d <= 2 ln(o) + k_cut
 
     const unsigned beg = tile_offset[tile];
     const unsigned n = tile_offset[tile + 1] - beg;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     bool done = !inside;
-    unsigned used = 0;                   // records this pixel examined (D_f bookkeeping)
+    unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     if (tid < 2) s_live[tid] = 0;
+    // prefetch batch 0 into registers
+    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
+    if ((unsigned)tid < min((unsigned)SGS_BATCH, n)) {
+        const float4* sp = reinterpret_cast<const float4*>(splats + rec_val[beg + tid]);
+        nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+    }
     __syncthreads();
     unsigned it = 0;
     for (unsigned base = 0; base < n; base += SGS_BATCH, ++it) {
-        const bool wave_live = __ballot(!done) != 0ull;
-        if (lane == 0 && wave_live) atomicAdd(&s_live[it & 1u], 1u);
-        // gather this batch: each lane fetches one 48-B splat
+        const unsigned par = it & 1u;
         const unsigned m = min((unsigned)SGS_BATCH, n - base);
-        if ((unsigned)tid < m) {
-            const unsigned s = rec_val[beg + base + tid];
-            const float4* sp = reinterpret_cast<const float4*>(splats + s);
-            s_a[tid] = sp[0];
-            s_b[tid] = sp[1];
-            s_c[tid] = sp[2].x;
-        }
-        __syncthreads();                 // batch staged, liveness counted
-        if (s_live[it & 1u] == 0) break; // every pixel of the tile has terminated (uniform)
-        if (wave_live) {
-            for (unsigned j = 0; j < m; ++j) {
-                if ((j & 15u) == 0u && __ballot(!done) == 0ull) break;   // wave-uniform early out
-                if (!done) {
-                    const float4 A = s_a[j];
-                    const float4 B = s_b[j];
-                    used = base + j + 1u;
-                    const float dx = A.x - fpx, dy = A.y - fpy;
-                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                    if (power <= 0.0f) {
-                        const float alpha = fminf(P.alpha_max, B.y * __expf(power));
-                        if (alpha >= P.alpha_min) {
-                            const float testT = T * (1.0f - alpha);
-                            if (testT < P.t_min) done = true;
-                            else {
-                                const float wgt = alpha * T;
-                                C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * s_c[j];
-                                T = testT;
-                            }
-                        }
-                    }
+        const bool wave_live = __ballot(!done) != 0ull;
+        if (lane == 0 && wave_live) atomicAdd(&s_live[par], 1u);
+        // ---- stage the prefetched batch + per-quadrant overlap ballots --------------------------
+        const bool have = (unsigned)tid < m;
+        unsigned qbits = 0;
+        if (have) {
+            s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
+            // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K * Sigma_xx), sqrt(K * Sigma_yy)
+            const float K = 2.0f * __logf(nB.y) + k_cut;
+            const float detq = nA.z * nB.x - nA.w * nA.w;
+            if (K > 0.0f) {
+                float hx = 3.0e38f, hy = 3.0e38f;
+                if (detq > 1.0e-12f * nA.z * nB.x) {       // otherwise fp32 cannot bound it: keep everywhere
+                    const float inv = K / detq;
+                    hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
+                    hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
                 }
+                const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
+                const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
+                const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
+                qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
+                        ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
             }
         }
-        __syncthreads();                 // batch consumed by every wave; s_live[it&1] read by all
-        if (tid == 0) s_live[it & 1u] = 0;   // next used two batches from now
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const unsigned long long bal = __ballot((qbits >> q) & 1u);
+            if (lane == 0) s_ball[par][q][wave] = bal;
+        }
+        // ---- prefetch the next batch (loads stay in flight across the blend loop) ----------------
+        const unsigned nbase = base + SGS_BATCH;
+        if (nbase < n && (unsigned)tid < min((unsigned)SGS_BATCH, n - nbase)) {
+            const float4* sp = reinterpret_cast<const float4*>(splats + rec_val[beg + nbase + tid]);
+            nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+        }
+        __syncthreads();                 // batch staged, liveness counted
+        if (s_live[par] == 0) break;     // every pixel of the tile has terminated (uniform)
+        if (wave_live) {
+            bool wave_done = false;
+            for (int gw = 0; gw < 4 && !wave_done; ++gw) {
+                unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
+                if (mask == 0ull) continue;
+                unsigned j = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                mask &= mask - 1ull;
+                float4 A = s_a[j], B = s_b[j]; float cb_ = s_c[j];
+                unsigned cnt = 0;
+                for (;;) {
+                    // issue the LDS reads of the next splat before the arithmetic of this one
+                    const bool more = mask != 0ull;
+                    unsigned jn = j;
+                    float4 An = A, Bn = B; float cn = cb_;
+                    if (more) {
+                        jn = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                        mask &= mask - 1ull;
+                        An = s_a[jn]; Bn = s_b[jn]; cn = s_c[jn];
+                    }
+                    const float dx = A.x - fpx, dy = A.y - fpy;
+                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                    const float alpha = fminf(amax, B.y * __expf(power));
+                    const float testT = T * (1.0f - alpha);
+                    used = done ? used : base + j + 1u;
+                    const bool hit = !done && power <= 0.0f && alpha >= amin;
+                    const bool stop = hit && testT < tmin;
+                    const bool blend = hit && !stop;
+                    const float wgt = blend ? alpha * T : 0.0f;
+                    C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;
+                    T = blend ? testT : T;
+                    done = done || stop;
+                    if ((++cnt & 7u) == 0u && __ballot(!done) == 0ull) { wave_done = true; break; }
+                    if (!more) break;
+                    j = jn; A = An; B = Bn; cb_ = cn;
+                }
+            }
+            if (!done) used = base + m;      // still live: the whole batch counts as examined
+        }
+        __syncthreads();                 // batch consumed by every wave; s_live[par] read by all
+        if (tid == 0) s_live[par] = 0;   // next used two batches from now
     }
     if (inside) {
         float* o = out_rgb + ((size_t)py * P.width + px) * 3;
         o[0] = C0 + T * P.bg[0]; o[1] = C1 + T * P.bg[1]; o[2] = C2 + T * P.bg[2];
     }
-    if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = max over the tile's pixels
+    if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
         const unsigned wu = wave_max(inside ? used : 0u);
         __syncthreads();
         if (lane == 0) s_used[wave] = wu;
