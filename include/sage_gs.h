@@ -44,17 +44,18 @@ enum { SGS_BACKEND_CPU = 0, SGS_BACKEND_HIP = 1 };
 enum {
     SGS_FLAG_ASYNC  = 1u << 0,     /* do not synchronise the stream; collect with sgs_frame_sync() */
     SGS_FLAG_TIMING = 1u << 1,     /* bracket every stage with HIP events (fills sgs_stats.ms[]) */
-    SGS_FLAG_STATS  = 1u << 2      /* also count D_f (records consumed by the composite) */
+    SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite) */
+    SGS_FLAG_FULL_SORT = 1u << 3   /* tests: order every queue completely (the production path sorts
+                                      lazily and stops once a tile's pixels have all terminated) */
 };
 
 /* Pipeline stages, in launch order (index of sgs_stats.ms[] / .bytes[]). */
 enum {
-    SGS_STAGE_PREPROCESS = 0,      /* S1-S3 (+ per-tile counting): SH, EWA projection, AABB   */
-    SGS_STAGE_SCAN       = 1,      /* S4a: exclusive scan of the per-tile counts               */
-    SGS_STAGE_EMIT       = 2,      /* S4b: duplication into per-tile queues                    */
-    SGS_STAGE_SORT       = 3,      /* S5: per-tile radix depth sort                            */
-    SGS_STAGE_COMPOSITE  = 4,      /* S6: front-to-back alpha composite                        */
-    SGS_NUM_STAGES       = 5
+    SGS_STAGE_PREPROCESS = 0,      /* S1-S3: SH, EWA projection, AABB, compaction (k_preprocess)          */
+    SGS_STAGE_COUNT      = 1,      /* S4a: per-tile counts + exclusive scan (k_bin_count, k_tile_scan)     */
+    SGS_STAGE_EMIT       = 2,      /* S4b: duplication into per-tile queues (k_bin_emit)                   */
+    SGS_STAGE_RENDER     = 3,      /* S5+S6 fused: lazy per-tile radix depth sort + composite (k_tile_render) */
+    SGS_NUM_STAGES       = 4
 };
 
 typedef struct sgs_ctx sgs_ctx;        /* opaque */
@@ -94,7 +95,7 @@ typedef struct sgs_stats {
     int64_t n_pixels;      /* pixels written by this call                                */
     int32_t n_tiles;       /* tiles in [tile_row_begin, tile_row_end)                    */
     int32_t max_tile_len;  /* longest per-tile queue                                     */
-    int32_t n_spill_tiles; /* tiles whose queue exceeded the LDS sort capacity           */
+    int32_t n_spill_tiles; /* depth buckets too long for LDS, sorted through HBM         */
     int32_t retries;       /* re-renders after growing the record capacity               */
     float ms[SGS_NUM_STAGES];      /* per-stage GPU time (SGS_FLAG_TIMING), else 0       */
     float ms_total;                /* first launch -> last launch (SGS_FLAG_TIMING)      */
@@ -150,7 +151,7 @@ int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int
  * Returns the number of bytes the buffer holds (copying at most `bytes`), or a negative status. */
 enum {
     SGS_BUF_TILE_OFFSETS = 0,      /* uint32[T+1]                                                */
-    SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues after S5 (slot numbers)        */
+    SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues in (depth, index) order — complete only with SGS_FLAG_FULL_SORT */
     SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    Gaussian index of each slot, 0xFFFFFFFF = dead; S = ceil(N/1024)*1024 */
     SGS_BUF_SPLATS       = 3       /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
 };

@@ -44,7 +44,7 @@ struct sgs_ctx {
     unsigned* slot_id = nullptr;
     // per-tile scratch
     int tile_cap = 0;
-    unsigned *tile_count = nullptr, *tile_offset = nullptr, *class_list = nullptr;
+    unsigned *tile_count = nullptr, *tile_offset = nullptr;
     // binning scratch: live slots per range, per-workgroup (tile, base) lists
     int64_t range_cap = 0;
     unsigned* range_nvis = nullptr;
@@ -125,7 +125,6 @@ int ensure_tiles(sgs_ctx* ctx, int tiles) {
     int rc;
     if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->class_list, (size_t)tiles * SGS_SORT_CLASSES)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
     ctx->tile_cap = tiles;
@@ -224,7 +223,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
         hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
                            ctx->range_nvis, ctx->tile_count, ctx->blk_list, ctx->blk_len, st);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
-                       ctx->tile_offset, ctx->class_list, st);
+                       ctx->tile_offset, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
@@ -234,28 +233,12 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
-    if (ntiles > 0 && scene->n_chunks > 0) {
-        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_S, false>), dim3(ntiles), dim3(256), 0, stream, P, 0,
-                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
-                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
-        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_M, false>), dim3(ntiles), dim3(256), 0, stream, P, 1,
-                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
-                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
-        hipLaunchKernelGGL((sgs::k_tile_sort<SGS_CAP_L, false>), dim3(ntiles), dim3(256), 0, stream, P, 2,
-                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
-                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
-        hipLaunchKernelGGL((sgs::k_tile_sort<1, true>), dim3(ntiles), dim3(256), 0, stream, P, 3,
-                           ctx->tile_offset, ctx->class_list, ctx->rec_key, ctx->rec_val, ctx->alt_key,
-                           ctx->alt_val, ctx->slot_id, ctx->splats, st);
-    }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
-
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL(sgs::k_composite, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset,
-                           ctx->rec_val, ctx->splats, out_rgb, st);
+        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec_key,
+                           ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->slot_id, ctx->splats, out_rgb, st);
     }
-    if (timed) SGS_HIP(ctx, hipEventRecord(ev[5], stream));
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
     SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
 
@@ -285,10 +268,9 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
     stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 48 + 4) * nv;
-    stats->bytes[SGS_STAGE_SCAN] = 16 * nv + 16 * ((int64_t)ctx->last_T + 1);   // rect re-read + counters
+    stats->bytes[SGS_STAGE_COUNT] = 16 * nv + 16 * ((int64_t)ctx->last_T + 1);   // rect re-read + counters
     stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
-    stats->bytes[SGS_STAGE_SORT] = 12 * D;
-    stats->bytes[SGS_STAGE_COMPOSITE] = 40 * Df + 12 * pixels;
+    stats->bytes[SGS_STAGE_RENDER] = 8 * D + 36 * Df + 12 * pixels;               // every record seen once, D_f splats blended
     if (timed && ctx->ev) {
         hipEvent_t* ev = ctx->ev[slot];
         for (int i = 0; i < SGS_NUM_STAGES; ++i) {
@@ -353,7 +335,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->class_list, ctx->range_nvis,
+    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->range_nvis,
                     ctx->blk_list, ctx->blk_len, ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -19,10 +19,7 @@
 // Radix sort (S5)
 #define SGS_RADIX_BITS 8
 #define SGS_RADIX (1 << SGS_RADIX_BITS)
-#define SGS_SORT_CLASSES 4          // S / M / L (LDS-resident) and X (spill: ping-pong in HBM)
-#define SGS_CAP_S 1024
-#define SGS_CAP_M 4096
-#define SGS_CAP_L 9216
+#define SGS_SORT_CLASSES 4
 #define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
 
 // Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).
@@ -55,7 +52,7 @@ struct FrameStatus {
     uint32_t d_total;               // D
     uint32_t overflow;              // D > rec_capacity: emit/sort/composite did nothing
     uint32_t max_tile_len;
-    uint32_t class_count[SGS_SORT_CLASSES];   // tiles per sort class
+    uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
     unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
     uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
     uint32_t pad_[5];

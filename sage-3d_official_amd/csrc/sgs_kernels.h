@@ -4,11 +4,11 @@
 //   k_scene_layout   upload-time re-layout of the scene into wave-chunked float4 rows (A5)
 //   k_preprocess     S1 SH colour, S2 EWA projection (fp64 geometry), S3 AABB -> tile rect,
 //                    wave-ballot compaction of survivors inside 1024-Gaussian ranges
-//   k_tile_scan      S4: exclusive scan of the per-tile counts, sort-class lists
+//   k_tile_scan      S4: exclusive scan of the per-tile counts
 //   k_bin_count      S4: per-workgroup LDS tile histograms -> one global atomic per touched tile
 //   k_bin_emit       S4: duplication of each splat into the queues of the tiles it touches
-//   k_tile_sort      S5: per-tile LSD radix sort on the fp32 depth bits, LDS-resident, ties -> index
-//   k_composite      S6: front-to-back alpha composite, LDS-staged queue batches
+//   k_tile_render    S5+S6 fused: per-tile MSD bucket partition, lazy LDS radix sort of bucket groups
+//                    (ties -> index), front-to-back alpha composite of LDS-staged batches
 //   k_pack_rgba8     fp32 RGB -> uint8 RGBA (get_rgba()-shaped surface)
 //
 // None of these has a counterpart in the reference (it has no rasterizer); the
@@ -304,23 +304,19 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4: exclusive scan of tile counts (single workgroup; T <= 32400 at 4K), D, longest queue, and
-// the per-class tile lists the sort launches walk.  Every count is cleared once consumed, so the
-// counters are ready for the next frame without a memset.
+// S4: exclusive scan of tile counts (single workgroup; T <= 32400 at 4K), D and the longest queue.
+// Every count is cleared once consumed, so the counters are ready for the next frame without a memset.
 #define SGS_SCAN_THREADS 1024
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
                                                                 unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
-                                                                unsigned* __restrict__ class_list,
                                                                 FrameStatus* __restrict__ st) {
     __shared__ unsigned s_wsum[SGS_SCAN_THREADS / SGS_WAVE];
     __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
-    __shared__ unsigned s_class[SGS_SORT_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = P.gx * P.gy;
     const int per = (T + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS;
     const int beg = tid * per, end = min(T, beg + per);
-    if (tid < SGS_SORT_CLASSES) s_class[tid] = 0;
     unsigned sum = 0, mx = 0;
     for (int t = beg; t < end; ++t) { const unsigned c = tile_count[t]; sum += c; mx = c > mx ? c : mx; }
     const unsigned incl = wave_incl_scan(sum, lane);
@@ -330,32 +326,24 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     __syncthreads();
     unsigned wbase = 0, total = 0, tmax = 0;
     for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) {
-        const unsigned s = s_wsum[w];
-        if (w < wave) wbase += s;
-        total += s;
+        const unsigned sw = s_wsum[w];
+        if (w < wave) wbase += sw;
+        total += sw;
         tmax = s_wmax[w] > tmax ? s_wmax[w] : tmax;
     }
     unsigned run = wbase + incl - sum;
-    const bool overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity;
     for (int t = beg; t < end; ++t) {
         const unsigned c = tile_count[t];
         tile_offset[t] = run;
         tile_count[t] = 0;
         run += c;
-        if (c > 1 && !overflow) {
-            const int cls = c <= SGS_CAP_S ? 0 : (c <= SGS_CAP_M ? 1 : (c <= SGS_CAP_L ? 2 : 3));
-            const unsigned k = atomicAdd(&s_class[cls], 1u);
-            class_list[(size_t)cls * T + k] = (unsigned)t;
-        }
     }
-    __syncthreads();
     if (tid == 0) {
         tile_offset[T] = total;
         st->d_total = total;
         st->max_tile_len = tmax;
-        st->overflow = overflow ? 1u : 0u;
+        st->overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity ? 1u : 0u;
     }
-    if (tid < SGS_SORT_CLASSES) st->class_count[tid] = s_class[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,47 +547,19 @@ __device__ __forceinline__ void radix_sort_bits(unsigned* a_k, unsigned* a_v, un
     }
 }
 
-template <int CAP, bool SPILL>
-__global__ __launch_bounds__(256) void k_tile_sort(const FrameParams P, int cls,
-                                                   const unsigned* __restrict__ tile_offset,
-                                                   const unsigned* __restrict__ class_list,
-                                                   unsigned* rec_key, unsigned* rec_val,
-                                                   unsigned* alt_key, unsigned* alt_val,
-                                                   const unsigned* __restrict__ slot_id,
-                                                   const Splat* __restrict__ splats,
-                                                   FrameStatus* st) {
-    __shared__ SortShared sh;
-    __shared__ unsigned s_buf[SPILL ? 4 : 4 * CAP];
-    if (st->overflow) return;
-    if (blockIdx.x >= st->class_count[cls]) return;
-    const int tid = threadIdx.x;
-    const unsigned tile = class_list[(size_t)cls * (P.gx * P.gy) + blockIdx.x];
-    const unsigned beg = tile_offset[tile];
-    const unsigned n = tile_offset[tile + 1] - beg;
-
-    unsigned *a_k, *a_v, *b_k, *b_v;
-    if (SPILL) { a_k = rec_key + beg; a_v = rec_val + beg; b_k = alt_key + beg; b_v = alt_val + beg; }
-    else { a_k = s_buf; a_v = s_buf + CAP; b_k = s_buf + 2 * CAP; b_v = s_buf + 3 * CAP; }
-
-    if (tid == 0) { sh.kmin = 0xffffffffu; sh.kmax = 0u; sh.flag = 0u; }
+// Sorts (k,v)[0..n) by (depth bits, Gaussian index); b_k/b_v are ping-pong space of the same size.
+// Keys are known to lie in [sub, sub + 2^nbits).  All threads of the workgroup must call it.
+__device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsigned* b_k, unsigned* b_v,
+                                             unsigned n, unsigned sub, unsigned nbits, SortShared& sh,
+                                             const unsigned* __restrict__ slot_id,
+                                             const Splat* __restrict__ splats, long long n_gauss,
+                                             FrameStatus* st) {
+    const unsigned tid = threadIdx.x;
+    if (tid == 0) sh.flag = 0u;
     __syncthreads();
-    // load (LDS classes) and per-tile key range: only the bits that differ inside this tile are sorted
-    unsigned kmn = 0xffffffffu, kmx = 0u;
-    for (unsigned i = tid; i < n; i += 256) {
-        const unsigned k = rec_key[beg + i];
-        if (!SPILL) { a_k[i] = k; a_v[i] = rec_val[beg + i]; }
-        kmn = k < kmn ? k : kmn; kmx = k > kmx ? k : kmx;
-    }
-    kmn = wave_min(kmn); kmx = wave_max(kmx);
-    if ((tid & 63) == 0) { atomicMin(&sh.kmin, kmn); atomicMax(&sh.kmax, kmx); }
-    __syncthreads();
-    const unsigned sub = sh.kmin;
-    const unsigned span = sh.kmax - sub;
-    const unsigned nbits = span ? 32u - (unsigned)__clz((int)span) : 0u;
     radix_sort_bits(a_k, a_v, b_k, b_v, n, sub, nbits, sh);
-
     // Equal depth bits must order by Gaussian index.  Runs of equal keys are
-    // contiguous now; short ones are fixed in place by their first lane, a long one flags the tile.
+    // contiguous now; short ones are fixed in place by their first lane, a long one flags the segment.
     for (unsigned i = tid; i + 1 < n; i += 256) {
         const unsigned k = a_k[i];
         if (a_k[i + 1] == k && (i == 0 || a_k[i - 1] != k)) {
@@ -621,21 +581,34 @@ __global__ __launch_bounds__(256) void k_tile_sort(const FrameParams P, int cls,
         // rare: stable two-key sort — first by Gaussian index, then by depth bits
         for (unsigned i = tid; i < n; i += 256) a_k[i] = slot_id[a_v[i]];
         __syncthreads();
-        const unsigned idbits = P.n > 1 ? 64u - (unsigned)__clzll((long long)(P.n - 1)) : 1u;
+        const unsigned idbits = n_gauss > 1 ? 64u - (unsigned)__clzll((long long)(n_gauss - 1)) : 1u;
         radix_sort_bits(a_k, a_v, b_k, b_v, n, 0u, idbits, sh);
         for (unsigned i = tid; i < n; i += 256) a_k[i] = splats[a_v[i]].key;
         __syncthreads();
         radix_sort_bits(a_k, a_v, b_k, b_v, n, sub, nbits, sh);
         if (tid == 0) atomicAdd(&st->n_resort_tiles, 1u);
     }
-    if (!SPILL) {
-        for (unsigned i = tid; i < n; i += 256) rec_val[beg + i] = a_v[i];
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// S6: front-to-back alpha composite.  One workgroup per 16x16 tile, one lane per pixel; each wave
-// owns an 8x8 quadrant.  The tile's sorted queue is streamed through LDS in batches of 256 splats:
+// S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.
+//
+// Measured on the 3 M-Gaussian scene: a tile's queue holds ~900 records on average (up to 20 k), but
+// its pixels saturate after ~200 (p99 ~1000) — 80 % of a fully sorted queue is never read.  So the
+// workgroup of a tile
+//   1. partitions its queue into SGS_NB depth buckets with one MSD pass on the fp32 depth bits
+//      (bucket = (bits >> 19) - bits(near) >> 19: 16 buckets per binade of view depth, so buckets are
+//      fine near the camera where it matters); counters in LDS, records to the alt buffers (queues
+//      of <= SGS_GCAP records skip this and form a single group);
+//   2. walks the buckets front to back in groups of <= SGS_GCAP records: loads a group into LDS,
+//      finishes its order with the LDS radix sort above (only the bits that vary inside the group,
+//      ties -> Gaussian index), and blends it;
+//   3. stops as soon as every pixel of the tile has terminated.
+// A single bucket larger than SGS_GCAP (thousands of splats within 4 % of one depth) is sorted through
+// HBM with the same routine, ping-ponging between the two record buffers.
+//
+// Blend stage: one lane per pixel, each wave owns an 8x8 quadrant.  A group is streamed through LDS
+// in batches of 256 splats:
 //   * every lane gathers one 48-B splat of the NEXT batch into registers while the current batch is
 //     being blended (global latency hidden behind the VALU work);
 //   * when staging a batch, the gathering lane tests its splat against the four quadrants (the
@@ -646,6 +619,9 @@ __global__ __launch_bounds__(256) void k_tile_sort(const FrameParams P, int cls,
 // Block b is mapped so that consecutive blocks on one XCD (b % 8) render neighbouring tiles, which
 // share most of their splats -> the gathers hit that XCD's L2.
 #define SGS_BATCH 256
+#define SGS_NB 256
+#define SGS_BUCKET_SHIFT 19
+#define SGS_GCAP 1024
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
@@ -654,25 +630,31 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void k_composite(const FrameParams P,
-                                                   const unsigned* __restrict__ tile_offset,
-                                                   const unsigned* __restrict__ rec_val,
-                                                   const Splat* __restrict__ splats,
-                                                   float* __restrict__ out_rgb,
-                                                   FrameStatus* st) {
+__global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
+                                                     const unsigned* __restrict__ tile_offset,
+                                                     unsigned* rec_key, unsigned* rec_val,
+                                                     unsigned* alt_key, unsigned* alt_val,
+                                                     const unsigned* __restrict__ slot_id,
+                                                     const Splat* __restrict__ splats,
+                                                     float* __restrict__ out_rgb,
+                                                     FrameStatus* st) {
+    __shared__ SortShared sh;
+    __shared__ unsigned s_buf[4 * SGS_GCAP];         // group keys | vals | ping-pong keys | vals
+    __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
+    __shared__ unsigned s_boff[SGS_NB + 1];           // bucket offsets inside the queue
     __shared__ float4 s_a[SGS_BATCH];
     __shared__ float4 s_b[SGS_BATCH];
     __shared__ float s_c[SGS_BATCH];
-    __shared__ unsigned long long s_ball[2][4][4];   // [batch parity][quadrant][gathering wave]
-    __shared__ unsigned s_live[2];       // waves with an unfinished pixel, double-buffered by batch parity
+    __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
+    __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_used[4];
     if (st->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware remap of the block index over this call's tiles
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
     const unsigned per_xcd = (ntiles + 7u) / 8u;
-    const unsigned b = blockIdx.x;
-    const unsigned t_local = (b & 7u) * per_xcd + (b >> 3);
+    const unsigned blk = blockIdx.x;
+    const unsigned t_local = (blk & 7u) * per_xcd + (blk >> 3);
     if (t_local >= ntiles) return;       // workgroup-uniform
     const unsigned tile = (unsigned)(P.row_begin * P.gx) + t_local;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
@@ -683,6 +665,7 @@ __global__ __launch_bounds__(256) void k_composite(const FrameParams P,
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(tile_y * 16u);
     const float amin = P.alpha_min, amax = P.alpha_max, tmin = P.t_min;
     const float k_cut = -2.0f * __logf(amin);          // alpha >= amin  <=>  d^T Q d <= 2 ln(o) + k_cut
+    const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
 
     const unsigned beg = tile_offset[tile];
     const unsigned n = tile_offset[tile + 1] - beg;
@@ -690,95 +673,188 @@ __global__ __launch_bounds__(256) void k_composite(const FrameParams P,
     bool done = !inside;
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
-    if (tid < 2) s_live[tid] = 0;
-    // prefetch batch 0 into registers
-    float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
-    if ((unsigned)tid < min((unsigned)SGS_BATCH, n)) {
-        const float4* sp = reinterpret_cast<const float4*>(splats + rec_val[beg + tid]);
-        nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+    // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
+    const bool parted = n > SGS_GCAP;
+    const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
+    const unsigned* src_k = rec_key + beg;                 // where the (partitioned) queue lives
+    const unsigned* src_v = rec_val + beg;
+    if (tid < 2) s_any[tid] = 0;
+    if (parted) {
+        s_bcnt[tid] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < n; i += 256) {
+            const unsigned bk = min((unsigned)(SGS_NB - 1), (rec_key[beg + i] >> SGS_BUCKET_SHIFT) - kbase);
+            atomicAdd(&s_bcnt[bk], 1u);
+        }
+        __syncthreads();
+        {
+            const unsigned c = s_bcnt[tid];
+            const unsigned incl = wave_incl_scan(c, lane);
+            if (lane == 63) sh.wsum[wave] = incl;
+            __syncthreads();
+            unsigned ex = incl - c;
+            for (int w = 0; w < wave; ++w) ex += sh.wsum[w];
+            s_boff[tid] = ex;
+            s_bcnt[tid] = ex;                             // scatter cursor
+            if (tid == SGS_NB - 1) s_boff[SGS_NB] = ex + c;
+        }
+        __syncthreads();
+        for (unsigned i = tid; i < n; i += 256) {
+            const unsigned k = rec_key[beg + i], v = rec_val[beg + i];
+            const unsigned bk = min((unsigned)(SGS_NB - 1), (k >> SGS_BUCKET_SHIFT) - kbase);
+            const unsigned pos = atomicAdd(&s_bcnt[bk], 1u);
+            alt_key[beg + pos] = k;
+            alt_val[beg + pos] = v;
+        }
+        src_k = alt_key + beg; src_v = alt_val + beg;
     }
     __syncthreads();
-    unsigned it = 0;
-    for (unsigned base = 0; base < n; base += SGS_BATCH, ++it) {
-        const unsigned par = it & 1u;
-        const unsigned m = min((unsigned)SGS_BATCH, n - base);
-        const bool wave_live = __ballot(!done) != 0ull;
-        if (lane == 0 && wave_live) atomicAdd(&s_live[par], 1u);
-        // ---- stage the prefetched batch + per-quadrant overlap ballots --------------------------
-        const bool have = (unsigned)tid < m;
-        unsigned qbits = 0;
-        if (have) {
-            s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
-            // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K * Sigma_xx), sqrt(K * Sigma_yy)
-            const float K = 2.0f * __logf(nB.y) + k_cut;
-            const float detq = nA.z * nB.x - nA.w * nA.w;
-            if (K > 0.0f) {
-                float hx = 3.0e38f, hy = 3.0e38f;
-                if (detq > 1.0e-12f * nA.z * nB.x) {       // otherwise fp32 cannot bound it: keep everywhere
-                    const float inv = K / detq;
-                    hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
-                    hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
-                }
-                const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
-                const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
-                const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
-                qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
-                        ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
+
+    // ---- 2. groups of buckets, front to back -------------------------------------------------------
+    unsigned it = 0;                     // batch counter (parity of the LDS flags)
+    bool tile_done = false;
+    unsigned g_bucket = 0, lo = 0;       // next bucket / its queue position
+    while (lo < n && (!tile_done || full_sort)) {
+        unsigned hi, sub, nbits;
+        if (!parted) { hi = n; sub = 0u; nbits = 32u; }
+        else {
+            unsigned g1 = g_bucket;
+            while (g1 < SGS_NB && s_boff[g1 + 1] == lo) ++g1;                          // skip empty buckets
+            g_bucket = g1;
+            hi = s_boff[g1 + 1];
+            while (g1 + 1 < SGS_NB && s_boff[g1 + 2] - lo <= SGS_GCAP) { ++g1; hi = s_boff[g1 + 1]; }
+            sub = (kbase + g_bucket) << SGS_BUCKET_SHIFT;
+            const unsigned nb = g1 - g_bucket + 1u;
+            nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)nb));
+            if (nbits >= 32u) { sub = 0u; nbits = 32u; }
+            g_bucket = g1 + 1;
+        }
+        const unsigned cnt = hi - lo;
+        const unsigned* gv;              // the group's slot numbers in (depth, index) order
+        if (cnt <= SGS_GCAP) {
+            // load into LDS; the exact key range of the group decides how many radix passes are needed
+            unsigned* a_k = s_buf; unsigned* a_v = s_buf + SGS_GCAP;
+            if (tid == 0) { sh.kmin = 0xffffffffu; sh.kmax = 0u; }
+            __syncthreads();
+            unsigned kmn = 0xffffffffu, kmx = 0u;
+            for (unsigned i = tid; i < cnt; i += 256) {
+                const unsigned k = src_k[lo + i];
+                a_k[i] = k; a_v[i] = src_v[lo + i];
+                kmn = k < kmn ? k : kmn; kmx = k > kmx ? k : kmx;
+            }
+            kmn = wave_min(kmn); kmx = wave_max(kmx);
+            if (lane == 0) { atomicMin(&sh.kmin, kmn); atomicMax(&sh.kmax, kmx); }
+            __syncthreads();
+            sub = sh.kmin;
+            const unsigned span = sh.kmax - sub;
+            nbits = span ? 32u - (unsigned)__clz((int)span) : 0u;
+            sort_segment(a_k, a_v, s_buf + 2 * SGS_GCAP, s_buf + 3 * SGS_GCAP, cnt, sub, nbits, sh, slot_id, splats, P.n, st);
+            gv = a_v;
+            if (full_sort) for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = a_v[i];
+        } else {
+            // one oversized bucket: same sort, ping-ponging through HBM (rec_* is free once partitioned)
+            sort_segment(alt_key + beg + lo, alt_val + beg + lo, rec_key + beg + lo, rec_val + beg + lo, cnt, sub, nbits,
+                         sh, slot_id, splats, P.n, st);
+            gv = alt_val + beg + lo;
+            if (tid == 0) atomicAdd(&st->class_count[3], 1u);
+            if (full_sort) {
+                __syncthreads();
+                for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = gv[i];
             }
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const unsigned long long bal = __ballot((qbits >> q) & 1u);
-            if (lane == 0) s_ball[par][q][wave] = bal;
-        }
-        // ---- prefetch the next batch (loads stay in flight across the blend loop) ----------------
-        const unsigned nbase = base + SGS_BATCH;
-        if (nbase < n && (unsigned)tid < min((unsigned)SGS_BATCH, n - nbase)) {
-            const float4* sp = reinterpret_cast<const float4*>(splats + rec_val[beg + nbase + tid]);
-            nA = sp[0]; nB = sp[1]; nC = sp[2].x;
-        }
-        __syncthreads();                 // batch staged, liveness counted
-        if (s_live[par] == 0) break;     // every pixel of the tile has terminated (uniform)
-        if (wave_live) {
-            bool wave_done = false;
-            for (int gw = 0; gw < 4 && !wave_done; ++gw) {
-                unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
-                if (mask == 0ull) continue;
-                unsigned j = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                mask &= mask - 1ull;
-                float4 A = s_a[j], B = s_b[j]; float cb_ = s_c[j];
-                unsigned cnt = 0;
-                for (;;) {
-                    // issue the LDS reads of the next splat before the arithmetic of this one
-                    const bool more = mask != 0ull;
-                    unsigned jn = j;
-                    float4 An = A, Bn = B; float cn = cb_;
-                    if (more) {
-                        jn = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                        mask &= mask - 1ull;
-                        An = s_a[jn]; Bn = s_b[jn]; cn = s_c[jn];
+        __syncthreads();
+
+        // ---- 3. blend the group in batches of 256 ------------------------------------------------
+        if (!tile_done) {
+            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
+            if ((unsigned)tid < min((unsigned)SGS_BATCH, cnt)) {
+                const float4* sp = reinterpret_cast<const float4*>(splats + gv[tid]);
+                nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+            }
+            for (unsigned gb = 0; gb < cnt && !tile_done; gb += SGS_BATCH, ++it) {
+                const unsigned par = it & 1u;
+                const unsigned m = min((unsigned)SGS_BATCH, cnt - gb);
+                const unsigned base = lo + gb;               // queue position of this batch
+                // stage the prefetched batch + per-quadrant overlap ballots
+                const bool have = (unsigned)tid < m;
+                unsigned qbits = 0;
+                if (have) {
+                    s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
+                    // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
+                    const float K = 2.0f * __logf(nB.y) + k_cut;
+                    const float detq = nA.z * nB.x - nA.w * nA.w;
+                    if (K > 0.0f) {
+                        float hx = 3.0e38f, hy = 3.0e38f;
+                        if (detq > 1.0e-12f * nA.z * nB.x) {   // otherwise fp32 cannot bound it: keep everywhere
+                            const float inv = K / detq;
+                            hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
+                            hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
+                        }
+                        const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
+                        const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
+                        const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
+                        qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
+                                ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
                     }
-                    const float dx = A.x - fpx, dy = A.y - fpy;
-                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                    const float alpha = fminf(amax, B.y * __expf(power));
-                    const float testT = T * (1.0f - alpha);
-                    used = done ? used : base + j + 1u;
-                    const bool hit = !done && power <= 0.0f && alpha >= amin;
-                    const bool stop = hit && testT < tmin;
-                    const bool blend = hit && !stop;
-                    const float wgt = blend ? alpha * T : 0.0f;
-                    C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;
-                    T = blend ? testT : T;
-                    done = done || stop;
-                    if ((++cnt & 7u) == 0u && __ballot(!done) == 0ull) { wave_done = true; break; }
-                    if (!more) break;
-                    j = jn; A = An; B = Bn; cb_ = cn;
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long bal = __ballot((qbits >> q) & 1u);
+                    if (lane == 0) s_ball[par][q][wave] = bal;
+                }
+                // prefetch the next batch of this group (loads stay in flight across the blend loop)
+                const unsigned ngb = gb + SGS_BATCH;
+                if (ngb < cnt && (unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb)) {
+                    const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + tid]);
+                    nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+                }
+                __syncthreads();                 // batch staged
+                if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
+                if (__ballot(!done) != 0ull) {
+                    bool wave_done = false;
+                    for (int gw = 0; gw < 4 && !wave_done; ++gw) {
+                        unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
+                        if (mask == 0ull) continue;
+                        unsigned j = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                        mask &= mask - 1ull;
+                        float4 A = s_a[j], B = s_b[j]; float cb_ = s_c[j];
+                        unsigned cn = 0;
+                        for (;;) {
+                            // issue the LDS reads of the next splat before the arithmetic of this one
+                            const bool more = mask != 0ull;
+                            unsigned jn = j;
+                            float4 An = A, Bn = B; float cn_ = cb_;
+                            if (more) {
+                                jn = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                                mask &= mask - 1ull;
+                                An = s_a[jn]; Bn = s_b[jn]; cn_ = s_c[jn];
+                            }
+                            const float dx = A.x - fpx, dy = A.y - fpy;
+                            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                            const float alpha = fminf(amax, B.y * __expf(power));
+                            const float testT = T * (1.0f - alpha);
+                            used = done ? used : base + j + 1u;
+                            const bool hit = !done && power <= 0.0f && alpha >= amin;
+                            const bool stop = hit && testT < tmin;
+                            const bool blend = hit && !stop;
+                            const float wgt = blend ? alpha * T : 0.0f;
+                            C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;
+                            T = blend ? testT : T;
+                            done = done || stop;
+                            if ((++cn & 7u) == 0u && __ballot(!done) == 0ull) { wave_done = true; break; }
+                            if (!more) break;
+                            j = jn; A = An; B = Bn; cb_ = cn_;
+                        }
+                    }
+                    if (!done) used = base + m;      // still live: the whole batch counts as examined
+                }
+                const bool still_live = __ballot(!done) != 0ull;
+                if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
+                __syncthreads();                 // batch consumed by every wave, liveness posted
+                tile_done = s_any[par] == 0u;    // uniform
             }
-            if (!done) used = base + m;      // still live: the whole batch counts as examined
         }
-        __syncthreads();                 // batch consumed by every wave; s_live[par] read by all
-        if (tid == 0) s_live[par] = 0;   // next used two batches from now
+        lo = hi;
     }
     if (inside) {
         float* o = out_rgb + ((size_t)py * P.width + px) * 3;

@@ -9,10 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-NUM_STAGES = 5
-STAGE_NAMES = ("preprocess", "scan", "emit", "sort", "composite")
+NUM_STAGES = 4
+STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
-FLAG_ASYNC, FLAG_TIMING, FLAG_STATS = 1, 2, 4
+FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT = 1, 2, 4, 8
 BACKEND_CPU, BACKEND_HIP = 0, 1
 BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS = 0, 1, 2, 3
 

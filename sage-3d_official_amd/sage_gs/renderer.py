@@ -178,7 +178,7 @@ class Renderer:
     # -- frames -----------------------------------------------------------------------------------
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
-               tile_rows=None, timing=False, sync=True) -> torch.Tensor:
+               tile_rows=None, timing=False, sync=True, full_sort=False) -> torch.Tensor:
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
@@ -204,7 +204,8 @@ class Renderer:
                   or tuple(out.shape) != (camera.height, camera.width, 3)):
                 raise ValueError("out must be a contiguous float32 [H,W,3] tensor on the renderer's device")
             ptr, ret = out.data_ptr(), out
-        flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0)
+        flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
+                (_capi.FLAG_FULL_SORT if full_sort else 0)     # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         self._lib.check(self._lib.sgs_render(self._ctx, scene.handle, C.byref(cam), C.byref(cfg), r0, r1,
                                              ptr, C.byref(st), self._stream()), self._ctx)

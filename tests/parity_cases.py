@@ -43,7 +43,12 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     """Full comparison of one frame: counts and queues bit-exact, splat attributes to fp32 rounding,
     image within the parity tolerance."""
     drv.upload(*scene)
+    # production path: queues are sorted lazily, only as far as the composite reads them
     img, st = drv.render(cam, cfg, rows)
+    # test hook: order every queue completely so the whole (depth bits, index) order can be compared
+    img_full, st_full = drv.render(cam, cfg, rows, full_sort=True)
+    assert (img_full == img).all(), f"{what}: lazy and full sort must blend the same records in the same order"
+    assert st_full["d_fetched"] == st["d_fetched"] and st_full["d_total"] == st["d_total"]
     ref, aux = oracle_c.render(*scene, cam, cfg, rows[0], rows[1])
     assert st["n_visible"] == aux["n_visible"], (what, st["n_visible"], aux["n_visible"])
     assert st["d_total"] == aux["D"], (what, st["d_total"], aux["D"])
@@ -172,7 +177,24 @@ def case_sort_classes(drv, sizes=(700, 2500, 6000, 9500)):
         cam = onp.Camera(32, 32, 32.0, 32.0, 16.0, 16.0, np.eye(4, dtype=np.float32))
         img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what=f"sort class n={n}")
         assert st["max_tile_len"] == n
-        assert st["n_spill_tiles"] == (4 if n > 9216 else 0)
+
+
+def case_big_depth_bucket(drv, n_slab=3000):
+    """Thousands of splats inside one 4 % depth bucket of one tile (a wall facing the camera): the bucket
+    exceeds the LDS group capacity and is sorted through HBM; includes a long run of equal depths."""
+    rng = np.random.default_rng(8)
+    n = n_slab + 500
+    means = np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), rng.uniform(1.0, 12.0, n)], 1).astype(np.float32)
+    means[:n_slab, 2] = rng.uniform(3.0, 3.08, n_slab).astype(np.float32)
+    means[100:170, 2] = 3.05                                   # 70 equal depths inside the slab
+    perm = rng.permutation(n); means = means[perm]
+    scales = np.full((n, 3), 0.3, np.float32)
+    quats = rng.normal(size=(n, 4)).astype(np.float32)
+    opac = rng.uniform(0.005, 0.012, n).astype(np.float32)
+    sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
+    cam = onp.Camera(32, 32, 32.0, 32.0, 16.0, 16.0, np.eye(4, dtype=np.float32))
+    img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what="big depth bucket")
+    assert st["n_spill_tiles"] >= 1
 
 
 def case_full_grid_splat(drv, res=(1920, 1080)):
@@ -207,8 +229,10 @@ def case_determinism(drv, n=4000):
     scene = random_scene(n, 31, 1, scale=(0.03, 0.3))
     cam = onp.Camera(176, 144, 120.0, 120.0, 88.0, 72.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    a, _ = drv.render(cam)
+    a, _ = drv.render(cam, full_sort=True)
     ids_a = drv.intermediates()[1].copy()
-    b, _ = drv.render(cam)
+    b, _ = drv.render(cam, full_sort=True)
     ids_b = drv.intermediates()[1]
+    c, _ = drv.render(cam)
+    assert (c == a).all()
     assert (a == b).all() and (ids_a == ids_b).all(), "two renders of the same frame differ"

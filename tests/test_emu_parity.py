@@ -40,6 +40,10 @@ def test_depth_ties(drv):
     pc.case_depth_ties(drv)
 
 
+def test_big_depth_bucket(drv):
+    pc.case_big_depth_bucket(drv, n_slab=1500)
+
+
 def test_sort_classes(drv):
     pc.case_sort_classes(drv, sizes=(700, 2500, 9500))
 

@@ -30,13 +30,14 @@ class GpuDriver:
             self.scene.free()
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
                                                   cfg.alpha_max, cfg.t_min, cfg.background, cfg.sh_degree)
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
-        img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows)
+        img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
+                            full_sort=full_sort)
         return img.cpu().numpy(), self.r.last_stats
 
     def intermediates(self):
@@ -88,6 +89,10 @@ def test_tile_row_bands(drv):
 
 def test_depth_ties(drv):
     pc.case_depth_ties(drv)
+
+
+def test_big_depth_bucket(drv):
+    pc.case_big_depth_bucket(drv, n_slab=6000)
 
 
 def test_sort_classes(drv):
@@ -144,7 +149,7 @@ def test_3m_scene_properties(drv, big_scene):
     for cam in (cams[0], cams[5]):
         view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
         ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
-        full, st = drv.render(ocam)
+        full, st = drv.render(ocam, full_sort=True)
         assert np.isfinite(full).all() and full.min() >= 0.0
         assert 0 < st["n_visible"] <= 3_000_000 and st["d_total"] >= st["n_visible"] and st["d_fetched"] <= st["d_total"]
         off, ids, slot_ids, splats = drv.intermediates()
