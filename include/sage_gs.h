@@ -152,7 +152,7 @@ int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int
 enum {
     SGS_BUF_TILE_OFFSETS = 0,      /* uint32[T+1]                                                */
     SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues in (depth, index) order — complete only with SGS_FLAG_FULL_SORT */
-    SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    Gaussian index of each slot, 0xFFFFFFFF = dead; S = ceil(N/1024)*1024 */
+    SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    slot i holds Gaussian i: i if live this frame, 0xFFFFFFFF if culled; S = ceil(N/64)*64 */
     SGS_BUF_SPLATS       = 3       /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
 };
 int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);

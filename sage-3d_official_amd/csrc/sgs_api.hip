@@ -40,14 +40,13 @@ struct sgs_ctx {
     std::string err;
     // per-Gaussian scratch
     int64_t splat_cap = 0;
-    Splat* splats = nullptr;
-    unsigned* slot_id = nullptr;
+    Splat* splats = nullptr;                 // one slot per Gaussian (slot == index)
+    unsigned long long* vismask = nullptr;   // per 64-Gaussian chunk: which slots are live this frame
     // per-tile scratch
     int tile_cap = 0;
     unsigned *tile_count = nullptr, *tile_offset = nullptr;
-    // binning scratch: live slots per range, per-workgroup (tile, base) lists
-    int64_t range_cap = 0;
-    unsigned* range_nvis = nullptr;
+    unsigned long long* tile_prof = nullptr;         // profiling build: 8 words per tile
+    // binning scratch: per-workgroup (tile, base) lists
     int64_t blk_list_cap = 0;
     uint2* blk_list = nullptr;
     unsigned* blk_len = nullptr;
@@ -100,14 +99,13 @@ int grow(sgs_ctx* ctx, T*& p, size_t count) {
 
 int ensure_splats(sgs_ctx* ctx, int64_t n) {
     if (n <= ctx->splat_cap && ctx->blk_len) return SGS_OK;
-    const int64_t ranges = std::max<int64_t>(1, (n + SGS_RANGE - 1) / SGS_RANGE);
-    const int64_t cap = ranges * SGS_RANGE;          // slots are compacted per range
+    const int64_t chunks = std::max<int64_t>(1, (n + 63) / 64);
+    const int64_t cap = chunks * 64;
     int rc;
     if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->slot_id, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->range_nvis, (size_t)ranges)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->vismask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS)) != SGS_OK) return rc;
-    ctx->splat_cap = cap; ctx->range_cap = ranges;
+    ctx->splat_cap = cap;
     return SGS_OK;
 }
 
@@ -125,6 +123,7 @@ int ensure_tiles(sgs_ctx* ctx, int tiles) {
     int rc;
     if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_prof, (size_t)tiles * 8)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
     ctx->tile_cap = tiles;
@@ -214,21 +213,21 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
     const unsigned bin_blocks = (unsigned)std::min<int64_t>(SGS_BIN_BLOCKS, P.n_ranges);
-    if (P.n_ranges > 0)
-        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)P.n_ranges), dim3(256), 0, stream, P, scene->geom,
-                           scene->shq, ctx->splats, ctx->slot_id, ctx->range_nvis);
+    if (P.n_chunks > 0)
+        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
+                           scene->geom, scene->shq, ctx->splats, ctx->vismask);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
-                           ctx->range_nvis, ctx->tile_count, ctx->blk_list, ctx->blk_len, st);
+                           ctx->vismask, ctx->tile_count, ctx->blk_list, ctx->blk_len, st);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
                        ctx->tile_offset, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
-                           ctx->range_nvis, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec_key,
+                           ctx->vismask, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec_key,
                            ctx->rec_val, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
@@ -236,7 +235,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
         hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec_key,
-                           ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->slot_id, ctx->splats, out_rgb, st);
+                           ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->splats, out_rgb, st, ctx->tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
@@ -335,7 +334,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->slot_id, ctx->tile_count, ctx->tile_offset, ctx->range_nvis,
+    void* bufs[] = {ctx->splats, ctx->vismask, ctx->tile_count, ctx->tile_offset, ctx->tile_prof,
                     ctx->blk_list, ctx->blk_len, ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -542,34 +541,35 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     SGS_HIP(ctx, hipDeviceSynchronize());
     const FrameStatus& s = ctx->h_status[ctx->last_slot];
-    const int64_t n_ranges = (ctx->last_n + SGS_RANGE - 1) / SGS_RANGE;
-    const int64_t n_slots = n_ranges * SGS_RANGE;
+    const int64_t n_chunks = (ctx->last_n + 63) / 64;
+    const int64_t n_slots = n_chunks * 64;
     const void* src = nullptr;
     int64_t have = 0, elem = 0;
     switch (what) {
         case SGS_BUF_TILE_OFFSETS: src = ctx->tile_offset; have = ((int64_t)ctx->last_T + 1) * 4; break;
         case SGS_BUF_SORTED_SLOTS: src = ctx->rec_val; have = s.overflow ? 0 : (int64_t)s.d_total * 4; break;
-        case SGS_BUF_SLOT_IDS: src = ctx->slot_id; elem = 4; have = n_slots * elem; break;
+        case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: src = ctx->splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
+        case 100: src = ctx->tile_prof; have = (int64_t)ctx->last_T * 64; break;    // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
     }
     const int64_t n = std::min(have, bytes);
     if (n <= 0 || !host_dst) return have;
-    SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    if (src) SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
     if (elem) {
-        // slots are compacted per 1024-Gaussian range; blank the dead tail of every range
-        // (slot ids -> 0xFFFFFFFF, splats -> 0) so stale data of earlier frames cannot be mistaken for live
-        unsigned* nvis = (unsigned*)malloc((size_t)std::max<int64_t>(1, n_ranges) * 4);
-        if (!nvis) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
-        hipError_t e = hipMemcpy(nvis, ctx->range_nvis, (size_t)n_ranges * 4, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) { free(nvis); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+        // a splat lives at its Gaussian's index; the per-chunk visibility masks say which are live.
+        // Dead slots are blanked (slot ids -> 0xFFFFFFFF, splats -> 0) so stale data cannot pass for live.
+        unsigned long long* vm = (unsigned long long*)malloc((size_t)std::max<int64_t>(1, n_chunks) * 8);
+        if (!vm) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+        hipError_t e = hipMemcpy(vm, ctx->vismask, (size_t)n_chunks * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(vm); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
         char* dst = (char*)host_dst;
-        for (int64_t r = 0; r < n_ranges; ++r) {
-            const int64_t b0 = (r * SGS_RANGE + nvis[r]) * elem, b1 = (r + 1) * SGS_RANGE * elem;
-            if (b0 >= n) break;
-            memset(dst + b0, what == SGS_BUF_SLOT_IDS ? 0xFF : 0, (size_t)(std::min(b1, n) - b0));
+        for (int64_t i = 0; i < n_slots && (i + 1) * elem <= n; ++i) {
+            const bool live = (vm[i >> 6] >> (i & 63)) & 1ull;
+            if (what == SGS_BUF_SLOT_IDS) ((unsigned*)dst)[i] = live ? (unsigned)i : 0xFFFFFFFFu;
+            else if (!live) memset(dst + i * elem, 0, (size_t)elem);
         }
-        free(nvis);
+        free(vm);
     }
     return have;
 }

@@ -167,8 +167,7 @@ __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
 // One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
 __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const float4* __restrict__ geom,
                                                  const float4* __restrict__ shq, Splat* __restrict__ splats,
-                                                 unsigned* __restrict__ slot_id, long long chunk,
-                                                 unsigned slot_base, unsigned* range_cursor, int lane) {
+                                                 unsigned long long* __restrict__ vismask, long long chunk, int lane) {
     const long long id = chunk * SGS_WAVE + lane;
 
     const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
@@ -244,14 +243,11 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         }
     }
 
-    // wave-ballot compaction inside the range: one LDS atomic per wave hands out a block of slots
+    // No compaction: a splat lives at its Gaussian's index (slot == index), and the wave's ballot is
+    // the chunk's visibility mask.  Ties on depth can then break on the slot number itself.
     const unsigned long long vmask = __ballot(vis);
-    const unsigned nvis = (unsigned)__popcll(vmask);
-    if (nvis == 0) return;                                  // wave-uniform: whole chunk culled
-    unsigned base = 0;
-    if (lane == 0) base = atomicAdd(range_cursor, nvis);
-    base = __shfl(base, 0);
-    const unsigned slot = slot_base + base + (unsigned)__popcll(vmask & lanemask_lt(lane));
+    if (lane == 0) vismask[chunk] = vmask;
+    const unsigned slot = (unsigned)id;
 
     if (vis) {
         // S1: view direction in model space (fp64 difference, fp32 polynomial)
@@ -271,36 +267,24 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         sp[0] = make_float4(sx, sy, ca, cb);
         sp[1] = make_float4(cc, g0.w, r, g);
         sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
-        slot_id[slot] = (unsigned)id;
     }
 
 }
 
-// S1-S3 + compaction.  One lane = one Gaussian, one wave = one 64-Gaussian chunk of the scene (all
-// loads are full 1-KiB rows), one workgroup = one RANGE of 1024 Gaussians.  Geometry runs in fp64
-// (MI355X fp64 vector rate is 1/2 of fp32 and this kernel is HBM-bound), which makes every integer
-// decision (cull, radius, rect, tile counts) agree with the fp64 oracle.
-// Survivors are compacted inside their range: slot = range * 1024 + (arrival order in the range),
-// handed out by wave ballot + one LDS atomic per wave.  No device-scope atomic is issued here (a
-// single global cursor serialises at ~12 ns per wave on MI355X); range_nvis[range] tells the
-// consumers how many slots of the range are live.
+// S1-S3.  One lane = one Gaussian, one wave = one 64-Gaussian chunk of the scene (all loads are full
+// 1-KiB rows).  Geometry runs in fp64 (MI355X fp64 vector rate is 1/2 of fp32 and this kernel is
+// HBM-bound), which makes every integer decision (cull, radius, rect, tile counts) agree with the
+// fp64 oracle.  A pure map kernel: no LDS, no atomics; vismask[chunk] (the wave's ballot) tells the
+// consumers which of the chunk's 64 splat slots are live this frame.
 __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
                                                     const float4* __restrict__ geom,
                                                     const float4* __restrict__ shq,
                                                     Splat* __restrict__ splats,
-                                                    unsigned* __restrict__ slot_id,
-                                                    unsigned* __restrict__ range_nvis) {
-    __shared__ unsigned s_cnt;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long range = blockIdx.x;
-    if (threadIdx.x == 0) s_cnt = 0;
-    __syncthreads();
-    for (int round = 0; round < SGS_RANGE_CHUNKS / 4; ++round) {
-        const long long chunk = range * SGS_RANGE_CHUNKS + round * 4 + wave;
-        if (chunk < P.n_chunks) preprocess_chunk(P, geom, shq, splats, slot_id, chunk, (unsigned)(range * SGS_RANGE), &s_cnt, lane);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) range_nvis[range] = s_cnt;
+                                                    unsigned long long* __restrict__ vismask) {
+    const int lane = threadIdx.x & 63;
+    const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (chunk >= P.n_chunks) return;                       // wave-uniform
+    preprocess_chunk(P, geom, shq, splats, vismask, chunk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -358,25 +342,24 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
 // atomicAdd per tile it touched: the returned value is the workgroup's base inside that tile's queue.
 // The (tile, base) pairs go to a per-workgroup list; after the scan, k_bin_emit reloads them as
 // absolute cursors into LDS and writes every record with an LDS atomic only.
-struct BinTraversal {
-    int wr0, wr1;                       // tile rows of the current window
-};
-
 // Calls f(valid, local tile index, depth bits, slot) for every record of this workgroup's splats
-// that falls into tile rows [wr0, wr1).  Returns the number of live slots seen (first lane valid).
+// that falls into tile rows [wr0, wr1).  Workgroup b owns the 1024-Gaussian ranges b, b+B, ...; its
+// waves take the chunks of a range.  Returns the number of live splats seen by this lane's wave.
 template <class F>
 __device__ __forceinline__ unsigned bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
-                                             const unsigned* __restrict__ range_nvis, int wr0, int wr1, F&& f) {
+                                             const unsigned long long* __restrict__ vismask, int wr0, int wr1, F&& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     unsigned seen = 0;
     for (int r = blockIdx.x; r < P.n_ranges; r += gridDim.x) {
-        const unsigned nv = range_nvis[r];
-        seen += nv;
-        for (unsigned s0 = (unsigned)wave * SGS_WAVE; s0 < nv; s0 += (unsigned)nwaves * SGS_WAVE) {
-            const unsigned s = s0 + (unsigned)lane;
-            const unsigned slot = (unsigned)r * SGS_RANGE + s;
+        for (int cw = wave; cw < SGS_RANGE_CHUNKS; cw += nwaves) {
+            const long long chunk = (long long)r * SGS_RANGE_CHUNKS + cw;
+            if (chunk >= P.n_chunks) break;                   // wave-uniform
+            const unsigned long long vm = vismask[chunk];
+            if (vm == 0ull) continue;                         // wave-uniform: whole chunk culled
+            seen += (unsigned)__popcll(vm);
+            const unsigned slot = (unsigned)(chunk * SGS_WAVE) + (unsigned)lane;
             unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
-            if (s < nv) {
+            if ((vm >> lane) & 1ull) {
                 const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
                 key = __float_as_uint(c.y);
                 const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
@@ -393,25 +376,27 @@ __device__ __forceinline__ unsigned bin_walk(const FrameParams& P, const Splat* 
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
                                                                const Splat* __restrict__ splats,
-                                                               const unsigned* __restrict__ range_nvis,
+                                                               const unsigned long long* __restrict__ vismask,
                                                                unsigned* __restrict__ tile_count,
                                                                uint2* __restrict__ blk_list,
                                                                unsigned* __restrict__ blk_len,
                                                                FrameStatus* __restrict__ st) {
     __shared__ unsigned s_cnt[SGS_WT];
     __shared__ unsigned short s_list[SGS_WT];
-    __shared__ unsigned s_nlist;
+    __shared__ unsigned s_nlist, s_seen;
     const int tid = threadIdx.x;
     for (int i = tid; i < SGS_WT; i += SGS_BIN_THREADS) s_cnt[i] = 0;
+    if (tid == 0) s_seen = 0;
     for (int w = 0; w < P.n_windows; ++w) {
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
         if (tid == 0) s_nlist = 0;
         __syncthreads();
-        const unsigned seen = bin_walk(P, splats, range_nvis, wr0, wr1,
+        const unsigned seen = bin_walk(P, splats, vismask, wr0, wr1,
                                        [&](bool valid, unsigned tl, unsigned, unsigned) {
                                            if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
                                                s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
                                        });
+        if (w == 0 && (tid & 63) == 0 && seen) atomicAdd(&s_seen, seen);
         __syncthreads();
         // flush: one device-scope atomic per touched tile; its return value is our base in the queue
         const unsigned nl = s_nlist;
@@ -425,7 +410,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         }
         if (tid == 0) {
             blk_len[blockIdx.x * SGS_MAX_WINDOWS + w] = nl;
-            if (w == 0 && seen) atomicAdd(&st->n_visible, seen);    // one per workgroup
+            if (w == 0 && s_seen) atomicAdd(&st->n_visible, s_seen);    // one per workgroup
         }
         __syncthreads();
     }
@@ -433,7 +418,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams P,
                                                               const Splat* __restrict__ splats,
-                                                              const unsigned* __restrict__ range_nvis,
+                                                              const unsigned long long* __restrict__ vismask,
                                                               const unsigned* __restrict__ tile_offset,
                                                               const uint2* __restrict__ blk_list,
                                                               const unsigned* __restrict__ blk_len,
@@ -452,7 +437,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
             s_next[e.x] = tile_offset[(unsigned)wr0 * (unsigned)P.gx + e.x] + e.y;
         }
         __syncthreads();
-        bin_walk(P, splats, range_nvis, wr0, wr1,
+        bin_walk(P, splats, vismask, wr0, wr1,
                  [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
                      if (valid) {
                          const unsigned dst = atomicAdd(&s_next[tl], 1u);
@@ -547,11 +532,11 @@ __device__ __forceinline__ void radix_sort_bits(unsigned* a_k, unsigned* a_v, un
     }
 }
 
-// Sorts (k,v)[0..n) by (depth bits, Gaussian index); b_k/b_v are ping-pong space of the same size.
-// Keys are known to lie in [sub, sub + 2^nbits).  All threads of the workgroup must call it.
+// Sorts (k,v)[0..n) by (depth bits, slot); b_k/b_v are ping-pong space of the same size.  A splat's
+// slot IS its Gaussian index, so ties on depth break on v itself.  Keys lie in [sub, sub + 2^nbits).
+// All threads of the workgroup must call it.  (Used for depth buckets too long for the LDS rank sort.)
 __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsigned* b_k, unsigned* b_v,
                                              unsigned n, unsigned sub, unsigned nbits, SortShared& sh,
-                                             const unsigned* __restrict__ slot_id,
                                              const Splat* __restrict__ splats, long long n_gauss,
                                              FrameStatus* st) {
     const unsigned tid = threadIdx.x;
@@ -568,9 +553,9 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
             if (e - i > SGS_TIE_RUN_MAX) { atomicOr(&sh.flag, 1u); }
             else {
                 for (unsigned p = i + 1; p < e; ++p) {
-                    const unsigned v = a_v[p], idv = slot_id[v];
+                    const unsigned v = a_v[p];
                     unsigned q = p;
-                    while (q > i && slot_id[a_v[q - 1]] > idv) { a_v[q] = a_v[q - 1]; --q; }
+                    while (q > i && a_v[q - 1] > v) { a_v[q] = a_v[q - 1]; --q; }
                     a_v[q] = v;
                 }
             }
@@ -579,7 +564,7 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
     __syncthreads();
     if (sh.flag) {
         // rare: stable two-key sort — first by Gaussian index, then by depth bits
-        for (unsigned i = tid; i < n; i += 256) a_k[i] = slot_id[a_v[i]];
+        for (unsigned i = tid; i < n; i += 256) a_k[i] = a_v[i];
         __syncthreads();
         const unsigned idbits = n_gauss > 1 ? 64u - (unsigned)__clzll((long long)(n_gauss - 1)) : 1u;
         radix_sort_bits(a_k, a_v, b_k, b_v, n, 0u, idbits, sh);
@@ -590,6 +575,30 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
     }
 }
 
+// Rank sort of cnt <= R*256 records held in LDS as kk[i] = depth bits << 32 | slot (all distinct).
+// Lane t owns records t, t+256, ...; it walks the whole list with broadcast LDS reads and counts the
+// records that precede each of its own.  Two barriers, no passes, ties resolved by the slot half.
+template <int R>
+__device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned* out_v, unsigned cnt) {
+    const unsigned tid = threadIdx.x;
+    unsigned long long mine[R];
+    unsigned rank[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const unsigned i = tid + 256u * (unsigned)r;
+        mine[r] = i < cnt ? kk[i] : ~0ull;
+        rank[r] = 0;
+    }
+    for (unsigned j = 0; j < cnt; ++j) {
+        const unsigned long long x = kk[j];
+#pragma unroll
+        for (int r = 0; r < R; ++r) rank[r] += x < mine[r] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (tid + 256u * (unsigned)r < cnt) out_v[rank[r]] = (unsigned)mine[r];
+}
+
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.
 //
@@ -597,15 +606,15 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
 // its pixels saturate after ~200 (p99 ~1000) — 80 % of a fully sorted queue is never read.  So the
 // workgroup of a tile
 //   1. partitions its queue into SGS_NB depth buckets with one MSD pass on the fp32 depth bits
-//      (bucket = (bits >> 19) - bits(near) >> 19: 16 buckets per binade of view depth, so buckets are
+//      (bucket = (bits >> 18) - (bits(near) >> 18): 32 buckets per binade of view depth, so buckets are
 //      fine near the camera where it matters); counters in LDS, records to the alt buffers (queues
-//      of <= SGS_GCAP records skip this and form a single group);
-//   2. walks the buckets front to back in groups of <= SGS_GCAP records: loads a group into LDS,
-//      finishes its order with the LDS radix sort above (only the bits that vary inside the group,
-//      ties -> Gaussian index), and blends it;
+//      of <= SGS_GROUP records skip this and form a single group);
+//   2. walks the buckets front to back in groups of about SGS_GROUP records: loads a group into LDS as
+//      (depth << 32 | slot) words, orders it with the rank sort above and blends it;
 //   3. stops as soon as every pixel of the tile has terminated.
-// A single bucket larger than SGS_GCAP (thousands of splats within 4 % of one depth) is sorted through
-// HBM with the same routine, ping-ponging between the two record buffers.
+// A single bucket may hold up to SGS_GCAP records (rank sort with 2-4 records per lane); one longer
+// than that (thousands of splats within 2 % of one depth) is radix-sorted through HBM, ping-ponging
+// between the two record buffers.
 //
 // Blend stage: one lane per pixel, each wave owns an 8x8 quadrant.  A group is streamed through LDS
 // in batches of 256 splats:
@@ -620,8 +629,9 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
 // share most of their splats -> the gathers hit that XCD's L2.
 #define SGS_BATCH 256
 #define SGS_NB 256
-#define SGS_BUCKET_SHIFT 19
-#define SGS_GCAP 1024
+#define SGS_BUCKET_SHIFT 18
+#define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
+#define SGS_GCAP 1024                 // hard cap of the LDS rank sort (one oversized bucket)
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
@@ -634,12 +644,12 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
                                                      unsigned* rec_key, unsigned* rec_val,
                                                      unsigned* alt_key, unsigned* alt_val,
-                                                     const unsigned* __restrict__ slot_id,
                                                      const Splat* __restrict__ splats,
                                                      float* __restrict__ out_rgb,
-                                                     FrameStatus* st) {
+                                                     FrameStatus* st, unsigned long long* prof) {
     __shared__ SortShared sh;
-    __shared__ unsigned s_buf[4 * SGS_GCAP];         // group keys | vals | ping-pong keys | vals
+    __shared__ unsigned long long s_kk[SGS_GCAP];     // group records: depth bits << 32 | slot
+    __shared__ unsigned s_sorted[SGS_GCAP];           // the group's slots in (depth, index) order
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_boff[SGS_NB + 1];           // bucket offsets inside the queue
     __shared__ float4 s_a[SGS_BATCH];
@@ -648,6 +658,13 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_used[4];
+#ifdef SGS_TILE_PROF
+    // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
+    unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
+#define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
+#else
+#define SGS_PROF_MARK(acc) do { } while (0)
+#endif
     if (st->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware remap of the block index over this call's tiles
@@ -674,7 +691,7 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
-    const bool parted = n > SGS_GCAP;
+    const bool parted = n > SGS_GROUP;
     const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
     const unsigned* src_k = rec_key + beg;                 // where the (partitioned) queue lives
     const unsigned* src_v = rec_val + beg;
@@ -709,60 +726,56 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
         src_k = alt_key + beg; src_v = alt_val + beg;
     }
     __syncthreads();
+#ifdef SGS_TILE_PROF
+    ptm = clock64(); pt_part = ptm - pt0;
+#endif
 
     // ---- 2. groups of buckets, front to back -------------------------------------------------------
     unsigned it = 0;                     // batch counter (parity of the LDS flags)
     bool tile_done = false;
     unsigned g_bucket = 0, lo = 0;       // next bucket / its queue position
     while (lo < n && (!tile_done || full_sort)) {
-        unsigned hi, sub, nbits;
-        if (!parted) { hi = n; sub = 0u; nbits = 32u; }
+        unsigned hi, g0 = 0, g1 = 0;
+        if (!parted) hi = n;
         else {
-            unsigned g1 = g_bucket;
-            while (g1 < SGS_NB && s_boff[g1 + 1] == lo) ++g1;                          // skip empty buckets
-            g_bucket = g1;
+            g1 = g_bucket;
+            while (s_boff[g1 + 1] == lo) ++g1;                                         // skip empty buckets
+            g0 = g1;
             hi = s_boff[g1 + 1];
-            while (g1 + 1 < SGS_NB && s_boff[g1 + 2] - lo <= SGS_GCAP) { ++g1; hi = s_boff[g1 + 1]; }
-            sub = (kbase + g_bucket) << SGS_BUCKET_SHIFT;
-            const unsigned nb = g1 - g_bucket + 1u;
-            nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)nb));
-            if (nbits >= 32u) { sub = 0u; nbits = 32u; }
+            while (g1 + 1 < SGS_NB && s_boff[g1 + 2] - lo <= SGS_GROUP) { ++g1; hi = s_boff[g1 + 1]; }
             g_bucket = g1 + 1;
         }
         const unsigned cnt = hi - lo;
-        const unsigned* gv;              // the group's slot numbers in (depth, index) order
+        const unsigned* gv;              // the group's slots in (depth, index) order
         if (cnt <= SGS_GCAP) {
-            // load into LDS; the exact key range of the group decides how many radix passes are needed
-            unsigned* a_k = s_buf; unsigned* a_v = s_buf + SGS_GCAP;
-            if (tid == 0) { sh.kmin = 0xffffffffu; sh.kmax = 0u; }
+            for (unsigned i = tid; i < cnt; i += 256)
+                s_kk[i] = ((unsigned long long)src_k[lo + i] << 32) | src_v[lo + i];
             __syncthreads();
-            unsigned kmn = 0xffffffffu, kmx = 0u;
-            for (unsigned i = tid; i < cnt; i += 256) {
-                const unsigned k = src_k[lo + i];
-                a_k[i] = k; a_v[i] = src_v[lo + i];
-                kmn = k < kmn ? k : kmn; kmx = k > kmx ? k : kmx;
-            }
-            kmn = wave_min(kmn); kmx = wave_max(kmx);
-            if (lane == 0) { atomicMin(&sh.kmin, kmn); atomicMax(&sh.kmax, kmx); }
+            if (cnt <= 256) rank_sort<1>(s_kk, s_sorted, cnt);
+            else if (cnt <= 512) rank_sort<2>(s_kk, s_sorted, cnt);
+            else rank_sort<4>(s_kk, s_sorted, cnt);
             __syncthreads();
-            sub = sh.kmin;
-            const unsigned span = sh.kmax - sub;
-            nbits = span ? 32u - (unsigned)__clz((int)span) : 0u;
-            sort_segment(a_k, a_v, s_buf + 2 * SGS_GCAP, s_buf + 3 * SGS_GCAP, cnt, sub, nbits, sh, slot_id, splats, P.n, st);
-            gv = a_v;
-            if (full_sort) for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = a_v[i];
+            gv = s_sorted;
+            if (full_sort) for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = s_sorted[i];
         } else {
-            // one oversized bucket: same sort, ping-ponging through HBM (rec_* is free once partitioned)
+            // one oversized bucket: radix sort through HBM (rec_* is free once the queue is partitioned)
+            unsigned sub = (kbase + g0) << SGS_BUCKET_SHIFT;
+            unsigned nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
+            if (nbits >= 32u) { sub = 0u; nbits = 32u; }
             sort_segment(alt_key + beg + lo, alt_val + beg + lo, rec_key + beg + lo, rec_val + beg + lo, cnt, sub, nbits,
-                         sh, slot_id, splats, P.n, st);
+                         sh, splats, P.n, st);
             gv = alt_val + beg + lo;
             if (tid == 0) atomicAdd(&st->class_count[3], 1u);
             if (full_sort) {
                 __syncthreads();
                 for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = gv[i];
             }
+            __syncthreads();
         }
-        __syncthreads();
+        SGS_PROF_MARK(pt_sort);
+#ifdef SGS_TILE_PROF
+        ++pn_groups;
+#endif
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
@@ -852,10 +865,21 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
+#ifdef SGS_TILE_PROF
+                ++pn_batches;
+#endif
             }
         }
+        SGS_PROF_MARK(pt_blend);
         lo = hi;
     }
+#ifdef SGS_TILE_PROF
+    if (tid == 0 && prof) {
+        unsigned long long* o = prof + (size_t)tile * 8;
+        o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
+        o[6] = clock64() - pt0; o[7] = pt0;
+    }
+#endif
     if (inside) {
         float* o = out_rgb + ((size_t)py * P.width + px) * 3;
         o[0] = C0 + T * P.bg[0]; o[1] = C1 + T * P.bg[1]; o[2] = C2 + T * P.bg[2];

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-tile phase breakdown of k_tile_render (profiling build lib/libsage_gs_prof.so).  Run on the GPU box."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
+os.environ["SAGE_GS_LIB"] = os.path.join(ROOT, "sage-3d_official_amd", "lib", "libsage_gs_prof.so")
+import numpy as np, torch
+from sage_gs import Renderer, scenes
+sc = scenes.make_room(int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, seed=2)
+cams = scenes.room_cameras(sc, 1920, 1080, 4, 64, seed=2)
+r = Renderer("cuda:0", record_capacity=96 << 20)
+gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
+out = {}
+for ci in (5, 20, 70, 140, 200):
+    for _ in range(3):
+        r.render(cams[ci], gs, timing=True)
+    st = r.last_stats
+    p = r.debug_buffer(100, np.uint64).reshape(-1, 8).astype(np.float64)
+    n, part, sort, blend, ng, nb, tot, t0 = p.T
+    clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
+    print(f"cam {ci}: render {st['ms']['render']*1e3:.0f} us  D={st['d_total']} D_f={st['d_fetched']} | tile-cycles sum: part {part.sum()/1e6:.1f}M sort {sort.sum()/1e6:.1f}M blend {blend.sum()/1e6:.1f}M total {tot.sum()/1e6:.1f}M | "
+          f"groups/tile {ng.mean():.2f} batches/tile {nb.mean():.2f} | max tile total {tot.max()/1e3:.0f}k cyc (n={int(n[tot.argmax()])}) | span {(t0+tot).max()-t0.min():.0f} cyc")
+    order = np.argsort(-tot)[:5]
+    for o in order:
+        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])}")
+    # by size class
+    for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
+        m = (n > lo) & (n <= hi)
+        if m.any():
+            print(f"     n in ({lo},{hi}]: {m.sum()} tiles, mean cyc part {part[m].mean():.0f} sort {sort[m].mean():.0f} blend {blend[m].mean():.0f}")

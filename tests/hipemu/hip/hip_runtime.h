@@ -224,6 +224,7 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
+static inline unsigned long long clock64() { return 0; }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // callers pass wave-uniform values
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }

@@ -188,7 +188,7 @@ def case_big_depth_bucket(drv, n_slab=3000):
     means[:n_slab, 2] = rng.uniform(3.0, 3.08, n_slab).astype(np.float32)
     means[100:170, 2] = 3.05                                   # 70 equal depths inside the slab
     perm = rng.permutation(n); means = means[perm]
-    scales = np.full((n, 3), 0.3, np.float32)
+    scales = np.full((n, 3), 2.0, np.float32) * means[:, 2:3]      # broad: alpha stays clear of the 1/255 cut-off
     quats = rng.normal(size=(n, 4)).astype(np.float32)
     opac = rng.uniform(0.005, 0.012, n).astype(np.float32)
     sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
