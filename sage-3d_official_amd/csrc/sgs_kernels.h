@@ -575,9 +575,10 @@ __device__ __forceinline__ void sort_segment(unsigned* a_k, unsigned* a_v, unsig
     }
 }
 
-// Rank sort of cnt <= R*256 records held in LDS as kk[i] = depth bits << 32 | slot (all distinct).
-// Lane t owns records t, t+256, ...; it walks the whole list with broadcast LDS reads and counts the
-// records that precede each of its own.  Two barriers, no passes, ties resolved by the slot half.
+// Rank sort of cnt <= R*256 records held in LDS as kk[i] = depth bits << 32 | slot (all distinct);
+// kk is padded with ~0 up to a multiple of 8.  Lane t owns records t, t+256, ...; it walks the whole
+// list with broadcast LDS reads (8 per trip, so the read latency is paid once per 8 compares) and counts
+// the records that precede each of its own.  Two barriers, no passes, ties resolved by the slot half.
 template <int R>
 __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned* out_v, unsigned cnt) {
     const unsigned tid = threadIdx.x;
@@ -589,10 +590,16 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         mine[r] = i < cnt ? kk[i] : ~0ull;
         rank[r] = 0;
     }
-    for (unsigned j = 0; j < cnt; ++j) {
-        const unsigned long long x = kk[j];
+    const unsigned cnt8 = (cnt + 7u) & ~7u;
+    for (unsigned j = 0; j < cnt8; j += 8) {
+        unsigned long long x[8];
 #pragma unroll
-        for (int r = 0; r < R; ++r) rank[r] += x < mine[r] ? 1u : 0u;
+        for (int u = 0; u < 8; ++u) x[u] = kk[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) rank[r] += x[u] < mine[r] ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -607,12 +614,13 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // workgroup of a tile
 //   1. partitions its queue into SGS_NB depth buckets with one MSD pass on the fp32 depth bits
 //      (bucket = (bits >> 18) - (bits(near) >> 18): 32 buckets per binade of view depth, so buckets are
-//      fine near the camera where it matters); counters in LDS, records to the alt buffers (queues
-//      of <= SGS_GROUP records skip this and form a single group);
+//      fine near the camera where it matters); counters in LDS; queues of <= SGS_QCAP records are
+//      read from HBM once and partitioned inside LDS, longer ones go through the alt buffers (queues
+//      of <= SGS_GROUP records skip the partition and form a single group);
 //   2. walks the buckets front to back in groups of about SGS_GROUP records: loads a group into LDS as
 //      (depth << 32 | slot) words, orders it with the rank sort above and blends it;
 //   3. stops as soon as every pixel of the tile has terminated.
-// A single bucket may hold up to SGS_GCAP records (rank sort with 2-4 records per lane); one longer
+// A single bucket may hold up to SGS_QCAP records (rank sort with 2-4 records per lane); one longer
 // than that (thousands of splats within 2 % of one depth) is radix-sorted through HBM, ping-ponging
 // between the two record buffers.
 //
@@ -631,7 +639,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_NB 256
 #define SGS_BUCKET_SHIFT 18
 #define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
-#define SGS_GCAP 1024                 // hard cap of the LDS rank sort (one oversized bucket)
+#define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
@@ -640,21 +648,26 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
+__global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
                                                      unsigned* rec_key, unsigned* rec_val,
                                                      unsigned* alt_key, unsigned* alt_val,
                                                      const Splat* __restrict__ splats,
                                                      float* __restrict__ out_rgb,
                                                      FrameStatus* st, unsigned long long* prof) {
-    __shared__ SortShared sh;
-    __shared__ unsigned long long s_kk[SGS_GCAP];     // group records: depth bits << 32 | slot
-    __shared__ unsigned s_sorted[SGS_GCAP];           // the group's slots in (depth, index) order
+    // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
+    __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
+    __shared__ float4 s_arena[2 * SGS_BATCH + SGS_BATCH / 4];
+    static_assert(sizeof(float4) * (2 * SGS_BATCH + SGS_BATCH / 4) >= sizeof(SortShared), "arena");
+    float4* const s_a = s_arena;                      // blend phase: the staged batch of splats
+    float4* const s_b = s_arena + SGS_BATCH;
+    float* const s_c = reinterpret_cast<float*>(s_arena + 2 * SGS_BATCH);
+    SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
+    __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
-    __shared__ unsigned s_boff[SGS_NB + 1];           // bucket offsets inside the queue
-    __shared__ float4 s_a[SGS_BATCH];
-    __shared__ float4 s_b[SGS_BATCH];
-    __shared__ float s_c[SGS_BATCH];
+    __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
+    __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
+    __shared__ unsigned s_wsum[4], s_wne[4];
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_used[4];
@@ -691,39 +704,75 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
+    // n <= SGS_QCAP: the queue is read from HBM exactly once (4 records per lane, held in registers
+    // between the histogram and the scatter) and lives in LDS from then on.  Longer queues are
+    // partitioned through HBM into the alt buffers and groups are loaded into s_q one at a time.
     const bool parted = n > SGS_GROUP;
+    const bool in_lds = n <= SGS_QCAP;
     const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
-    const unsigned* src_k = rec_key + beg;                 // where the (partitioned) queue lives
-    const unsigned* src_v = rec_val + beg;
     if (tid < 2) s_any[tid] = 0;
-    if (parted) {
-        s_bcnt[tid] = 0;
-        __syncthreads();
-        for (unsigned i = tid; i < n; i += 256) {
-            const unsigned bk = min((unsigned)(SGS_NB - 1), (rec_key[beg + i] >> SGS_BUCKET_SHIFT) - kbase);
-            atomicAdd(&s_bcnt[bk], 1u);
+    unsigned n_ne = 0;                                   // non-empty buckets (uniform)
+    {
+        unsigned rk[4], rv[4];
+        if (in_lds) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned i = (unsigned)tid + 256u * (unsigned)r;
+                rk[r] = i < n ? rec_key[beg + i] : 0xffffffffu;
+                rv[r] = i < n ? rec_val[beg + i] : 0xffffffffu;
+            }
         }
-        __syncthreads();
-        {
-            const unsigned c = s_bcnt[tid];
-            const unsigned incl = wave_incl_scan(c, lane);
-            if (lane == 63) sh.wsum[wave] = incl;
+        if (!parted) {
+            s_q[tid] = ((unsigned long long)rk[0] << 32) | rv[0];          // n <= 256: one group, pad = ~0
+            if (tid < 8) s_q[SGS_GROUP + tid] = ~0ull;
+        } else {
+            s_bcnt[tid] = 0;
             __syncthreads();
-            unsigned ex = incl - c;
-            for (int w = 0; w < wave; ++w) ex += sh.wsum[w];
-            s_boff[tid] = ex;
-            s_bcnt[tid] = ex;                             // scatter cursor
-            if (tid == SGS_NB - 1) s_boff[SGS_NB] = ex + c;
+            if (in_lds) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((unsigned)tid + 256u * (unsigned)r < n)
+                        atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), (rk[r] >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+            } else {
+                for (unsigned i = tid; i < n; i += 256)
+                    atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), (rec_key[beg + i] >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+            }
+            __syncthreads();
+            {
+                // exclusive scan of the 256 counts + ordered compaction of the non-empty buckets
+                const unsigned c = s_bcnt[tid];
+                const unsigned incl = wave_incl_scan(c, lane);
+                const unsigned long long nem = __ballot(c != 0u);
+                if (lane == 63) s_wsum[wave] = incl;
+                if (lane == 0) s_wne[wave] = (unsigned)__popcll(nem);
+                __syncthreads();
+                unsigned ex = incl - c, nb = 0;
+                for (int w = 0; w < 4; ++w) { if (w < wave) { ex += s_wsum[w]; nb += s_wne[w]; } n_ne += s_wne[w]; }
+                s_bcnt[tid] = ex;                             // scatter cursor
+                if (c != 0u) {
+                    const unsigned p = nb + (unsigned)__popcll(nem & lanemask_lt(lane));
+                    s_ne_end[p] = ex + c; s_ne_bkt[p] = (unsigned short)tid;
+                }
+            }
+            __syncthreads();
+            if (in_lds) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((unsigned)tid + 256u * (unsigned)r < n) {
+                        const unsigned bk = min((unsigned)(SGS_NB - 1), (rk[r] >> SGS_BUCKET_SHIFT) - kbase);
+                        s_q[atomicAdd(&s_bcnt[bk], 1u)] = ((unsigned long long)rk[r] << 32) | rv[r];
+                    }
+                if (tid < 8) s_q[n + tid] = ~0ull;
+            } else {
+                for (unsigned i = tid; i < n; i += 256) {
+                    const unsigned k = rec_key[beg + i], v = rec_val[beg + i];
+                    const unsigned bk = min((unsigned)(SGS_NB - 1), (k >> SGS_BUCKET_SHIFT) - kbase);
+                    const unsigned pos = atomicAdd(&s_bcnt[bk], 1u);
+                    alt_key[beg + pos] = k;
+                    alt_val[beg + pos] = v;
+                }
+            }
         }
-        __syncthreads();
-        for (unsigned i = tid; i < n; i += 256) {
-            const unsigned k = rec_key[beg + i], v = rec_val[beg + i];
-            const unsigned bk = min((unsigned)(SGS_NB - 1), (k >> SGS_BUCKET_SHIFT) - kbase);
-            const unsigned pos = atomicAdd(&s_bcnt[bk], 1u);
-            alt_key[beg + pos] = k;
-            alt_val[beg + pos] = v;
-        }
-        src_k = alt_key + beg; src_v = alt_val + beg;
     }
     __syncthreads();
 #ifdef SGS_TILE_PROF
@@ -733,32 +782,37 @@ __global__ __launch_bounds__(256) void k_tile_render(const FrameParams P,
     // ---- 2. groups of buckets, front to back -------------------------------------------------------
     unsigned it = 0;                     // batch counter (parity of the LDS flags)
     bool tile_done = false;
-    unsigned g_bucket = 0, lo = 0;       // next bucket / its queue position
+    unsigned e_next = 0, lo = 0;         // next non-empty bucket (index into s_ne_*) / its queue position
     while (lo < n && (!tile_done || full_sort)) {
-        unsigned hi, g0 = 0, g1 = 0;
+        unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
         else {
-            g1 = g_bucket;
-            while (s_boff[g1 + 1] == lo) ++g1;                                         // skip empty buckets
-            g0 = g1;
-            hi = s_boff[g1 + 1];
-            while (g1 + 1 < SGS_NB && s_boff[g1 + 2] - lo <= SGS_GROUP) { ++g1; hi = s_boff[g1 + 1]; }
-            g_bucket = g1 + 1;
+            hi = s_ne_end[e1];
+            while (e1 + 1 < n_ne && s_ne_end[e1 + 1] - lo <= SGS_GROUP) { ++e1; hi = s_ne_end[e1]; }
+            e_next = e1 + 1;
         }
         const unsigned cnt = hi - lo;
         const unsigned* gv;              // the group's slots in (depth, index) order
-        if (cnt <= SGS_GCAP) {
-            for (unsigned i = tid; i < cnt; i += 256)
-                s_kk[i] = ((unsigned long long)src_k[lo + i] << 32) | src_v[lo + i];
-            __syncthreads();
-            if (cnt <= 256) rank_sort<1>(s_kk, s_sorted, cnt);
-            else if (cnt <= 512) rank_sort<2>(s_kk, s_sorted, cnt);
-            else rank_sort<4>(s_kk, s_sorted, cnt);
+        if (cnt <= SGS_QCAP) {
+            const unsigned long long* kk = s_q + lo;       // in LDS already: sort the slice in place;
+            if (!in_lds) {                                  // the records that follow it are deeper, so they
+                kk = s_q;                                   // act as the sentinels the 8-wide walk needs
+                for (unsigned i = tid; i < ((cnt + 7u) & ~7u); i += 256)
+                    s_q[i] = i < cnt ? ((unsigned long long)alt_key[beg + lo + i] << 32) | alt_val[beg + lo + i] : ~0ull;
+                __syncthreads();
+            }
+            if (cnt <= 256) rank_sort<1>(kk, s_sorted, cnt);
+            else if (cnt <= 512) rank_sort<2>(kk, s_sorted, cnt);
+            else rank_sort<4>(kk, s_sorted, cnt);
             __syncthreads();
             gv = s_sorted;
-            if (full_sort) for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = s_sorted[i];
+            if (full_sort) {
+                for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = s_sorted[i];
+                __syncthreads();         // s_sorted is rewritten by the next group when the blend is skipped
+            }
         } else {
-            // one oversized bucket: radix sort through HBM (rec_* is free once the queue is partitioned)
+            // one oversized bucket of a long queue: radix sort through HBM (rec_* is free once partitioned)
+            const unsigned g0 = s_ne_bkt[e0], g1 = s_ne_bkt[e1];
             unsigned sub = (kbase + g0) << SGS_BUCKET_SHIFT;
             unsigned nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
             if (nbits >= 32u) { sub = 0u; nbits = 32u; }
