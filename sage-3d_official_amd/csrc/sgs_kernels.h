@@ -657,11 +657,11 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      FrameStatus* st, unsigned long long* prof) {
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
-    __shared__ float4 s_arena[2 * SGS_BATCH + SGS_BATCH / 4];
-    static_assert(sizeof(float4) * (2 * SGS_BATCH + SGS_BATCH / 4) >= sizeof(SortShared), "arena");
-    float4* const s_a = s_arena;                      // blend phase: the staged batch of splats
-    float4* const s_b = s_arena + SGS_BATCH;
-    float* const s_c = reinterpret_cast<float*>(s_arena + 2 * SGS_BATCH);
+    __shared__ float4 s_arena[2 * (SGS_BATCH + 1) + (SGS_BATCH + 4) / 4];
+    static_assert(sizeof(float4) * (2 * (SGS_BATCH + 1) + (SGS_BATCH + 4) / 4) >= sizeof(SortShared), "arena");
+    float4* const s_a = s_arena;                      // blend phase: the staged batch of splats (+1 dummy)
+    float4* const s_b = s_arena + (SGS_BATCH + 1);
+    float* const s_c = reinterpret_cast<float*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
     __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     const unsigned beg = tile_offset[tile];
     const unsigned n = tile_offset[tile + 1] - beg;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-    bool done = !inside;
+    float live = inside ? 1.0f : 0.0f;   // 1 while the pixel still accepts splats
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
@@ -845,6 +845,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 // stage the prefetched batch + per-quadrant overlap ballots
                 const bool have = (unsigned)tid < m;
                 unsigned qbits = 0;
+                if (tid == 0) {                       // the zero-opacity dummy (the arena is shared with the sort scratch)
+                    s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
+                    s_c[SGS_BATCH] = 0.f;
+                }
                 if (have) {
                     s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
                     // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
@@ -877,45 +881,47 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
-                if (__ballot(!done) != 0ull) {
+                if (__ballot(live > 0.0f) != 0ull) {
+                    // Predicates stay on the VALU (compare -> select): the scalar unit is shared by the CU's
+                    // four SIMDs and exec-mask algebra there was the bottleneck of this loop.  Two splats per
+                    // trip; an odd tail pairs with the zero-opacity dummy at index SGS_BATCH.
+#define SGS_BLEND(J)                                                                                   \
+    {                                                                                                  \
+        const float4 A = s_a[J], B = s_b[J];                                                           \
+        const float cb_ = s_c[J];                                                                      \
+        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
+        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
+        float alpha = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);   /* min(amax, .) */   \
+        alpha = power <= 0.0f ? alpha : 0.0f;      /* S6: skip if power > 0 */                          \
+        alpha = alpha >= amin ? alpha : 0.0f;      /* S6: skip if alpha < 1/255 */                      \
+        alpha *= live;                             /* finished (or outside) pixels take nothing */      \
+        const float testT = T * (1.0f - alpha);                                                        \
+        const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
+        const float wgt = stop ? 0.0f : alpha * T;                                                     \
+        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;                                             \
+        T = stop ? T : testT;                                                                          \
+        used = stop ? base + (J) + 1u : used;                                                          \
+        live = stop ? 0.0f : live;                                                                     \
+    }
                     bool wave_done = false;
                     for (int gw = 0; gw < 4 && !wave_done; ++gw) {
                         unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
-                        if (mask == 0ull) continue;
-                        unsigned j = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                        mask &= mask - 1ull;
-                        float4 A = s_a[j], B = s_b[j]; float cb_ = s_c[j];
                         unsigned cn = 0;
-                        for (;;) {
-                            // issue the LDS reads of the next splat before the arithmetic of this one
-                            const bool more = mask != 0ull;
-                            unsigned jn = j;
-                            float4 An = A, Bn = B; float cn_ = cb_;
-                            if (more) {
-                                jn = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                                mask &= mask - 1ull;
-                                An = s_a[jn]; Bn = s_b[jn]; cn_ = s_c[jn];
-                            }
-                            const float dx = A.x - fpx, dy = A.y - fpy;
-                            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                            const float alpha = fminf(amax, B.y * __expf(power));
-                            const float testT = T * (1.0f - alpha);
-                            used = done ? used : base + j + 1u;
-                            const bool hit = !done && power <= 0.0f && alpha >= amin;
-                            const bool stop = hit && testT < tmin;
-                            const bool blend = hit && !stop;
-                            const float wgt = blend ? alpha * T : 0.0f;
-                            C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;
-                            T = blend ? testT : T;
-                            done = done || stop;
-                            if ((++cn & 7u) == 0u && __ballot(!done) == 0ull) { wave_done = true; break; }
-                            if (!more) break;
-                            j = jn; A = An; B = Bn; cb_ = cn_;
+                        while (mask != 0ull) {
+                            const unsigned j0 = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                            mask &= mask - 1ull;
+                            const unsigned j1 = mask != 0ull ? (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1)
+                                                             : (unsigned)SGS_BATCH;
+                            mask &= mask - 1ull;
+                            SGS_BLEND(j0)
+                            SGS_BLEND(j1)
+                            if ((++cn & 3u) == 0u && __ballot(live > 0.0f) == 0ull) { wave_done = true; break; }
                         }
                     }
-                    if (!done) used = base + m;      // still live: the whole batch counts as examined
+#undef SGS_BLEND
+                    used = live > 0.0f ? base + m : used;     // still live: the whole batch counts as examined
                 }
-                const bool still_live = __ballot(!done) != 0ull;
+                const bool still_live = __ballot(live > 0.0f) != 0ull;
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform

@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 PMC passes over a short bench run (counters in their own runs: no --kernel-trace/--stats mixing beyond what is allowed).
+TAG=${1:-r01}
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/pmc_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+run() { # name counters...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $GRAFT_REPO_ROOT/bench.py --steps ${PMC_STEPS:-12} --warmup 2 --no-cpu-baseline --no-events > $OUT/$name.log 2>&1
+  find $OUT/$name -name "*counter_collection.csv" -exec cp {} $OUT/$name.csv \;
+  rm -rf $OUT/$name
+}
+run sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
+run sq2 SQ_BUSY_CYCLES SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run grbm GRBM_GUI_ACTIVE
+ls -la $OUT

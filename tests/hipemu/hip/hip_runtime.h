@@ -225,6 +225,7 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
 static inline unsigned long long clock64() { return 0; }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // callers pass wave-uniform values
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
