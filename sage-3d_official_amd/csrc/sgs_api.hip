@@ -52,7 +52,9 @@ struct sgs_ctx {
     unsigned* blk_len = nullptr;
     // per-record scratch
     int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
-    unsigned *rec_key = nullptr, *rec_val = nullptr, *alt_key = nullptr, *alt_val = nullptr;
+    unsigned long long *rec = nullptr, *alt = nullptr;   // queues of (depth bits << 32 | slot) records + partition space
+    unsigned* sorted_out = nullptr;                      // SGS_FLAG_FULL_SORT (tests): fully ordered queues
+    int64_t sorted_cap = 0;
     // status ring
     FrameStatus* d_status = nullptr;
     FrameStatus* h_status = nullptr;
@@ -121,25 +123,31 @@ int ensure_blk_list(sgs_ctx* ctx, int n_windows) {
 int ensure_tiles(sgs_ctx* ctx, int tiles) {
     if (tiles <= ctx->tile_cap) return SGS_OK;
     int rc;
-    if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_prof, (size_t)tiles * 8)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
-    SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
+    SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
     ctx->tile_cap = tiles;
     return SGS_OK;
 }
 
 int ensure_records(sgs_ctx* ctx) {
-    if (ctx->rec_cap >= ctx->rec_cap_wanted && ctx->rec_key) return SGS_OK;
+    if (ctx->rec_cap >= ctx->rec_cap_wanted && ctx->rec) return SGS_OK;
     const int64_t cap = std::max<int64_t>(ctx->rec_cap_wanted, 1024);
     if (cap > 0xfffffff0ll) SGS_FAIL(ctx, SGS_ERR_INVALID, "record capacity %lld exceeds 2^32", (long long)cap);
     int rc;
-    if ((rc = grow(ctx, ctx->rec_key, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->rec_val, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->alt_key, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->alt_val, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->rec, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->alt, (size_t)cap)) != SGS_OK) return rc;
     ctx->rec_cap = cap;
+    return SGS_OK;
+}
+
+int ensure_sorted_out(sgs_ctx* ctx) {
+    if (ctx->sorted_cap >= ctx->rec_cap && ctx->sorted_out) return SGS_OK;
+    int rc;
+    if ((rc = grow(ctx, ctx->sorted_out, (size_t)ctx->rec_cap)) != SGS_OK) return rc;
+    ctx->sorted_cap = ctx->rec_cap;
     return SGS_OK;
 }
 
@@ -197,6 +205,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     FrameParams P;
     fill_params(P, ctx, scene, cam, cfg, row_begin, row_end);
     if ((rc = ensure_blk_list(ctx, std::max(1, P.n_windows))) != SGS_OK) return rc;
+    if ((P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx)) != SGS_OK) return rc;
     FrameStatus* st = ctx->d_status + slot;
     SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
     hipEvent_t* ev = nullptr;
@@ -227,15 +236,14 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
-                           ctx->vismask, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec_key,
-                           ctx->rec_val, st);
+                           ctx->vismask, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec_key,
-                           ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->splats, out_rgb, st, ctx->tile_prof);
+        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec,
+                           ctx->alt, ctx->sorted_out, ctx->splats, out_rgb, st, ctx->tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
@@ -335,7 +343,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {ctx->splats, ctx->vismask, ctx->tile_count, ctx->tile_offset, ctx->tile_prof,
-                    ctx->blk_list, ctx->blk_len, ctx->rec_key, ctx->rec_val, ctx->alt_key, ctx->alt_val, ctx->d_status};
+                    ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->sorted_out, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev) {
@@ -546,8 +554,8 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
     const void* src = nullptr;
     int64_t have = 0, elem = 0;
     switch (what) {
-        case SGS_BUF_TILE_OFFSETS: src = ctx->tile_offset; have = ((int64_t)ctx->last_T + 1) * 4; break;
-        case SGS_BUF_SORTED_SLOTS: src = ctx->rec_val; have = s.overflow ? 0 : (int64_t)s.d_total * 4; break;
+        case SGS_BUF_TILE_OFFSETS: have = ((int64_t)ctx->last_T + 1) * 4; break;       // every 8th sub-queue offset
+        case SGS_BUF_SORTED_SLOTS: src = ctx->sorted_out; have = (s.overflow || !ctx->sorted_out) ? 0 : (int64_t)s.d_total * 4; break;
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: src = ctx->splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
         case 100: src = ctx->tile_prof; have = (int64_t)ctx->last_T * 64; break;    // profiling build only
@@ -556,6 +564,15 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
     const int64_t n = std::min(have, bytes);
     if (n <= 0 || !host_dst) return have;
     if (src) SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
+    if (what == SGS_BUF_TILE_OFFSETS) {
+        const size_t cnt = (size_t)ctx->last_T * SGS_XCDS + 1;
+        unsigned* tmp = (unsigned*)malloc(cnt * 4);
+        if (!tmp) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+        hipError_t e = hipMemcpy(tmp, ctx->tile_offset, cnt * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { free(tmp); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
+        for (int64_t i = 0; (i + 1) * 4 <= n; ++i) ((unsigned*)host_dst)[i] = tmp[(size_t)i * SGS_XCDS];
+        free(tmp);
+    }
     if (elem) {
         // a splat lives at its Gaussian's index; the per-chunk visibility masks say which are live.
         // Dead slots are blanked (slot ids -> 0xFFFFFFFF, splats -> 0) so stale data cannot pass for live.

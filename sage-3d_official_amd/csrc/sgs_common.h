@@ -15,6 +15,8 @@
 #define SGS_BIN_THREADS 512
 #define SGS_BIN_BLOCKS 512          // binning workgroups (2 per CU); each owns ranges b, b+B, b+2B, ...
 #define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)
+#define SGS_XCDS 8                  // sub-queues per tile: one per XCD the binning workgroups run on
+#define SGS_MAX_LIVE 4096           // live chunks a binning workgroup can list (its share is n_chunks / SGS_BIN_BLOCKS)
 
 // Radix sort (S5)
 #define SGS_RADIX_BITS 8

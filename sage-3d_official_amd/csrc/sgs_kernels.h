@@ -288,8 +288,10 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4: exclusive scan of tile counts (single workgroup; T <= 32400 at 4K), D and the longest queue.
-// Every count is cleared once consumed, so the counters are ready for the next frame without a memset.
+// S4: exclusive scan of the tile counts (single workgroup), D and the longest queue.  A tile has
+// SGS_XCDS sub-counters — one per XCD the binning workgroups run on — so that the records an XCD
+// writes into a queue are contiguous and its L2 can write-combine them; the queue of tile t is
+// [offset[8t], offset[8t+8]).  Every count is cleared once consumed: no per-frame memset.
 #define SGS_SCAN_THREADS 1024
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
                                                                 unsigned* __restrict__ tile_count,
@@ -299,10 +301,15 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = P.gx * P.gy;
-    const int per = (T + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS;
+    const int per = (T + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS;      // whole tiles per thread
     const int beg = tid * per, end = min(T, beg + per);
     unsigned sum = 0, mx = 0;
-    for (int t = beg; t < end; ++t) { const unsigned c = tile_count[t]; sum += c; mx = c > mx ? c : mx; }
+    for (int t = beg; t < end; ++t) {
+        const uint4 c0 = reinterpret_cast<const uint4*>(tile_count + (size_t)t * SGS_XCDS)[0];
+        const uint4 c1 = reinterpret_cast<const uint4*>(tile_count + (size_t)t * SGS_XCDS)[1];
+        const unsigned c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
+        sum += c; mx = c > mx ? c : mx;
+    }
     const unsigned incl = wave_incl_scan(sum, lane);
     const unsigned wmx = wave_max(mx);
     if (lane == 63) s_wsum[wave] = incl;
@@ -317,13 +324,13 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     }
     unsigned run = wbase + incl - sum;
     for (int t = beg; t < end; ++t) {
-        const unsigned c = tile_count[t];
-        tile_offset[t] = run;
-        tile_count[t] = 0;
-        run += c;
+        unsigned* c = tile_count + (size_t)t * SGS_XCDS;
+        unsigned* o = tile_offset + (size_t)t * SGS_XCDS;
+#pragma unroll
+        for (int x = 0; x < SGS_XCDS; ++x) { const unsigned v = c[x]; o[x] = run; c[x] = 0; run += v; }
     }
     if (tid == 0) {
-        tile_offset[T] = total;
+        tile_offset[(size_t)T * SGS_XCDS] = total;
         st->d_total = total;
         st->max_tile_len = tmax;
         st->overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity ? 1u : 0u;
@@ -342,36 +349,79 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
 // atomicAdd per tile it touched: the returned value is the workgroup's base inside that tile's queue.
 // The (tile, base) pairs go to a per-workgroup list; after the scan, k_bin_emit reloads them as
 // absolute cursors into LDS and writes every record with an LDS atomic only.
-// Calls f(valid, local tile index, depth bits, slot) for every record of this workgroup's splats
-// that falls into tile rows [wr0, wr1).  Workgroup b owns the 1024-Gaussian ranges b, b+B, ...; its
-// waves take the chunks of a range.  Returns the number of live splats seen by this lane's wave.
-template <class F>
-__device__ __forceinline__ unsigned bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
-                                             const unsigned long long* __restrict__ vismask, int wr0, int wr1, F&& f) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    unsigned seen = 0;
-    for (int r = blockIdx.x; r < P.n_ranges; r += gridDim.x) {
-        for (int cw = wave; cw < SGS_RANGE_CHUNKS; cw += nwaves) {
-            const long long chunk = (long long)r * SGS_RANGE_CHUNKS + cw;
-            if (chunk >= P.n_chunks) break;                   // wave-uniform
+// The live chunks of this workgroup's ranges (b, b+B, b+2B, ...), found in ONE coalesced sweep over the
+// visibility masks and appended to an LDS list — so that no wave ever waits on a mask load just to learn
+// that a chunk is culled.  Must be called by all threads; ends with a barrier.
+struct LiveChunks {
+    unsigned chunk[SGS_MAX_LIVE];       // chunk index
+    unsigned n;
+    unsigned n_vis;                     // live splats (popcount of the masks)
+};
+// One sweep covers SGS_BIN_THREADS / 16 of the workgroup's ranges; a pass does at most
+// SGS_MAX_LIVE / SGS_BIN_THREADS sweeps, so the list cannot overflow however large the scene is.
+#define SGS_RANGES_PER_SWEEP (SGS_BIN_THREADS / SGS_RANGE_CHUNKS)
+#define SGS_SWEEPS_PER_PASS (SGS_MAX_LIVE / SGS_BIN_THREADS)
+__device__ __forceinline__ int bin_sweeps(const FrameParams& P) {
+    const int mine = (P.n_ranges - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // ranges b, b+B, ...
+    return (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP;
+}
+__device__ __forceinline__ void find_live_chunks(const FrameParams& P, const unsigned long long* __restrict__ vismask,
+                                                 LiveChunks& lc, int sweep0, int sweep1) {
+    if (threadIdx.x == 0) { lc.n = 0; lc.n_vis = 0; }
+    __syncthreads();
+    unsigned vis = 0;
+    for (int sw = sweep0; sw < sweep1; ++sw) {
+        const int j = sw * SGS_RANGES_PER_SWEEP + (int)(threadIdx.x / SGS_RANGE_CHUNKS);     // j-th range of this workgroup
+        const long long r = (long long)blockIdx.x + (long long)j * gridDim.x;
+        const long long chunk = r * SGS_RANGE_CHUNKS + (threadIdx.x % SGS_RANGE_CHUNKS);
+        if (r < P.n_ranges && chunk < P.n_chunks) {
             const unsigned long long vm = vismask[chunk];
-            if (vm == 0ull) continue;                         // wave-uniform: whole chunk culled
-            seen += (unsigned)__popcll(vm);
-            const unsigned slot = (unsigned)(chunk * SGS_WAVE) + (unsigned)lane;
-            unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
-            if ((vm >> lane) & 1ull) {
-                const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
-                key = __float_as_uint(c.y);
-                const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
-                x0 = r01 & 0xffffu;
-                w = (r23 & 0xffffu) - x0;
-                const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-                if (yb > ya) { y0 = (unsigned)(ya - wr0); cnt = w * (unsigned)(yb - ya); }
+            if (vm != 0ull) {
+                vis += (unsigned)__popcll(vm);
+                lc.chunk[atomicAdd(&lc.n, 1u)] = (unsigned)chunk;
             }
-            wave_expand(cnt, x0, y0, w, key, slot, P.gx, lane, f);
         }
     }
-    return seen;
+    if (vis) atomicAdd(&lc.n_vis, vis);
+    __syncthreads();
+}
+
+// Calls f(valid, local tile index, depth bits, slot) for every record of the listed chunks that falls
+// into tile rows [wr0, wr1).  Small rects (the common case: a splat touches ~7 tiles) are walked by their
+// own lane — a short divergent loop with no cross-lane traffic; only rects of more than SGS_SMALL_RECT
+// tiles go through the balanced wave-wide expansion, whose owner search is a chain of dependent shuffles.
+#define SGS_SMALL_RECT 16
+template <class F>
+__device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
+                                         const unsigned long long* __restrict__ vismask, const LiveChunks& lc,
+                                         int wr0, int wr1, F&& f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const unsigned nlive = lc.n;
+    for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
+        const unsigned chunk = lc.chunk[k];
+        const unsigned long long vm = vismask[chunk];
+        const unsigned slot = chunk * SGS_WAVE + (unsigned)lane;
+        unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
+        if ((vm >> lane) & 1ull) {
+            const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
+            key = __float_as_uint(c.y);
+            const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
+            x0 = r01 & 0xffffu;
+            w = (r23 & 0xffffu) - x0;
+            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+            if (yb > ya) { y0 = (unsigned)(ya - wr0); cnt = w * (unsigned)(yb - ya); }
+        }
+        const bool small = cnt <= SGS_SMALL_RECT;
+        if (small) {
+            unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
+            for (unsigned i = 0; i < cnt; ++i) {
+                f(true, row + tx, key, slot);
+                if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+            }
+        }
+        const unsigned big = small ? 0u : cnt;
+        if (__ballot(big != 0u) != 0ull) wave_expand(big, x0, y0, w, key, slot, P.gx, lane, f);
+    }
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
@@ -383,34 +433,40 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
                                                                FrameStatus* __restrict__ st) {
     __shared__ unsigned s_cnt[SGS_WT];
     __shared__ unsigned short s_list[SGS_WT];
-    __shared__ unsigned s_nlist, s_seen;
+    __shared__ unsigned s_nlist;
+    __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
+    const unsigned xcd = blockIdx.x & (SGS_XCDS - 1);         // a placement hint only (speed, not correctness)
     for (int i = tid; i < SGS_WT; i += SGS_BIN_THREADS) s_cnt[i] = 0;
-    if (tid == 0) s_seen = 0;
+    const int n_sweeps = bin_sweeps(P);
+    unsigned n_vis = 0;
     for (int w = 0; w < P.n_windows; ++w) {
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
         if (tid == 0) s_nlist = 0;
         __syncthreads();
-        const unsigned seen = bin_walk(P, splats, vismask, wr0, wr1,
-                                       [&](bool valid, unsigned tl, unsigned, unsigned) {
-                                           if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
-                                               s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
-                                       });
-        if (w == 0 && (tid & 63) == 0 && seen) atomicAdd(&s_seen, seen);
-        __syncthreads();
-        // flush: one device-scope atomic per touched tile; its return value is our base in the queue
+        for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
+            find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            if (w == 0) n_vis += lc.n_vis;
+            bin_walk(P, splats, vismask, lc, wr0, wr1,
+                     [&](bool valid, unsigned tl, unsigned, unsigned) {
+                         if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
+                             s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
+                     });
+            __syncthreads();
+        }
+        // flush: one device-scope atomic per touched tile; its return value is our base in the sub-queue
         const unsigned nl = s_nlist;
         uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
         for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
             const unsigned tl = s_list[i];
             const unsigned c = s_cnt[tl];
             s_cnt[tl] = 0;                                     // ready for the next window
-            const unsigned base = atomicAdd(&tile_count[(unsigned)wr0 * (unsigned)P.gx + tl], c);
+            const unsigned base = atomicAdd(&tile_count[((size_t)wr0 * P.gx + tl) * SGS_XCDS + xcd], c);
             out[i] = make_uint2(tl, base);
         }
         if (tid == 0) {
             blk_len[blockIdx.x * SGS_MAX_WINDOWS + w] = nl;
-            if (w == 0 && s_seen) atomicAdd(&st->n_visible, s_seen);    // one per workgroup
+            if (w == 0 && n_vis) atomicAdd(&st->n_visible, n_vis);    // one per workgroup
         }
         __syncthreads();
     }
@@ -422,30 +478,31 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
                                                               const unsigned* __restrict__ tile_offset,
                                                               const uint2* __restrict__ blk_list,
                                                               const unsigned* __restrict__ blk_len,
-                                                              unsigned* __restrict__ rec_key,
-                                                              unsigned* __restrict__ rec_val,
+                                                              unsigned long long* __restrict__ rec,
                                                               const FrameStatus* __restrict__ st) {
     __shared__ unsigned s_next[SGS_WT];
+    __shared__ LiveChunks lc;
     if (st->overflow) return;
     const int tid = threadIdx.x;
+    const unsigned xcd = blockIdx.x & (SGS_XCDS - 1);
+    const int n_sweeps = bin_sweeps(P);
     for (int w = 0; w < P.n_windows; ++w) {
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
         const unsigned nl = blk_len[blockIdx.x * SGS_MAX_WINDOWS + w];
         const uint2* in = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
         for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
             const uint2 e = in[i];
-            s_next[e.x] = tile_offset[(unsigned)wr0 * (unsigned)P.gx + e.x] + e.y;
+            s_next[e.x] = tile_offset[((size_t)wr0 * P.gx + e.x) * SGS_XCDS + xcd] + e.y;
         }
         __syncthreads();
-        bin_walk(P, splats, vismask, wr0, wr1,
-                 [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
-                     if (valid) {
-                         const unsigned dst = atomicAdd(&s_next[tl], 1u);
-                         rec_key[dst] = okey;
-                         rec_val[dst] = oslot;
-                     }
-                 });
-        __syncthreads();
+        for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
+            find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            bin_walk(P, splats, vismask, lc, wr0, wr1,
+                     [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
+                         if (valid) rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
+                     });
+            __syncthreads();
+        }
     }
 }
 
@@ -650,8 +707,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 
 __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
-                                                     unsigned* rec_key, unsigned* rec_val,
-                                                     unsigned* alt_key, unsigned* alt_val,
+                                                     unsigned long long* rec, unsigned long long* alt,
+                                                     unsigned* sorted_out,
                                                      const Splat* __restrict__ splats,
                                                      float* __restrict__ out_rgb,
                                                      FrameStatus* st, unsigned long long* prof) {
@@ -697,8 +754,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     const float k_cut = -2.0f * __logf(amin);          // alpha >= amin  <=>  d^T Q d <= 2 ln(o) + k_cut
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
 
-    const unsigned beg = tile_offset[tile];
-    const unsigned n = tile_offset[tile + 1] - beg;
+    const unsigned beg = tile_offset[(size_t)tile * SGS_XCDS];              // the tile's 8 per-XCD sub-queues are adjacent
+    const unsigned n = tile_offset[(size_t)tile * SGS_XCDS + SGS_XCDS] - beg;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
     float live = inside ? 1.0f : 0.0f;   // 1 while the pixel still accepts splats
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
@@ -713,17 +770,16 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     if (tid < 2) s_any[tid] = 0;
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
     {
-        unsigned rk[4], rv[4];
+        unsigned long long rq[4];
         if (in_lds) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const unsigned i = (unsigned)tid + 256u * (unsigned)r;
-                rk[r] = i < n ? rec_key[beg + i] : 0xffffffffu;
-                rv[r] = i < n ? rec_val[beg + i] : 0xffffffffu;
+                rq[r] = i < n ? rec[beg + i] : ~0ull;
             }
         }
         if (!parted) {
-            s_q[tid] = ((unsigned long long)rk[0] << 32) | rv[0];          // n <= 256: one group, pad = ~0
+            s_q[tid] = rq[0];                                              // n <= 256: one group, padded with ~0
             if (tid < 8) s_q[SGS_GROUP + tid] = ~0ull;
         } else {
             s_bcnt[tid] = 0;
@@ -732,10 +788,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if ((unsigned)tid + 256u * (unsigned)r < n)
-                        atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), (rk[r] >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                        atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(rq[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
             } else {
                 for (unsigned i = tid; i < n; i += 256)
-                    atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), (rec_key[beg + i] >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                    atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(rec[beg + i] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
             }
             __syncthreads();
             {
@@ -759,17 +815,15 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if ((unsigned)tid + 256u * (unsigned)r < n) {
-                        const unsigned bk = min((unsigned)(SGS_NB - 1), (rk[r] >> SGS_BUCKET_SHIFT) - kbase);
-                        s_q[atomicAdd(&s_bcnt[bk], 1u)] = ((unsigned long long)rk[r] << 32) | rv[r];
+                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(rq[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                        s_q[atomicAdd(&s_bcnt[bk], 1u)] = rq[r];
                     }
                 if (tid < 8) s_q[n + tid] = ~0ull;
             } else {
                 for (unsigned i = tid; i < n; i += 256) {
-                    const unsigned k = rec_key[beg + i], v = rec_val[beg + i];
-                    const unsigned bk = min((unsigned)(SGS_NB - 1), (k >> SGS_BUCKET_SHIFT) - kbase);
-                    const unsigned pos = atomicAdd(&s_bcnt[bk], 1u);
-                    alt_key[beg + pos] = k;
-                    alt_val[beg + pos] = v;
+                    const unsigned long long x = rec[beg + i];
+                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                    alt[beg + atomicAdd(&s_bcnt[bk], 1u)] = x;
                 }
             }
         }
@@ -797,8 +851,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             const unsigned long long* kk = s_q + lo;       // in LDS already: sort the slice in place;
             if (!in_lds) {                                  // the records that follow it are deeper, so they
                 kk = s_q;                                   // act as the sentinels the 8-wide walk needs
-                for (unsigned i = tid; i < ((cnt + 7u) & ~7u); i += 256)
-                    s_q[i] = i < cnt ? ((unsigned long long)alt_key[beg + lo + i] << 32) | alt_val[beg + lo + i] : ~0ull;
+                for (unsigned i = tid; i < ((cnt + 7u) & ~7u); i += 256) s_q[i] = i < cnt ? alt[beg + lo + i] : ~0ull;
                 __syncthreads();
             }
             if (cnt <= 256) rank_sort<1>(kk, s_sorted, cnt);
@@ -807,22 +860,30 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             __syncthreads();
             gv = s_sorted;
             if (full_sort) {
-                for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = s_sorted[i];
+                for (unsigned i = tid; i < cnt; i += 256) sorted_out[beg + lo + i] = s_sorted[i];
                 __syncthreads();         // s_sorted is rewritten by the next group when the blend is skipped
             }
         } else {
-            // one oversized bucket of a long queue: radix sort through HBM (rec_* is free once partitioned)
+            // One oversized bucket of a long queue: radix sort through HBM.  The segment's 8-byte records are
+            // split into a key half and a slot half inside the (now free) rec segment; the alt segment is
+            // the ping-pong space.
             const unsigned g0 = s_ne_bkt[e0], g1 = s_ne_bkt[e1];
             unsigned sub = (kbase + g0) << SGS_BUCKET_SHIFT;
             unsigned nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
             if (nbits >= 32u) { sub = 0u; nbits = 32u; }
-            sort_segment(alt_key + beg + lo, alt_val + beg + lo, rec_key + beg + lo, rec_val + beg + lo, cnt, sub, nbits,
-                         sh, splats, P.n, st);
-            gv = alt_val + beg + lo;
+            unsigned* b_k = reinterpret_cast<unsigned*>(rec + beg + lo); unsigned* b_v = b_k + cnt;
+            unsigned* a_k = reinterpret_cast<unsigned*>(alt + beg + lo); unsigned* a_v = a_k + cnt;
+            for (unsigned i = tid; i < cnt; i += 256) {
+                const unsigned long long x = alt[beg + lo + i];
+                b_k[i] = (unsigned)(x >> 32); b_v[i] = (unsigned)x;
+            }
+            __syncthreads();
+            sort_segment(b_k, b_v, a_k, a_v, cnt, sub, nbits, sh, splats, P.n, st);
+            gv = b_v;
             if (tid == 0) atomicAdd(&st->class_count[3], 1u);
             if (full_sort) {
                 __syncthreads();
-                for (unsigned i = tid; i < cnt; i += 256) rec_val[beg + lo + i] = gv[i];
+                for (unsigned i = tid; i < cnt; i += 256) sorted_out[beg + lo + i] = gv[i];
             }
             __syncthreads();
         }

@@ -42,6 +42,7 @@ struct dim3 {
 struct alignas(16) float4 { float x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
 namespace hipemu {
