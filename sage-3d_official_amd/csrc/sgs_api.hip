@@ -106,7 +106,7 @@ int ensure_splats(sgs_ctx* ctx, int64_t n) {
     int rc;
     if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->vismask, (size_t)chunks)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * (SGS_MAX_WINDOWS + 1))) != SGS_OK) return rc;
     ctx->splat_cap = cap;
     return SGS_OK;
 }
