@@ -42,10 +42,13 @@ struct sgs_ctx {
     int64_t splat_cap = 0;
     Splat* splats = nullptr;                 // one slot per Gaussian (slot == index)
     unsigned long long* vismask = nullptr;   // per 64-Gaussian chunk: which slots are live this frame
+    unsigned long long* bigmask = nullptr;   //   ... and which of those went to the big-rect list
+    unsigned* big_list = nullptr;
     // per-tile scratch
     int tile_cap = 0;
     unsigned *tile_count = nullptr, *tile_offset = nullptr;
     unsigned long long* tile_prof = nullptr;         // profiling build: 8 words per tile
+    unsigned long long* bin_prof = nullptr;          // profiling build: 8 words per binning workgroup
     // binning scratch: per-workgroup (tile, base) lists
     int64_t blk_list_cap = 0;
     uint2* blk_list = nullptr;
@@ -106,7 +109,10 @@ int ensure_splats(sgs_ctx* ctx, int64_t n) {
     int rc;
     if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->vismask, (size_t)chunks)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->bigmask, (size_t)chunks)) != SGS_OK) return rc;
+    if (!ctx->big_list && (rc = grow(ctx, ctx->big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * (SGS_MAX_WINDOWS + 1))) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->bin_prof, (size_t)SGS_BIN_BLOCKS * 8)) != SGS_OK) return rc;
     ctx->splat_cap = cap;
     return SGS_OK;
 }
@@ -224,19 +230,21 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     const unsigned bin_blocks = (unsigned)std::min<int64_t>(SGS_BIN_BLOCKS, P.n_ranges);
     if (P.n_chunks > 0)
         hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
-                           scene->geom, scene->shq, ctx->splats, ctx->vismask);
+                           scene->geom, scene->shq, ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
-                           ctx->vismask, ctx->tile_count, ctx->blk_list, ctx->blk_len, st);
+                           ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_count, ctx->blk_list, ctx->blk_len, st,
+                           ctx->bin_prof);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
                        ctx->tile_offset, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
-                           ctx->vismask, ctx->tile_offset, ctx->blk_list, ctx->blk_len, ctx->rec, st);
+                           ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_offset, ctx->blk_list, ctx->blk_len,
+                           ctx->rec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
@@ -342,7 +350,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->vismask, ctx->tile_count, ctx->tile_offset, ctx->tile_prof,
+    void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_count, ctx->tile_offset, ctx->tile_prof, ctx->bin_prof,
                     ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->sorted_out, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -559,6 +567,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: src = ctx->splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
         case 100: src = ctx->tile_prof; have = (int64_t)ctx->last_T * 64; break;    // profiling build only
+        case 101: src = ctx->bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
     }
     const int64_t n = std::min(have, bytes);

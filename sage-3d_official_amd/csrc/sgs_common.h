@@ -16,6 +16,8 @@
 #define SGS_BIN_BLOCKS 512          // binning workgroups (2 per CU); each owns ranges b, b+B, b+2B, ...
 #define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)
 #define SGS_XCDS 8                  // sub-queues per tile: one per XCD the binning workgroups run on
+#define SGS_BIG_RECT 256            // splats touching more tiles than this are expanded by a whole workgroup
+#define SGS_BIG_CAP 65536           // entries of the per-frame big-splat list (overflow falls back to the wave path)
 #define SGS_MAX_LIVE 4096           // live chunks a binning workgroup can list (its share is n_chunks / SGS_BIN_BLOCKS)
 
 // Radix sort (S5)
@@ -57,7 +59,8 @@ struct FrameStatus {
     uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
     unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
     uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
-    uint32_t pad_[5];
+    uint32_t n_big;                 // splats in the big-rect list (may exceed SGS_BIG_CAP; consumers clamp)
+    uint32_t pad_[4];
 };
 
 // One projected Gaussian ("splat"), 48 B, three aligned 16-B words.

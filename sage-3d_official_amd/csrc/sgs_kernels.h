@@ -179,7 +179,9 @@ __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
 // One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
 __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const float4* __restrict__ geom,
                                                  const float4* __restrict__ shq, Splat* __restrict__ splats,
-                                                 unsigned long long* __restrict__ vismask, long long chunk, int lane) {
+                                                 unsigned long long* __restrict__ vismask,
+                                                 unsigned long long* __restrict__ bigmask, unsigned* __restrict__ big_list,
+                                                 FrameStatus* __restrict__ st, long long chunk, int lane) {
     const long long id = chunk * SGS_WAVE + lane;
 
     const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
@@ -189,7 +191,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
     const bool front = id < P.n && tz > (double)P.near_z && tz <= (double)P.far_z;
 
-    bool vis = false;
+    bool vis = false, big = false;
     unsigned rect01 = 0, rect23 = 0;
     float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     if (front) {
@@ -247,6 +249,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
                 vis = true;
+                big = nt > SGS_BIG_RECT;
                 rect01 = (unsigned)x0 | ((unsigned)y0 << 16);
                 rect23 = (unsigned)x1 | ((unsigned)y1 << 16);
                 sx = (float)px; sy = (float)py;
@@ -258,8 +261,16 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     // No compaction: a splat lives at its Gaussian's index (slot == index), and the wave's ballot is
     // the chunk's visibility mask.  Ties on depth can then break on the slot number itself.
     const unsigned long long vmask = __ballot(vis);
-    if (lane == 0) vismask[chunk] = vmask;
     const unsigned slot = (unsigned)id;
+    // A splat whose rect covers hundreds of tiles (a near-camera Gaussian) would keep ONE wave of the
+    // binning kernels busy for its whole expansion; those few go to a global list instead and are
+    // expanded by entire workgroups.  bigmask tells the per-chunk walk to skip them.
+    if (big) {
+        const unsigned k = atomicAdd(&st->n_big, 1u);
+        if (k < SGS_BIG_CAP) big_list[k] = slot; else big = false;
+    }
+    const unsigned long long bmask = __ballot(big);
+    if (lane == 0) { vismask[chunk] = vmask; bigmask[chunk] = bmask; }
 
     if (vis) {
         // S1: view direction in model space (fp64 difference, fp32 polynomial)
@@ -292,11 +303,14 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
                                                     const float4* __restrict__ geom,
                                                     const float4* __restrict__ shq,
                                                     Splat* __restrict__ splats,
-                                                    unsigned long long* __restrict__ vismask) {
+                                                    unsigned long long* __restrict__ vismask,
+                                                    unsigned long long* __restrict__ bigmask,
+                                                    unsigned* __restrict__ big_list,
+                                                    FrameStatus* __restrict__ st) {
     const int lane = threadIdx.x & 63;
     const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (chunk >= P.n_chunks) return;                       // wave-uniform
-    preprocess_chunk(P, geom, shq, splats, vismask, chunk, lane);
+    preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, st, chunk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -409,13 +423,14 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
 #define SGS_SMALL_RECT 16
 template <class F>
 __device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
-                                         const unsigned long long* __restrict__ vismask, const LiveChunks& lc,
+                                         const unsigned long long* __restrict__ vismask,
+                                         const unsigned long long* __restrict__ bigmask, const LiveChunks& lc,
                                          int wr0, int wr1, F&& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
     for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
         const unsigned chunk = lc.chunk[k];
-        const unsigned long long vm = vismask[chunk];
+        const unsigned long long vm = vismask[chunk] & ~bigmask[chunk];
         const unsigned slot = chunk * SGS_WAVE + (unsigned)lane;
         unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
         if ((vm >> lane) & 1ull) {
@@ -440,13 +455,45 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __re
     }
 }
 
+// The big-rect splats (k_preprocess's list), dealt round-robin to the workgroups; every thread of the
+// workgroup takes a share of each rect.  Same callback contract as bin_walk.
+template <class F>
+__device__ __forceinline__ void bin_walk_big(const FrameParams& P, const Splat* __restrict__ splats,
+                                             const unsigned* __restrict__ big_list, unsigned n_big,
+                                             int wr0, int wr1, F&& f) {
+    n_big = min(n_big, (unsigned)SGS_BIG_CAP);
+    for (unsigned i = blockIdx.x; i < n_big; i += gridDim.x) {
+        const unsigned slot = big_list[i];
+        const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
+        const unsigned key = __float_as_uint(c.y);
+        const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
+        const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
+        const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+        if (yb <= ya) continue;                              // workgroup-uniform
+        const unsigned total = w * (unsigned)(yb - ya);
+        const float rw = 1.0f / (float)w;
+        for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
+            const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);      // k / w, exact (see wave_expand)
+            f(true, ((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), key, slot);
+        }
+    }
+}
+
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
                                                                const Splat* __restrict__ splats,
                                                                const unsigned long long* __restrict__ vismask,
+                                                               const unsigned long long* __restrict__ bigmask,
+                                                               const unsigned* __restrict__ big_list,
                                                                unsigned* __restrict__ tile_count,
                                                                uint2* __restrict__ blk_list,
                                                                unsigned* __restrict__ blk_len,
-                                                               FrameStatus* __restrict__ st) {
+                                                               FrameStatus* __restrict__ st, unsigned long long* prof) {
+#ifdef SGS_TILE_PROF
+    unsigned long long bt0 = clock64(), bt_find = 0, bt_walk = 0, bt_flush = 0, btm = bt0;
+#define SGS_BPROF(acc) do { unsigned long long now_ = clock64(); acc += now_ - btm; btm = now_; } while (0)
+#else
+#define SGS_BPROF(acc) do { } while (0)
+#endif
     __shared__ unsigned s_cnt[SGS_WT];
     __shared__ unsigned short s_list[SGS_WT];
     __shared__ unsigned s_nlist;
@@ -462,14 +509,21 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            SGS_BPROF(bt_find);
             if (w == 0) n_vis += lc.n_vis;
-            bin_walk(P, splats, vismask, lc, wr0, wr1,
+            bin_walk(P, splats, vismask, bigmask, lc, wr0, wr1,
                      [&](bool valid, unsigned tl, unsigned, unsigned) {
                          if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
                              s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
                      });
             __syncthreads();
+            SGS_BPROF(bt_walk);
         }
+        bin_walk_big(P, splats, big_list, st->n_big, wr0, wr1,
+                     [&](bool, unsigned tl, unsigned, unsigned) {
+                         if (atomicAdd(&s_cnt[tl], 1u) == 0u) s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
+                     });
+        __syncthreads();
         // flush: one device-scope atomic per touched tile; its return value is our base in the sub-queue
         const unsigned nl = s_nlist;
         uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
@@ -486,12 +540,21 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
             if (w == 0 && n_vis) atomicAdd(&st->n_visible, n_vis);    // one per workgroup
         }
         __syncthreads();
+        SGS_BPROF(bt_flush);
     }
+#ifdef SGS_TILE_PROF
+    if (tid == 0 && prof) {
+        unsigned long long* o = prof + (size_t)blockIdx.x * 8;
+        o[0] = lc.n; o[1] = bt_find; o[2] = bt_walk; o[3] = bt_flush; o[4] = s_nlist; o[5] = n_vis; o[6] = clock64() - bt0; o[7] = bt0;
+    }
+#endif
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams P,
                                                               const Splat* __restrict__ splats,
                                                               const unsigned long long* __restrict__ vismask,
+                                                              const unsigned long long* __restrict__ bigmask,
+                                                              const unsigned* __restrict__ big_list,
                                                               const unsigned* __restrict__ tile_offset,
                                                               const uint2* __restrict__ blk_list,
                                                               const unsigned* __restrict__ blk_len,
@@ -514,12 +577,17 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
-            bin_walk(P, splats, vismask, lc, wr0, wr1,
+            bin_walk(P, splats, vismask, bigmask, lc, wr0, wr1,
                      [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
                          if (valid) rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
                      });
             __syncthreads();
         }
+        bin_walk_big(P, splats, big_list, st->n_big, wr0, wr1,
+                     [&](bool, unsigned tl, unsigned okey, unsigned oslot) {
+                         rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
+                     });
+        __syncthreads();
     }
 }
 
