@@ -54,38 +54,6 @@ __device__ __forceinline__ unsigned wave_min(unsigned x) {
     return x;
 }
 
-// Balanced duplication: lane l owns `cnt` records laid out row-major over a rect of width w at
-// (x0,y0).  All 64 lanes then walk the wave's concatenated record list 64 at a time, so a Gaussian
-// covering 400 tiles costs the wave the same as 400 Gaussians covering one.  For every record the
-// callback gets (valid, tile index, p0/p1 of the owning lane).  Must be called wave-uniformly.
-template <class F>
-__device__ __forceinline__ void wave_expand(unsigned cnt, unsigned x0, unsigned y0, unsigned w,
-                                            unsigned p0, unsigned p1, int gx, int lane, F&& f) {
-    const unsigned incl = wave_incl_scan(cnt, lane);
-    const unsigned total = __shfl(incl, SGS_WAVE - 1);
-    const unsigned excl = incl - cnt;
-    const float rw = 1.0f / (float)(w ? w : 1u);
-    for (unsigned base = 0; base < total; base += SGS_WAVE) {
-        const unsigned k = base + (unsigned)lane;
-        unsigned lo = 0;                       // number of lanes whose inclusive sum is <= k
-#pragma unroll
-        for (int step = 32; step >= 1; step >>= 1) {
-            const unsigned v = __shfl(incl, (int)(lo + step - 1));
-            if (v <= k) lo += step;
-        }
-        const int o = (int)(lo & 63u);
-        const unsigned oe = __shfl(excl, o), ow = __shfl(w, o), ox = __shfl(x0, o), oy = __shfl(y0, o);
-        const unsigned op0 = __shfl(p0, o), op1 = __shfl(p1, o);
-        const float orw = __shfl(rw, o);
-        const bool valid = k < total;
-        const unsigned idx = k - oe;
-        // idx / ow without an integer divide: exact for idx < 2^21 (tests/test_kernel_logic.py)
-        const unsigned ty = (unsigned)(((float)idx + 0.5f) * orw);
-        const unsigned tx = idx - ty * ow;
-        f(valid, (oy + ty) * (unsigned)gx + ox + tx, op0, op1);
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
 // row (64 lanes x 16 B).  geom rows: (mx,my,mz,opacity) (sx,sy,sz,qw) (qx,qy,qz,0).
@@ -368,9 +336,10 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4 binning, part 1 (count) and part 2 (emit).  Both walk the compacted splats range by range
-// (workgroup b owns ranges b, b+B, b+2B, ...: a uniform sample of the scene, so the static split is
-// balanced) and expand every rect into its tiles with wave_expand().
+// S4 binning, part 1 (count) and part 2 (emit).  Both walk the live splats of the workgroup's ranges
+// (b, b+B, b+2B, ...: a uniform sample of the scene, so the static split is balanced) and expand every
+// rect into its tiles: one lane per splat for rects of <= SGS_BIG_RECT tiles, the whole workgroup per
+// splat for the few larger ones (k_preprocess's big list).
 //
 // Device-scope atomics on MI355X execute in the fabric and serialise per address (~12 ns each), so
 // one atomic per (splat, tile) record is hopeless for a tile that receives 20 k records.  Instead
@@ -417,10 +386,7 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
 }
 
 // Calls f(valid, local tile index, depth bits, slot) for every record of the listed chunks that falls
-// into tile rows [wr0, wr1).  Small rects (the common case: a splat touches ~7 tiles) are walked by their
-// own lane — a short divergent loop with no cross-lane traffic; only rects of more than SGS_SMALL_RECT
-// tiles go through the balanced wave-wide expansion, whose owner search is a chain of dependent shuffles.
-#define SGS_SMALL_RECT 16
+// into tile rows [wr0, wr1).
 template <class F>
 __device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
                                          const unsigned long long* __restrict__ vismask,
@@ -442,16 +408,15 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __re
             const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
             if (yb > ya) { y0 = (unsigned)(ya - wr0); cnt = w * (unsigned)(yb - ya); }
         }
-        const bool small = cnt <= SGS_SMALL_RECT;
-        if (small) {
-            unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
-            for (unsigned i = 0; i < cnt; ++i) {
-                f(true, row + tx, key, slot);
-                if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
-            }
+        // Every lane walks its own rect (<= SGS_BIG_RECT tiles; larger ones are on the big list, or — if that
+        // list overflowed — still here).  Neighbouring Gaussians have similar footprints, so the lanes of a
+        // wave run similar trip counts; a wave-wide balanced expansion (shuffle-based owner search) measured
+        // ~23 cycles per record against ~1 for this loop.
+        unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
+        for (unsigned i = 0; i < cnt; ++i) {
+            f(true, row + tx, key, slot);
+            if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
         }
-        const unsigned big = small ? 0u : cnt;
-        if (__ballot(big != 0u) != 0ull) wave_expand(big, x0, y0, w, key, slot, P.gx, lane, f);
     }
 }
 
@@ -473,7 +438,8 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const Splat* 
         const unsigned total = w * (unsigned)(yb - ya);
         const float rw = 1.0f / (float)w;
         for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
-            const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);      // k / w, exact (see wave_expand)
+            // k / w without an integer divide: exact for k < 2^21 (tests/test_emu_parity.py)
+            const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
             f(true, ((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), key, slot);
         }
     }
