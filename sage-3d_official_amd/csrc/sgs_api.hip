@@ -44,6 +44,7 @@ struct sgs_ctx {
     unsigned long long* vismask = nullptr;   // per 64-Gaussian chunk: which slots are live this frame
     unsigned long long* bigmask = nullptr;   //   ... and which of those went to the big-rect list
     unsigned* big_list = nullptr;
+    uint4* binrec = nullptr;                 // per slot: depth bits, rect01, rect23 (dense copy for the binning kernels)
     // per-tile scratch
     int tile_cap = 0;
     unsigned *tile_count = nullptr, *tile_offset = nullptr;
@@ -110,6 +111,7 @@ int ensure_splats(sgs_ctx* ctx, int64_t n) {
     if ((rc = grow(ctx, ctx->splats, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->vismask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->bigmask, (size_t)chunks)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->binrec, (size_t)cap)) != SGS_OK) return rc;
     if (!ctx->big_list && (rc = grow(ctx, ctx->big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->blk_len, (size_t)SGS_BIN_BLOCKS * (SGS_MAX_WINDOWS + 1))) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->bin_prof, (size_t)SGS_BIN_BLOCKS * 8)) != SGS_OK) return rc;
@@ -230,11 +232,11 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     const unsigned bin_blocks = (unsigned)std::min<int64_t>(SGS_BIN_BLOCKS, P.n_ranges);
     if (P.n_chunks > 0)
         hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
-                           scene->geom, scene->shq, ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, st);
+                           scene->geom, scene->shq, ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->binrec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
+        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->binrec,
                            ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_count, ctx->blk_list, ctx->blk_len, st,
                            ctx->bin_prof);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
@@ -242,7 +244,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->splats,
+        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, ctx->binrec,
                            ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_offset, ctx->blk_list, ctx->blk_len,
                            ctx->rec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
@@ -350,7 +352,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_count, ctx->tile_offset, ctx->tile_prof, ctx->bin_prof,
+    void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->binrec, ctx->tile_count, ctx->tile_offset, ctx->tile_prof, ctx->bin_prof,
                     ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->sorted_out, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);

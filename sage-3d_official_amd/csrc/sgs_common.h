@@ -18,7 +18,7 @@
 #define SGS_XCDS 8                  // sub-queues per tile: one per XCD the binning workgroups run on
 #define SGS_BIG_RECT 256            // splats touching more tiles than this are expanded by a whole workgroup
 #define SGS_BIG_CAP 65536           // entries of the per-frame big-splat list (overflow falls back to the wave path)
-#define SGS_MAX_LIVE 4096           // live chunks a binning workgroup can list (its share is n_chunks / SGS_BIN_BLOCKS)
+#define SGS_MAX_LIVE 2048           // live chunks a binning workgroup can list (its share is n_chunks / SGS_BIN_BLOCKS)
 
 // Radix sort (S5)
 #define SGS_RADIX_BITS 8

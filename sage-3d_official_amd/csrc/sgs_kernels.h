@@ -149,6 +149,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                                                  const float4* __restrict__ shq, Splat* __restrict__ splats,
                                                  unsigned long long* __restrict__ vismask,
                                                  unsigned long long* __restrict__ bigmask, unsigned* __restrict__ big_list,
+                                                 uint4* __restrict__ binrec,
                                                  FrameStatus* __restrict__ st, long long chunk, int lane) {
     const long long id = chunk * SGS_WAVE + lane;
 
@@ -258,6 +259,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         sp[0] = make_float4(sx, sy, ca, cb);
         sp[1] = make_float4(cc, g0.w, r, g);
         sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
+        // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
+        binrec[slot] = uint4{__float_as_uint(depth), rect01, rect23, 0u};
     }
 
 }
@@ -274,11 +277,12 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
                                                     unsigned long long* __restrict__ vismask,
                                                     unsigned long long* __restrict__ bigmask,
                                                     unsigned* __restrict__ big_list,
+                                                    uint4* __restrict__ binrec,
                                                     FrameStatus* __restrict__ st) {
     const int lane = threadIdx.x & 63;
     const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (chunk >= P.n_chunks) return;                       // wave-uniform
-    preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, st, chunk, lane);
+    preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, chunk, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -352,9 +356,10 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
 // visibility masks and appended to an LDS list — so that no wave ever waits on a mask load just to learn
 // that a chunk is culled.  Must be called by all threads; ends with a barrier.
 struct LiveChunks {
-    unsigned chunk[SGS_MAX_LIVE];       // chunk index
+    unsigned long long mask[SGS_MAX_LIVE];  // live, non-big lanes of the chunk
+    unsigned chunk[SGS_MAX_LIVE];           // chunk index
     unsigned n;
-    unsigned n_vis;                     // live splats (popcount of the masks)
+    unsigned n_vis;                         // live splats (popcount of the visibility masks)
 };
 // One sweep covers SGS_BIN_THREADS / 16 of the workgroup's ranges; a pass does at most
 // SGS_MAX_LIVE / SGS_BIN_THREADS sweeps, so the list cannot overflow however large the scene is.
@@ -365,6 +370,7 @@ __device__ __forceinline__ int bin_sweeps(const FrameParams& P) {
     return (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP;
 }
 __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const unsigned long long* __restrict__ vismask,
+                                                 const unsigned long long* __restrict__ bigmask,
                                                  LiveChunks& lc, int sweep0, int sweep1) {
     if (threadIdx.x == 0) { lc.n = 0; lc.n_vis = 0; }
     __syncthreads();
@@ -377,7 +383,11 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
             const unsigned long long vm = vismask[chunk];
             if (vm != 0ull) {
                 vis += (unsigned)__popcll(vm);
-                lc.chunk[atomicAdd(&lc.n, 1u)] = (unsigned)chunk;
+                const unsigned long long m = vm & ~bigmask[chunk];
+                if (m != 0ull) {
+                    const unsigned k = atomicAdd(&lc.n, 1u);
+                    lc.chunk[k] = (unsigned)chunk; lc.mask[k] = m;
+                }
             }
         }
     }
@@ -386,36 +396,44 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
 }
 
 // Calls f(valid, local tile index, depth bits, slot) for every record of the listed chunks that falls
-// into tile rows [wr0, wr1).
+// into tile rows [wr0, wr1).  A wave takes four chunks per trip so that four coalesced 1-KiB rows of
+// bin records are in flight at once (the walk is otherwise a chain of dependent round trips).
+// Every lane walks its own rect (<= SGS_BIG_RECT tiles; larger ones are on the big list, or — if that
+// list overflowed — still here).  Neighbouring Gaussians have similar footprints, so the lanes of a
+// wave run similar trip counts; a wave-wide balanced expansion (shuffle-based owner search) measured
+// ~23 cycles per record against ~1 for this loop.
 template <class F>
-__device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __restrict__ splats,
-                                         const unsigned long long* __restrict__ vismask,
-                                         const unsigned long long* __restrict__ bigmask, const LiveChunks& lc,
+__device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __restrict__ binrec, const LiveChunks& lc,
                                          int wr0, int wr1, F&& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
-    for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
-        const unsigned chunk = lc.chunk[k];
-        const unsigned long long vm = vismask[chunk] & ~bigmask[chunk];
-        const unsigned slot = chunk * SGS_WAVE + (unsigned)lane;
-        unsigned cnt = 0, x0 = 0, y0 = 0, w = 0, key = 0;
-        if ((vm >> lane) & 1ull) {
-            const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
-            key = __float_as_uint(c.y);
-            const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
-            x0 = r01 & 0xffffu;
-            w = (r23 & 0xffffu) - x0;
-            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-            if (yb > ya) { y0 = (unsigned)(ya - wr0); cnt = w * (unsigned)(yb - ya); }
+    for (unsigned k0 = (unsigned)wave * 4u; k0 < nlive; k0 += (unsigned)nwaves * 4u) {
+        uint4 br[4];
+        unsigned slot[4];
+        bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned k = k0 + (unsigned)u;
+            on[u] = false; slot[u] = 0; br[u] = uint4{0u, 0u, 0u, 0u};
+            if (k < nlive) {
+                slot[u] = lc.chunk[k] * SGS_WAVE + (unsigned)lane;
+                on[u] = (lc.mask[k] >> lane) & 1ull;
+                if (on[u]) br[u] = binrec[slot[u]];
+            }
         }
-        // Every lane walks its own rect (<= SGS_BIG_RECT tiles; larger ones are on the big list, or — if that
-        // list overflowed — still here).  Neighbouring Gaussians have similar footprints, so the lanes of a
-        // wave run similar trip counts; a wave-wide balanced expansion (shuffle-based owner search) measured
-        // ~23 cycles per record against ~1 for this loop.
-        unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
-        for (unsigned i = 0; i < cnt; ++i) {
-            f(true, row + tx, key, slot);
-            if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
+            const unsigned key = br[u].x, r01 = br[u].y, r23 = br[u].z;
+            const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
+            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+            if (yb <= ya) continue;
+            const unsigned cnt = w * (unsigned)(yb - ya);
+            unsigned tx = 0, row = (unsigned)(ya - wr0) * (unsigned)P.gx + x0;
+            for (unsigned i = 0; i < cnt; ++i) {
+                f(true, row + tx, key, slot[u]);
+                if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+            }
         }
     }
 }
@@ -423,15 +441,14 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const Splat* __re
 // The big-rect splats (k_preprocess's list), dealt round-robin to the workgroups; every thread of the
 // workgroup takes a share of each rect.  Same callback contract as bin_walk.
 template <class F>
-__device__ __forceinline__ void bin_walk_big(const FrameParams& P, const Splat* __restrict__ splats,
+__device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* __restrict__ binrec,
                                              const unsigned* __restrict__ big_list, unsigned n_big,
                                              int wr0, int wr1, F&& f) {
     n_big = min(n_big, (unsigned)SGS_BIG_CAP);
     for (unsigned i = blockIdx.x; i < n_big; i += gridDim.x) {
         const unsigned slot = big_list[i];
-        const float4 c = reinterpret_cast<const float4*>(splats + slot)[2];
-        const unsigned key = __float_as_uint(c.y);
-        const unsigned r01 = __float_as_uint(c.z), r23 = __float_as_uint(c.w);
+        const uint4 br = binrec[slot];
+        const unsigned key = br.x, r01 = br.y, r23 = br.z;
         const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
         const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
         if (yb <= ya) continue;                              // workgroup-uniform
@@ -446,7 +463,7 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const Splat* 
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
-                                                               const Splat* __restrict__ splats,
+                                                               const uint4* __restrict__ binrec,
                                                                const unsigned long long* __restrict__ vismask,
                                                                const unsigned long long* __restrict__ bigmask,
                                                                const unsigned* __restrict__ big_list,
@@ -474,10 +491,10 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         if (tid == 0) s_nlist = 0;
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
-            find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             SGS_BPROF(bt_find);
             if (w == 0) n_vis += lc.n_vis;
-            bin_walk(P, splats, vismask, bigmask, lc, wr0, wr1,
+            bin_walk(P, binrec, lc, wr0, wr1,
                      [&](bool valid, unsigned tl, unsigned, unsigned) {
                          if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
                              s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
             __syncthreads();
             SGS_BPROF(bt_walk);
         }
-        bin_walk_big(P, splats, big_list, st->n_big, wr0, wr1,
+        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
                      [&](bool, unsigned tl, unsigned, unsigned) {
                          if (atomicAdd(&s_cnt[tl], 1u) == 0u) s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
                      });
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams P,
-                                                              const Splat* __restrict__ splats,
+                                                              const uint4* __restrict__ binrec,
                                                               const unsigned long long* __restrict__ vismask,
                                                               const unsigned long long* __restrict__ bigmask,
                                                               const unsigned* __restrict__ big_list,
@@ -542,14 +559,14 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
         }
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
-            find_live_chunks(P, vismask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
-            bin_walk(P, splats, vismask, bigmask, lc, wr0, wr1,
+            find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            bin_walk(P, binrec, lc, wr0, wr1,
                      [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
                          if (valid) rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
                      });
             __syncthreads();
         }
-        bin_walk_big(P, splats, big_list, st->n_big, wr0, wr1,
+        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
                      [&](bool, unsigned tl, unsigned okey, unsigned oslot) {
                          rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
                      });
