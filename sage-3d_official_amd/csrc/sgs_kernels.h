@@ -395,9 +395,8 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     __syncthreads();
 }
 
-// Calls f(valid, local tile index, depth bits, slot) for every record of the listed chunks that falls
-// into tile rows [wr0, wr1).  A wave takes four chunks per trip so that four coalesced 1-KiB rows of
-// bin records are in flight at once (the walk is otherwise a chain of dependent round trips).
+// Calls f(tiles[4], how many of them are valid, depth bits, slot) for the records of the listed chunks that
+// fall into tile rows [wr0, wr1); tiles are local indices inside the window.
 // Every lane walks its own rect (<= SGS_BIG_RECT tiles; larger ones are on the big list, or — if that
 // list overflowed — still here).  Neighbouring Gaussians have similar footprints, so the lanes of a
 // wave run similar trip counts; a wave-wide balanced expansion (shuffle-based owner search) measured
@@ -407,33 +406,25 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
                                          int wr0, int wr1, F&& f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
-    for (unsigned k0 = (unsigned)wave * 4u; k0 < nlive; k0 += (unsigned)nwaves * 4u) {
-        uint4 br[4];
-        unsigned slot[4];
-        bool on[4];
+    for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
+        const unsigned slot = lc.chunk[k] * SGS_WAVE + (unsigned)lane;
+        if (!((lc.mask[k] >> lane) & 1ull)) continue;
+        const uint4 br = binrec[slot];
+        const unsigned key = br.x, r01 = br.y, r23 = br.z;
+        const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
+        const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+        if (yb <= ya) continue;
+        const unsigned cnt = w * (unsigned)(yb - ya);
+        // four tiles per trip: the callback's LDS atomics (returning ones in the emit) overlap
+        unsigned tx = 0, row = (unsigned)(ya - wr0) * (unsigned)P.gx + x0;
+        for (unsigned i = 0; i < cnt; i += 4) {
+            unsigned tl[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const unsigned k = k0 + (unsigned)u;
-            on[u] = false; slot[u] = 0; br[u] = uint4{0u, 0u, 0u, 0u};
-            if (k < nlive) {
-                slot[u] = lc.chunk[k] * SGS_WAVE + (unsigned)lane;
-                on[u] = (lc.mask[k] >> lane) & 1ull;
-                if (on[u]) br[u] = binrec[slot[u]];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!on[u]) continue;
-            const unsigned key = br[u].x, r01 = br[u].y, r23 = br[u].z;
-            const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
-            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-            if (yb <= ya) continue;
-            const unsigned cnt = w * (unsigned)(yb - ya);
-            unsigned tx = 0, row = (unsigned)(ya - wr0) * (unsigned)P.gx + x0;
-            for (unsigned i = 0; i < cnt; ++i) {
-                f(true, row + tx, key, slot[u]);
+            for (int u = 0; u < 4; ++u) {
+                tl[u] = row + tx;
                 if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
             }
+            f(tl, min(4u, cnt - i), key, slot);
         }
     }
 }
@@ -457,7 +448,8 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
         for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
             // k / w without an integer divide: exact for k < 2^21 (tests/test_emu_parity.py)
             const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
-            f(true, ((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), key, slot);
+            unsigned tl[4] = {((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), 0u, 0u, 0u};
+            f(tl, 1u, key, slot);
         }
     }
 }
@@ -495,17 +487,19 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
             SGS_BPROF(bt_find);
             if (w == 0) n_vis += lc.n_vis;
             bin_walk(P, binrec, lc, wr0, wr1,
-                     [&](bool valid, unsigned tl, unsigned, unsigned) {
-                         if (valid && atomicAdd(&s_cnt[tl], 1u) == 0u)
-                             s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
+                     [&](const unsigned* tl, unsigned nv, unsigned, unsigned) {
+#pragma unroll
+                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) atomicAdd(&s_cnt[tl[u]], 1u);   // fire and forget
                      });
             __syncthreads();
             SGS_BPROF(bt_walk);
         }
         bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
-                     [&](bool, unsigned tl, unsigned, unsigned) {
-                         if (atomicAdd(&s_cnt[tl], 1u) == 0u) s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)tl;
-                     });
+                     [&](const unsigned* tl, unsigned, unsigned, unsigned) { atomicAdd(&s_cnt[tl[0]], 1u); });
+        __syncthreads();
+        // the touched tiles, by one sweep over the window's counters (no returning atomic in the hot loop)
+        for (unsigned i = tid; i < (unsigned)SGS_WT; i += SGS_BIN_THREADS)
+            if (s_cnt[i] != 0u) s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)i;
         __syncthreads();
         // flush: one device-scope atomic per touched tile; its return value is our base in the sub-queue
         const unsigned nl = s_nlist;
@@ -561,14 +555,19 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             bin_walk(P, binrec, lc, wr0, wr1,
-                     [&](bool valid, unsigned tl, unsigned okey, unsigned oslot) {
-                         if (valid) rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
+                     [&](const unsigned* tl, unsigned nv, unsigned okey, unsigned oslot) {
+                         unsigned dst[4];
+#pragma unroll
+                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) dst[u] = atomicAdd(&s_next[tl[u]], 1u);
+                         const unsigned long long r = ((unsigned long long)okey << 32) | oslot;
+#pragma unroll
+                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) rec[dst[u]] = r;
                      });
             __syncthreads();
         }
         bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
-                     [&](bool, unsigned tl, unsigned okey, unsigned oslot) {
-                         rec[atomicAdd(&s_next[tl], 1u)] = ((unsigned long long)okey << 32) | oslot;
+                     [&](const unsigned* tl, unsigned, unsigned okey, unsigned oslot) {
+                         rec[atomicAdd(&s_next[tl[0]], 1u)] = ((unsigned long long)okey << 32) | oslot;
                      });
         __syncthreads();
     }
