@@ -395,36 +395,81 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     __syncthreads();
 }
 
-// Calls f(tiles[4], how many of them are valid, depth bits, slot) for the records of the listed chunks that
-// fall into tile rows [wr0, wr1); tiles are local indices inside the window.
-// Every lane walks its own rect (<= SGS_BIG_RECT tiles; larger ones are on the big list, or — if that
-// list overflowed — still here).  Neighbouring Gaussians have similar footprints, so the lanes of a
-// wave run similar trip counts; a wave-wide balanced expansion (shuffle-based owner search) measured
-// ~23 cycles per record against ~1 for this loop.
-template <class F>
+__device__ __forceinline__ unsigned wave_sum(unsigned x) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+
+// Bins the records of the listed chunks that fall into tile rows [wr0, wr1) of the current window.
+//   EMIT == false: s_arr = per-tile counters of the window (LDS); counts every record.
+//   EMIT == true : s_arr = per-tile write cursors (LDS); writes depth<<32|slot records to `rec`.
+// One wave per chunk.  Neighbouring Gaussians cover the same tiles, so the wave walks the UNION of its
+// lanes' rects tile by tile and ballots "who covers this tile": one LDS atomic per (wave, tile) adds
+// popc(ballot) — instead of one same-address atomic per record — and in the emit every covering lane
+// stores at base + (its rank in the ballot), i.e. the wave writes one contiguous run per tile.
+// A chunk whose lanes are far apart (union much larger than the records it holds) falls back to one
+// lane per rect.
+template <bool EMIT>
 __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __restrict__ binrec, const LiveChunks& lc,
-                                         int wr0, int wr1, F&& f) {
+                                         int wr0, int wr1, unsigned* s_arr, unsigned long long* __restrict__ rec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
     for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
         const unsigned slot = lc.chunk[k] * SGS_WAVE + (unsigned)lane;
-        if (!((lc.mask[k] >> lane) & 1ull)) continue;
-        const uint4 br = binrec[slot];
-        const unsigned key = br.x, r01 = br.y, r23 = br.z;
-        const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
-        const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-        if (yb <= ya) continue;
-        const unsigned cnt = w * (unsigned)(yb - ya);
-        // four tiles per trip: the callback's LDS atomics (returning ones in the emit) overlap
-        unsigned tx = 0, row = (unsigned)(ya - wr0) * (unsigned)P.gx + x0;
-        for (unsigned i = 0; i < cnt; i += 4) {
-            unsigned tl[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                tl[u] = row + tx;
-                if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+        unsigned key = 0, x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
+        if ((lc.mask[k] >> lane) & 1ull) {
+            const uint4 br = binrec[slot];
+            const int ya = max((int)(br.y >> 16), wr0), yb = min((int)(br.z >> 16), wr1);
+            if (yb > ya) {
+                key = br.x; x0 = br.y & 0xffffu; x1 = br.z & 0xffffu;
+                y0 = (unsigned)(ya - wr0); y1 = (unsigned)(yb - wr0);
             }
-            f(tl, min(4u, cnt - i), key, slot);
+        }
+        const bool on = y1 > y0;
+        const unsigned cnt = on ? (x1 - x0) * (y1 - y0) : 0u;
+        const unsigned long long r = ((unsigned long long)key << 32) | slot;
+        const unsigned ux0 = wave_min(x0), uy0 = wave_min(y0), ux1 = wave_max(x1), uy1 = wave_max(y1);
+        if (ux1 <= ux0 || uy1 <= uy0) continue;                              // nothing in this window
+        const unsigned area = (ux1 - ux0) * (uy1 - uy0), total = wave_sum(cnt);
+        if (area <= 2u * total + 32u) {
+            // tile-major: ballot the coverage of every tile of the union rect
+            for (unsigned ty = uy0; ty < uy1; ++ty) {
+                const bool row_on = on && ty >= y0 && ty < y1;
+                const unsigned row = ty * (unsigned)P.gx;
+                for (unsigned tx = ux0; tx < ux1; ++tx) {
+                    const unsigned long long m = __ballot(row_on && tx >= x0 && tx < x1);
+                    if (m == 0ull) continue;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (!EMIT) {
+                        if (lane == leader) atomicAdd(&s_arr[row + tx], (unsigned)__popcll(m));
+                    } else {
+                        unsigned base = 0;
+                        if (lane == leader) base = atomicAdd(&s_arr[row + tx], (unsigned)__popcll(m));
+                        base = __shfl(base, leader);
+                        if ((m >> lane) & 1ull) rec[base + (unsigned)__popcll(m & lanemask_lt(lane))] = r;
+                    }
+                }
+            }
+        } else if (on) {
+            // lane-major: every lane walks its own rect, four tiles per trip so the LDS atomics overlap
+            const unsigned w = x1 - x0;
+            unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
+            for (unsigned i = 0; i < cnt; i += 4) {
+                unsigned tl[4], dst[4];
+                const unsigned nv = min(4u, cnt - i);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    tl[u] = row + tx;
+                    if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
+                if (EMIT) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) rec[dst[u]] = r;
+                }
+            }
         }
     }
 }
@@ -486,11 +531,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
             find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             SGS_BPROF(bt_find);
             if (w == 0) n_vis += lc.n_vis;
-            bin_walk(P, binrec, lc, wr0, wr1,
-                     [&](const unsigned* tl, unsigned nv, unsigned, unsigned) {
-#pragma unroll
-                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) atomicAdd(&s_cnt[tl[u]], 1u);   // fire and forget
-                     });
+            bin_walk<false>(P, binrec, lc, wr0, wr1, s_cnt, nullptr);
             __syncthreads();
             SGS_BPROF(bt_walk);
         }
@@ -554,15 +595,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
-            bin_walk(P, binrec, lc, wr0, wr1,
-                     [&](const unsigned* tl, unsigned nv, unsigned okey, unsigned oslot) {
-                         unsigned dst[4];
-#pragma unroll
-                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) dst[u] = atomicAdd(&s_next[tl[u]], 1u);
-                         const unsigned long long r = ((unsigned long long)okey << 32) | oslot;
-#pragma unroll
-                         for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) rec[dst[u]] = r;
-                     });
+            bin_walk<true>(P, binrec, lc, wr0, wr1, s_next, rec);
             __syncthreads();
         }
         bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
