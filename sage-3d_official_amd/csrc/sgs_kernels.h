@@ -408,8 +408,8 @@ __device__ __forceinline__ unsigned wave_sum(unsigned x) {
 // lanes' rects tile by tile and ballots "who covers this tile": one LDS atomic per (wave, tile) adds
 // popc(ballot) — instead of one same-address atomic per record — and in the emit every covering lane
 // stores at base + (its rank in the ballot), i.e. the wave writes one contiguous run per tile.
-// A chunk whose lanes are far apart (union much larger than the records it holds) falls back to one
-// lane per rect.
+// Only chunks whose lanes overlap heavily take this path (near-camera surfaces: 64 splats over the same
+// ~150 tiles); the others walk one rect per lane.
 template <bool EMIT>
 __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __restrict__ binrec, const LiveChunks& lc,
                                          int wr0, int wr1, unsigned* s_arr, unsigned long long* __restrict__ rec) {
@@ -432,8 +432,9 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
         const unsigned ux0 = wave_min(x0), uy0 = wave_min(y0), ux1 = wave_max(x1), uy1 = wave_max(y1);
         if (ux1 <= ux0 || uy1 <= uy0) continue;                              // nothing in this window
         const unsigned area = (ux1 - ux0) * (uy1 - uy0), total = wave_sum(cnt);
-        if (area <= 2u * total + 32u) {
-            // tile-major: ballot the coverage of every tile of the union rect
+        if (area * 16u <= total) {
+            // tile-major pays ~30 cycles per union tile, lane-major ~(16 x multiplicity + 30) per four records:
+            // worth it only when the lanes overlap heavily (>= 16 records per tile of the union rect)
             for (unsigned ty = uy0; ty < uy1; ++ty) {
                 const bool row_on = on && ty >= y0 && ty < y1;
                 const unsigned row = ty * (unsigned)P.gx;
