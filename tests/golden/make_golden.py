@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures.  Run in THIS container only (it imports the reference).
+
+  pose_golden.json   — inputs/outputs of the reference's own importable pose functions
+                       (Code/data_pipeline/trajectory_generation/trajectory_2d_to_3d.py:
+                        quaternion_from_yaw :79, yaw_from_quaternion :66, transform_trajectory_points :124;
+                        Code/data_pipeline/training_data_construction/generate_actions.py:
+                        BatchActionGenerator.yaw_from_quaternion :117).  The reference holds no tests, so these
+                       are the only results of the reference itself that can be pinned for this path.
+  config1_golden.npz — a small BASELINE config-1 frame from the fp64 NumPy oracle (image, tile offsets,
+                       queue order, per-splat rects): pins the oracle against regressions and gives the GPU
+                       tests a fixture that does not depend on running the oracle.
+Only DATA is written; no reference source text is copied.
+"""
+import copy
+import json
+import math
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/Code"
+
+
+def pose_fixture():
+    sys.path.insert(0, os.path.join(REF, "data_pipeline", "trajectory_generation"))
+    sys.path.insert(0, os.path.join(REF, "data_pipeline", "training_data_construction"))
+    import trajectory_2d_to_3d as t23
+    rng = np.random.default_rng(42)
+    yaws = [0.0, 0.3, -0.3, 1.0, -2.5, 3.0, -3.1, math.pi / 2, -math.pi / 2] + list(rng.uniform(-math.pi, math.pi, 16))
+    cases = []
+    for yaw in yaws:
+        q = t23.quaternion_from_yaw(yaw)                      # the pre-transform quaternion (0,0,qz,qw)
+        pts = [{"position": [float(rng.uniform(0, 5)), float(rng.uniform(0, 5)), 0.0], "rotation": list(q)},
+               {"position": [1.0, 2.0, 0.0], "rotation": list(q)}]      # the LAST point's rotation is reset by the reference
+        before = copy.deepcopy(pts)
+        t23.transform_trajectory_points(pts, 0.0, 5.0, 0.0, 5.0)
+        cases.append({"yaw": float(yaw), "quaternion_from_yaw": [float(v) for v in q],
+                      "yaw_from_quaternion": float(t23.yaw_from_quaternion(*q)),
+                      "points_before": before, "points_after": pts})
+    # the action generator's decoder on the transformed rotations
+    try:
+        import generate_actions as ga
+        dec = ga.BatchActionGenerator.yaw_from_quaternion
+        for c in cases:
+            c["action_generator_yaw"] = float(dec(None, c["points_after"][0]["rotation"]))
+    except Exception as e:                                   # pragma: no cover
+        print("generate_actions not importable:", e)
+    json.dump({"source": "Galery23/SAGE-3D_Official @ /root/reference (functions named in make_golden.py)", "cases": cases},
+              open(os.path.join(HERE, "pose_golden.json"), "w"), indent=1)
+    print("pose_golden.json:", len(cases), "cases")
+
+
+def config1_fixture():
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_np as onp
+    scene, _ = onp.config1_scene(n=2500, seed=0)
+    cam = onp.Camera(128, 128, 64.0, 64.0, 64.0, 64.0, np.eye(4, dtype=np.float32))
+    img, aux = onp.render(*scene, cam)
+    pre = aux["pre"]
+    np.savez_compressed(os.path.join(HERE, "config1_golden.npz"),
+                        n=2500, seed=0, width=128, height=128, f=64.0,
+                        image=img.astype(np.float32), margin=aux["margin"].astype(np.float32),
+                        offsets=aux["offsets"].astype(np.int32), ids=aux["ids"].astype(np.int32),
+                        rect=pre["rect"].astype(np.int16), tiles=pre["tiles"].astype(np.int32),
+                        depth_bits=pre["depth"].view(np.uint32), n_contrib=aux["n_contrib"].astype(np.int32),
+                        n_visible=aux["n_visible"], D=aux["D"], D_f=aux["D_f"])
+    print("config1_golden.npz: D =", aux["D"], "D_f =", aux["D_f"])
+
+
+if __name__ == "__main__":
+    pose_fixture()
+    config1_fixture()

@@ -1,0 +1,105 @@
+"""Camera/pose conventions against golden vectors produced by the reference's own
+importable functions (tests/golden/make_golden.py -> pose_golden.json), and the oracle against its
+committed config-1 fixture."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_c
+import oracle_np as onp
+from sage_gs import camera
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def poses():
+    return json.load(open(os.path.join(GOLD, "pose_golden.json")))["cases"]
+
+
+def _wrap(a):
+    return (a + math.pi) % (2 * math.pi) - math.pi
+
+
+def test_rotation_encoding_matches_reference_transform(poses):
+    """trajectory_2d_to_3d.transform_trajectory_points: rotation = [-sin(psi/2),0,0,cos(psi/2)], psi = yaw+pi."""
+    for c in poses:
+        got = camera.rotation_from_yaw(c["yaw"])
+        assert np.allclose(got, c["points_after"][0]["rotation"], atol=1e-12), c["yaw"]
+        assert c["points_after"][-1]["rotation"] == [0.0, 0.0, 0.0, 1.0]      # the reference resets the last waypoint
+
+
+def test_yaw_decoding_matches_action_generator(poses):
+    """generate_actions.BatchActionGenerator.yaw_from_quaternion on the stored rotation."""
+    for c in poses:
+        rot = c["points_after"][0]["rotation"]
+        assert abs(camera.yaw_from_rotation(rot) - c["action_generator_yaw"]) < 1e-12
+        # and the environment's start heading (simple_env.py:1149-1182) undoes the +pi of the transform
+        assert abs(_wrap(camera.env_start_yaw(rot) - c["yaw"])) < 1e-9
+
+
+def test_view_matrix_of_datagen_pose(poses):
+    """generate_images.py:417-421 passes the stored 4-vector as Isaac's (w,x,y,z): a rotation about +Z by
+    psi + pi; the camera looks along R(q)(+X), eye height forced to 1.2 m."""
+    for c in poses:
+        pt = c["points_after"][0]
+        pos, orient = camera.datagen_pose(pt)
+        assert pos[2] == 1.2 and pos[:2] == pt["position"][:2]
+        V = camera.view_from_isaac_pose(pos, orient)
+        R = V[:3, :3]
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+        theta = c["action_generator_yaw"] + math.pi
+        fwd = np.array([math.cos(theta), math.sin(theta), 0.0])
+        assert np.allclose(R[2], fwd, atol=1e-9)                # camera +Z = heading
+        assert np.allclose(R[1], [0, 0, -1], atol=1e-12)        # camera +Y = world down (Z-up stage)
+        assert np.allclose(V @ np.array([*pos, 1.0]), [0, 0, 0, 1], atol=1e-12)
+        # a point one metre ahead lands on the optical axis, one metre deep
+        ahead = np.array(pos) + fwd
+        assert np.allclose(V @ np.array([*ahead, 1.0]), [0, 0, 1, 1], atol=1e-9)
+
+
+def test_env_orientation_restates_simple_env():
+    """simple_env.py:1208-1256: +sin(-22.5deg) on component 0, yaw delta composed above 0.01 rad."""
+    q = [0.3, 0.0, 0.0, 0.95]
+    base = camera.env_orientation(q)
+    assert np.allclose(base, [0.3 + math.sin(math.radians(-22.5)), 0.0, 0.0, 0.95])
+    assert camera.env_orientation(q, 1.0, 1.005) == base
+    d = 0.4
+    got = camera.env_orientation(q, 1.4, 1.0)
+    bx, bw = base[0], base[3]
+    assert np.allclose(got, [bx * math.cos(d / 2) - bw * math.sin(d / 2), 0.0, 0.0, bw * math.cos(d / 2) + bx * math.sin(d / 2)])
+
+
+def test_reference_intrinsics():
+    fx, fy, cx, cy = camera.reference_intrinsics(640, 480)         # simple_env.py:52 default resolution
+    assert abs(fx - 640 * 8.0 / 20.955) < 1e-9 and fx == fy and (cx, cy) == (320.0, 240.0)
+    assert abs(math.degrees(2 * math.atan(320 / fx)) - 105.3) < 0.1   # HFOV of the reference lens
+
+
+# ---- the oracle against its committed fixture ----------------------------------------------------------
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(GOLD, "config1_golden.npz"))
+
+
+@pytest.mark.parametrize("which", ["numpy", "c"])
+def test_oracle_reproduces_config1_golden(gold, which):
+    scene, _ = onp.config1_scene(n=int(gold["n"]), seed=int(gold["seed"]))
+    cam = onp.Camera(int(gold["width"]), int(gold["height"]), float(gold["f"]), float(gold["f"]), 64.0, 64.0,
+                     np.eye(4, dtype=np.float32))
+    if which == "numpy":
+        img, aux = onp.render(*scene, cam)
+        rect, tiles, depth = aux["pre"]["rect"], aux["pre"]["tiles"], aux["pre"]["depth"].view(np.uint32)
+        vis = aux["pre"]["visible"]
+    else:
+        img, aux = oracle_c.render(*scene, cam)
+        rect, tiles, depth = aux["rect"], aux["tiles"], aux["depth_bits"]
+        vis = tiles > 0
+    assert aux["D"] == int(gold["D"]) and aux["D_f"] == int(gold["D_f"]) and aux["n_visible"] == int(gold["n_visible"])
+    assert (aux["offsets"] == gold["offsets"]).all() and (aux["ids"] == gold["ids"]).all()
+    assert (tiles == gold["tiles"]).all() and (rect[vis] == gold["rect"][vis]).all() and (depth == gold["depth_bits"]).all()
+    assert (aux["n_contrib"] == gold["n_contrib"]).all()
+    assert np.abs(np.asarray(img, np.float64) - gold["image"]).max() < 1e-6

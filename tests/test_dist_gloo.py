@@ -1,0 +1,76 @@
+"""The N>1 path on CPU: world_size-2 (and 3) `gloo` runs of the tile-row partition + framebuffer gather
+(sage_gs/dist.py).  Each rank contributes the oracle's render of ITS band of tile rows; rank 0 must end up
+with the full frame, bit-identical to an un-sharded render (tiles are independent after binning)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sage_gs.dist import FrameGather, row_partition, shard_cameras
+
+
+def test_row_partition_covers_rows_once():
+    for rows, world in ((68, 1), (68, 2), (68, 4), (68, 8), (135, 8), (3, 8), (16, 16), (1, 4)):
+        bands = row_partition(rows, world)
+        assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == rows
+        per = -(-rows // world)
+        for r, (a, b) in enumerate(bands):
+            assert 0 <= b - a <= per and a == min(r * per, rows)
+            if r:
+                assert a == bands[r - 1][1]
+    assert [len(shard_cameras(10, r, 4)) for r in range(4)] == [3, 3, 2, 2]
+    assert sorted(i for r in range(4) for i in shard_cameras(10, r, 4)) == list(range(10))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, h, w, n, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "oracle"), os.path.join(root, "sage-3d_official_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_c
+    import oracle_np as onp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scene, _ = onp.config1_scene(n=n, seed=3)
+        cam = onp.Camera(w, h, 0.6 * w, 0.6 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+        g = FrameGather(h, w, torch.device("cpu"))
+        r0, r1 = g.band
+        g.slab.fill_(-7.0)                                   # garbage that must not survive in the frame
+        if r1 > r0:
+            band, _ = oracle_c.render(*scene, cam, None, r0, r1, threads=1, want="image")
+            y0, y1 = g.band_pixel_rows
+            g.slab[: y1 - y0] = torch.from_numpy(band[y0:y1])
+        frame = g.gather()
+        if rank == 0:
+            full, _ = oracle_c.render(*scene, cam, threads=1, want="image")
+            q.put(bool((frame.numpy() == full).all()) and tuple(frame.shape) == (h, w, 3))
+        else:
+            assert frame is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,res", [(2, (112, 160)), (3, (100, 72)), (2, (24, 40))])
+def test_tile_row_gather_gloo(world, res):
+    h, w = res
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, 1500, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True

@@ -77,3 +77,18 @@ def test_float_reciprocal_division_is_exact():
         rw = np.float32(1.0) / np.float32(w)
         q = ((idx.astype(np.float32) + np.float32(0.5)) * rw).astype(np.uint32)
         assert (q == idx // w).all(), w
+
+
+def test_against_committed_golden_fixture(drv):
+    """The kernels (under the emulator) against tests/golden/config1_golden.npz — no oracle run involved."""
+    import os
+    from conftest import assert_frame_close
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_golden.npz"))
+    scene, _ = onp.config1_scene(n=int(g["n"]), seed=int(g["seed"]))
+    cam = onp.Camera(int(g["width"]), int(g["height"]), float(g["f"]), float(g["f"]), 64.0, 64.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    img, st = drv.render(cam, full_sort=True)
+    off, ids, _, _ = drv.intermediates()
+    assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
+    assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
+    assert_frame_close(img, g["image"], g["margin"], cmax=2.5, what="golden config1")

@@ -190,6 +190,20 @@ def test_3m_scene_crop_vs_oracle(drv, big_scene):
     assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="3M scene band")
 
 
+def test_against_committed_golden_fixture(drv):
+    """The HIP path against tests/golden/config1_golden.npz — no oracle run involved."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config1_golden.npz"))
+    scene, _ = onp.config1_scene(n=int(g["n"]), seed=int(g["seed"]))
+    cam = onp.Camera(int(g["width"]), int(g["height"]), float(g["f"]), float(g["f"]), 64.0, 64.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    img, st = drv.render(cam, full_sort=True)
+    off, ids, _, _ = drv.intermediates()
+    assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
+    assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
+    assert_frame_close(img, g["image"], g["margin"], cmax=2.5, what="golden config1")
+
+
 def test_batch_equals_single_frames(drv):
     from sage_gs import Camera, scenes
     sc = scenes.make_room(60_000, seed=4)
