@@ -56,7 +56,8 @@ struct sgs_ctx {
     unsigned* blk_len = nullptr;
     // per-record scratch
     int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
-    unsigned long long *rec = nullptr, *alt = nullptr;   // queues of (depth bits << 32 | slot) records + partition space
+    unsigned long long *rec = nullptr;                   // tile queues of (depth bits << 32 | slot) records
+    unsigned long long *alt = nullptr, *part = nullptr;  // scratch of the HBM radix path (oversized depth buckets only)
     unsigned* sorted_out = nullptr;                      // SGS_FLAG_FULL_SORT (tests): fully ordered queues
     int64_t sorted_cap = 0;
     // status ring
@@ -147,6 +148,7 @@ int ensure_records(sgs_ctx* ctx) {
     int rc;
     if ((rc = grow(ctx, ctx->rec, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->alt, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->part, (size_t)cap)) != SGS_OK) return rc;
     ctx->rec_cap = cap;
     return SGS_OK;
 }
@@ -253,7 +255,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
         hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec,
-                           ctx->alt, ctx->sorted_out, ctx->splats, out_rgb, st, ctx->tile_prof);
+                           ctx->alt, ctx->part, ctx->sorted_out, ctx->splats, out_rgb, st, ctx->tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
@@ -353,7 +355,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->binrec, ctx->tile_count, ctx->tile_offset, ctx->tile_prof, ctx->bin_prof,
-                    ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->sorted_out, ctx->d_status};
+                    ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->part, ctx->sorted_out, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev) {

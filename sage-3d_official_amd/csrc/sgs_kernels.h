@@ -808,7 +808,8 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 
 __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
-                                                     unsigned long long* rec, unsigned long long* alt,
+                                                     const unsigned long long* __restrict__ rec,
+                                                     unsigned long long* alt, unsigned long long* part,
                                                      unsigned* sorted_out,
                                                      const Splat* __restrict__ splats,
                                                      float* __restrict__ out_rgb,
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
-    __shared__ unsigned s_wsum[4], s_wne[4];
+    __shared__ unsigned s_wsum[4], s_wne[4], s_fill;
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_used[4];
@@ -920,13 +921,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                         s_q[atomicAdd(&s_bcnt[bk], 1u)] = rq[r];
                     }
                 if (tid < 8) s_q[n + tid] = ~0ull;
-            } else {
-                for (unsigned i = tid; i < n; i += 256) {
-                    const unsigned long long x = rec[beg + i];
-                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
-                    alt[beg + atomicAdd(&s_bcnt[bk], 1u)] = x;
-                }
             }
+            // longer queues stay where they are: each group re-scans the queue and keeps its bucket range
+            // (coalesced, L2-friendly reads; a scatter of 8-byte records into HBM measured 8x write amplification)
         }
     }
     __syncthreads();
@@ -952,7 +949,25 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             const unsigned long long* kk = s_q + lo;       // in LDS already: sort the slice in place;
             if (!in_lds) {                                  // the records that follow it are deeper, so they
                 kk = s_q;                                   // act as the sentinels the 8-wide walk needs
-                for (unsigned i = tid; i < ((cnt + 7u) & ~7u); i += 256) s_q[i] = i < cnt ? alt[beg + lo + i] : ~0ull;
+                const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[e1];
+                if (tid == 0) s_fill = 0;
+                __syncthreads();
+                for (unsigned i0 = 0; i0 < n; i0 += 256) {          // uniform trip count: ballots inside
+                    const unsigned i = i0 + (unsigned)tid;
+                    unsigned long long x = 0ull;
+                    bool take = false;
+                    if (i < n) {
+                        x = rec[beg + i];
+                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                        take = bk >= b0 && bk <= b1;
+                    }
+                    const unsigned long long m = __ballot(take);
+                    unsigned base = 0;
+                    if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
+                    base = __shfl(base, 0);
+                    if (take) s_q[base + (unsigned)__popcll(m & lanemask_lt(lane))] = x;
+                }
+                if (tid < 8) s_q[cnt + tid] = ~0ull;
                 __syncthreads();
             }
             if (cnt <= 256) rank_sort<1>(kk, s_sorted, cnt);
@@ -965,18 +980,34 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 __syncthreads();         // s_sorted is rewritten by the next group when the blend is skipped
             }
         } else {
-            // One oversized bucket of a long queue: radix sort through HBM.  The segment's 8-byte records are
-            // split into a key half and a slot half inside the (now free) rec segment; the alt segment is
-            // the ping-pong space.
+            // One oversized bucket of a long queue: radix sort through HBM.  The bucket's records are filtered
+            // out of the queue and split into a key half and a slot half inside two scratch spans.
             const unsigned g0 = s_ne_bkt[e0], g1 = s_ne_bkt[e1];
             unsigned sub = (kbase + g0) << SGS_BUCKET_SHIFT;
             unsigned nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
             if (nbits >= 32u) { sub = 0u; nbits = 32u; }
-            unsigned* b_k = reinterpret_cast<unsigned*>(rec + beg + lo); unsigned* b_v = b_k + cnt;
-            unsigned* a_k = reinterpret_cast<unsigned*>(alt + beg + lo); unsigned* a_v = a_k + cnt;
-            for (unsigned i = tid; i < cnt; i += 256) {
-                const unsigned long long x = alt[beg + lo + i];
-                b_k[i] = (unsigned)(x >> 32); b_v[i] = (unsigned)x;
+            // alt[beg+lo, +cnt) and part[beg+lo, +cnt) are private to this bucket (cnt 8-byte slots = keys[cnt] | slots[cnt]).
+            unsigned* b_k = reinterpret_cast<unsigned*>(alt + beg + lo); unsigned* b_v = b_k + cnt;     // keys[cnt] | slots[cnt]
+            unsigned* a_k = reinterpret_cast<unsigned*>(part + beg + lo); unsigned* a_v = a_k + cnt;    // ping-pong space
+            if (tid == 0) s_fill = 0;
+            __syncthreads();
+            for (unsigned i0 = 0; i0 < n; i0 += 256) {
+                const unsigned i = i0 + (unsigned)tid;
+                unsigned long long x = 0ull;
+                bool take = false;
+                if (i < n) {
+                    x = rec[beg + i];
+                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                    take = bk >= g0 && bk <= g1;
+                }
+                const unsigned long long m = __ballot(take);
+                unsigned base = 0;
+                if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
+                base = __shfl(base, 0);
+                if (take) {
+                    const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt(lane));
+                    b_k[pos] = (unsigned)(x >> 32); b_v[pos] = (unsigned)x;
+                }
             }
             __syncthreads();
             sort_segment(b_k, b_v, a_k, a_v, cnt, sub, nbits, sh, splats, P.n, st);
