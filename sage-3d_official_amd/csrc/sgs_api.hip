@@ -47,7 +47,7 @@ struct sgs_ctx {
     uint4* binrec = nullptr;                 // per slot: depth bits, rect01, rect23 (dense copy for the binning kernels)
     // per-tile scratch
     int tile_cap = 0;
-    unsigned *tile_count = nullptr, *tile_offset = nullptr;
+    unsigned *tile_count = nullptr, *tile_offset = nullptr, *tile_order = nullptr;
     unsigned long long* tile_prof = nullptr;         // profiling build: 8 words per tile
     unsigned long long* bin_prof = nullptr;          // profiling build: 8 words per binning workgroup
     // binning scratch: per-workgroup (tile, base) lists
@@ -135,6 +135,7 @@ int ensure_tiles(sgs_ctx* ctx, int tiles) {
     if ((rc = grow(ctx, ctx->tile_count, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, ctx->tile_prof, (size_t)tiles * 8)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, ctx->tile_order, (size_t)tiles)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(ctx->tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
     ctx->tile_cap = tiles;
@@ -242,7 +243,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
                            ctx->vismask, ctx->bigmask, ctx->big_list, ctx->tile_count, ctx->blk_list, ctx->blk_len, st,
                            ctx->bin_prof);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, ctx->tile_count,
-                       ctx->tile_offset, st);
+                       ctx->tile_offset, ctx->tile_order, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
@@ -254,7 +255,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->rec,
+        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->tile_order, ctx->rec,
                            ctx->alt, ctx->part, ctx->sorted_out, ctx->splats, out_rgb, st, ctx->tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
@@ -354,7 +355,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->binrec, ctx->tile_count, ctx->tile_offset, ctx->tile_prof, ctx->bin_prof,
+    void* bufs[] = {ctx->splats, ctx->vismask, ctx->bigmask, ctx->big_list, ctx->binrec, ctx->tile_count, ctx->tile_offset, ctx->tile_order, ctx->tile_prof, ctx->bin_prof,
                     ctx->blk_list, ctx->blk_len, ctx->rec, ctx->alt, ctx->part, ctx->sorted_out, ctx->d_status};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -294,11 +294,16 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
                                                                 unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
+                                                                unsigned* __restrict__ tile_order,
                                                                 FrameStatus* __restrict__ st) {
     __shared__ unsigned s_wsum[2][SGS_SCAN_THREADS / SGS_WAVE];
     __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
+    __shared__ unsigned s_cls[33];                    // tiles per log2(queue length) class, then cursors
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int T = P.gx * P.gy;
+    const int t_lo = P.row_begin * P.gx, t_hi = P.row_end * P.gx;      // the tiles this call renders
+    if (tid < 33) s_cls[tid] = 0;
+    __syncthreads();
     unsigned carry = 0, mx = 0;
     // one tile per thread per round: 32-byte vector loads/stores, the eight sub-counts stay in registers
     for (int t0 = 0, rnd = 0; t0 < T; t0 += SGS_SCAN_THREADS, ++rnd) {
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
         }
         const unsigned c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
         mx = c > mx ? c : mx;
+        if (t >= t_lo && t < t_hi) atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u);
         const unsigned incl = wave_incl_scan(c, lane);
         if (lane == 63) s_wsum[rnd & 1][wave] = incl;
         __syncthreads();
@@ -329,6 +335,19 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     const unsigned wmx = wave_max(mx);
     if (lane == 0) s_wmax[wave] = wmx;
     __syncthreads();
+    // Render order: longest queues first (log2 classes).  k_tile_render's blocks are dispatched in index order
+    // and a long tile costs as much as the whole kernel's average share, so it must not start last.
+    if (tid == 0) {
+        unsigned run = 0;
+        for (int c = 32; c >= 0; --c) { const unsigned v = s_cls[c]; s_cls[c] = run; run += v; }
+    }
+    __syncthreads();
+    for (int t = t_lo + tid; t < t_hi; t += SGS_SCAN_THREADS) {
+        const unsigned b = tile_offset[(size_t)t * SGS_XCDS];
+        const unsigned e = (t + 1 < T) ? tile_offset[(size_t)(t + 1) * SGS_XCDS] : carry;
+        const unsigned c = e - b;
+        tile_order[atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u)] = (unsigned)t;
+    }
     if (tid == 0) {
         unsigned tmax = 0;
         for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) tmax = s_wmax[w] > tmax ? s_wmax[w] : tmax;
@@ -808,6 +827,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 
 __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
+                                                     const unsigned* __restrict__ tile_order,
                                                      const unsigned long long* __restrict__ rec,
                                                      unsigned long long* alt, unsigned long long* part,
                                                      unsigned* sorted_out,
@@ -839,13 +859,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #endif
     if (st->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware remap of the block index over this call's tiles
+    // blocks take the tiles longest queue first (k_tile_scan's order)
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
-    const unsigned per_xcd = (ntiles + 7u) / 8u;
-    const unsigned blk = blockIdx.x;
-    const unsigned t_local = (blk & 7u) * per_xcd + (blk >> 3);
-    if (t_local >= ntiles) return;       // workgroup-uniform
-    const unsigned tile = (unsigned)(P.row_begin * P.gx) + t_local;
+    if (blockIdx.x >= ntiles) return;    // workgroup-uniform
+    const unsigned tile = tile_order[blockIdx.x];
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
     const unsigned py = tile_y * 16u + (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
@@ -944,7 +961,137 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             e_next = e1 + 1;
         }
         const unsigned cnt = hi - lo;
-        const unsigned* gv;              // the group's slots in (depth, index) order
+        const unsigned* gv = nullptr;    // the group's slots in (depth, index) order
+        // Common case — the group is a single batch: every lane owns one record, issues the gather of ITS
+        // splat first, ranks its record against the group while the loads are in flight, and stores the
+        // splat at staging[rank].  No sorted index list, no exposed gather latency.
+        const bool direct = cnt <= SGS_BATCH && !tile_done && !full_sort;
+        if (direct) {
+            const unsigned long long* kk = s_q + lo;
+            if (!in_lds) {
+                kk = s_q;
+                const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[e1];
+                if (tid == 0) s_fill = 0;
+                __syncthreads();
+                for (unsigned i0 = 0; i0 < n; i0 += 256) {          // uniform trip count: ballots inside
+                    const unsigned i = i0 + (unsigned)tid;
+                    unsigned long long x = 0ull;
+                    bool take = false;
+                    if (i < n) {
+                        x = rec[beg + i];
+                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                        take = bk >= b0 && bk <= b1;
+                    }
+                    const unsigned long long m = __ballot(take);
+                    unsigned base = 0;
+                    if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
+                    base = __shfl(base, 0);
+                    if (take) s_q[base + (unsigned)__popcll(m & lanemask_lt(lane))] = x;
+                }
+                if (tid < 8) s_q[cnt + tid] = ~0ull;
+                __syncthreads();
+            }
+            const unsigned par = it & 1u;
+            const bool have = (unsigned)tid < cnt;
+            const unsigned long long mine = have ? kk[tid] : ~0ull;
+            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
+            if (have) {
+                const float4* sp = reinterpret_cast<const float4*>(splats + (unsigned)mine);
+                nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+            }
+            if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // 4 quadrants x 4 x 64 bits
+            unsigned rank = 0;
+            {
+                const unsigned cnt8 = (cnt + 7u) & ~7u;
+                for (unsigned j = 0; j < cnt8; j += 8) {
+                    unsigned long long x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = kk[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rank += x[u] < mine ? 1u : 0u;
+                }
+            }
+            __syncthreads();             // every lane has read its record: the staging arena may be written
+                                         // (s_q and the arena are distinct, but s_ball was just cleared)
+            if (tid == 0) {
+                s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
+                s_c[SGS_BATCH] = 0.f;
+            }
+            if (have) {
+                s_a[rank] = nA; s_b[rank] = nB; s_c[rank] = nC;
+                const float K = 2.0f * __logf(nB.y) + k_cut;
+                const float detq = nA.z * nB.x - nA.w * nA.w;
+                if (K > 0.0f) {
+                    float hx = 3.0e38f, hy = 3.0e38f;
+                    if (detq > 1.0e-12f * nA.z * nB.x) {
+                        const float inv = K / detq;
+                        hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
+                        hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
+                    }
+                    const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
+                    const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
+                    const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
+                    unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
+                    const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
+                    if (x_lo && y_lo) atomicOr(&bw[0 * 8 + word], bit);
+                    if (x_hi && y_lo) atomicOr(&bw[1 * 8 + word], bit);
+                    if (x_lo && y_hi) atomicOr(&bw[2 * 8 + word], bit);
+                    if (x_hi && y_hi) atomicOr(&bw[3 * 8 + word], bit);
+                }
+            }
+            __syncthreads();             // batch staged in depth order
+            SGS_PROF_MARK(pt_sort);
+#ifdef SGS_TILE_PROF
+            ++pn_groups; ++pn_batches;
+#endif
+            if (tid == 0) s_any[par ^ 1u] = 0;
+            const unsigned base = lo, m = cnt;
+            if (__ballot(live > 0.0f) != 0ull) {
+#define SGS_BLEND(J)                                                                                   \
+    {                                                                                                  \
+        const float4 A = s_a[J], B = s_b[J];                                                           \
+        const float cb_ = s_c[J];                                                                      \
+        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
+        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
+        float alpha = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);                        \
+        alpha = power <= 0.0f ? alpha : 0.0f;                                                          \
+        alpha = alpha >= amin ? alpha : 0.0f;                                                          \
+        alpha *= live;                                                                                 \
+        const float testT = T * (1.0f - alpha);                                                        \
+        const bool stop = testT < tmin;                                                                \
+        const float wgt = stop ? 0.0f : alpha * T;                                                     \
+        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;                                             \
+        T = stop ? T : testT;                                                                          \
+        used = stop ? base + (J) + 1u : used;                                                          \
+        live = stop ? 0.0f : live;                                                                     \
+    }
+                bool wave_done = false;
+                for (int gw = 0; gw < 4 && !wave_done; ++gw) {
+                    unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
+                    unsigned cn = 0;
+                    while (mask != 0ull) {
+                        const unsigned j0 = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
+                        mask &= mask - 1ull;
+                        const unsigned j1 = mask != 0ull ? (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1)
+                                                         : (unsigned)SGS_BATCH;
+                        mask &= mask - 1ull;
+                        SGS_BLEND(j0)
+                        SGS_BLEND(j1)
+                        if ((++cn & 3u) == 0u && __ballot(live > 0.0f) == 0ull) { wave_done = true; break; }
+                    }
+                }
+#undef SGS_BLEND
+                used = live > 0.0f ? base + m : used;
+            }
+            const bool still_live = __ballot(live > 0.0f) != 0ull;
+            if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
+            __syncthreads();
+            tile_done = s_any[par] == 0u;
+            ++it;
+            SGS_PROF_MARK(pt_blend);
+            lo = hi;
+            continue;
+        }
         if (cnt <= SGS_QCAP) {
             const unsigned long long* kk = s_q + lo;       // in LDS already: sort the slice in place;
             if (!in_lds) {                                  // the records that follow it are deeper, so they
