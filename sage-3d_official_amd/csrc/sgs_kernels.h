@@ -783,6 +783,54 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         if (tid + 256u * (unsigned)r < cnt) out_v[rank[r]] = (unsigned)mine[r];
 }
 
+// ---- the blend loop of k_tile_render -----------------------------------------------------------------
+// Walks this wave's splats of the staged batch (bit mask per gathering wave) four at a time: the four
+// alphas are independent (ILP hides the LDS and transcendental latency — a long tile's critical path is one
+// wave's dependent chain), then the short sequential part (T, colour, stop) is applied in depth order.
+// Predicates stay on the VALU (compare -> select): the scalar unit is shared by the CU's four SIMDs and
+// exec-mask algebra there was the bottleneck of an earlier version.  Lists shorter than a multiple of four
+// are padded with the zero-opacity dummy splat at index SGS_BATCH.
+#define SGS_ALPHA(J, A, B, AL)                                                                         \
+    const float4 A = s_a[J], B = s_b[J];                                                               \
+    float AL;                                                                                          \
+    {                                                                                                  \
+        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
+        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
+        AL = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);   /* min(amax, .) */            \
+        AL = power <= 0.0f ? AL : 0.0f;            /* S6: skip if power > 0 */                          \
+        AL = AL >= amin ? AL : 0.0f;               /* S6: skip if alpha < 1/255 */                      \
+    }
+#define SGS_APPLY(J, B, AL)                                                                            \
+    {                                                                                                  \
+        const float al = AL * live;                /* finished (or outside) pixels take nothing */      \
+        const float testT = T * (1.0f - al);                                                           \
+        const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
+        const float wgt = stop ? 0.0f : al * T;                                                        \
+        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * s_c[J];                                          \
+        T = stop ? T : testT;                                                                          \
+        used = stop ? base + (J) + 1u : used;                                                          \
+        live = stop ? 0.0f : live;                                                                     \
+    }
+#define SGS_NEXT_BIT(JV)                                                                               \
+    const unsigned JV = mask != 0ull ? gwb + (unsigned)(__ffsll((long long)mask) - 1) : (unsigned)SGS_BATCH; \
+    mask &= mask - 1ull;
+#define SGS_BLEND_WAVE()                                                                               \
+    if (__ballot(live > 0.0f) != 0ull) {                                                               \
+        bool wave_done = false;                                                                        \
+        for (int gw = 0; gw < 4 && !wave_done; ++gw) {                                                 \
+            unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);                              \
+            const unsigned gwb = (unsigned)gw * 64u;                                                   \
+            while (mask != 0ull) {                                                                     \
+                SGS_NEXT_BIT(j0) SGS_NEXT_BIT(j1) SGS_NEXT_BIT(j2) SGS_NEXT_BIT(j3)                    \
+                SGS_ALPHA(j0, A0, B0, al0) SGS_ALPHA(j1, A1, B1, al1)                                  \
+                SGS_ALPHA(j2, A2, B2, al2) SGS_ALPHA(j3, A3, B3, al3)                                  \
+                SGS_APPLY(j0, B0, al0) SGS_APPLY(j1, B1, al1) SGS_APPLY(j2, B2, al2) SGS_APPLY(j3, B3, al3) \
+                if (__ballot(live > 0.0f) == 0ull) { wave_done = true; break; }                        \
+            }                                                                                          \
+        }                                                                                              \
+        used = live > 0.0f ? base + m : used;     /* still live: the whole batch counts as examined */  \
+    }
+
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.
 //
@@ -1046,48 +1094,15 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #endif
             if (tid == 0) s_any[par ^ 1u] = 0;
             const unsigned base = lo, m = cnt;
-            if (__ballot(live > 0.0f) != 0ull) {
-#define SGS_BLEND(J)                                                                                   \
-    {                                                                                                  \
-        const float4 A = s_a[J], B = s_b[J];                                                           \
-        const float cb_ = s_c[J];                                                                      \
-        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
-        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
-        float alpha = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);                        \
-        alpha = power <= 0.0f ? alpha : 0.0f;                                                          \
-        alpha = alpha >= amin ? alpha : 0.0f;                                                          \
-        alpha *= live;                                                                                 \
-        const float testT = T * (1.0f - alpha);                                                        \
-        const bool stop = testT < tmin;                                                                \
-        const float wgt = stop ? 0.0f : alpha * T;                                                     \
-        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;                                             \
-        T = stop ? T : testT;                                                                          \
-        used = stop ? base + (J) + 1u : used;                                                          \
-        live = stop ? 0.0f : live;                                                                     \
-    }
-                bool wave_done = false;
-                for (int gw = 0; gw < 4 && !wave_done; ++gw) {
-                    unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
-                    unsigned cn = 0;
-                    while (mask != 0ull) {
-                        const unsigned j0 = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                        mask &= mask - 1ull;
-                        const unsigned j1 = mask != 0ull ? (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1)
-                                                         : (unsigned)SGS_BATCH;
-                        mask &= mask - 1ull;
-                        SGS_BLEND(j0)
-                        SGS_BLEND(j1)
-                        if ((++cn & 3u) == 0u && __ballot(live > 0.0f) == 0ull) { wave_done = true; break; }
-                    }
-                }
-#undef SGS_BLEND
-                used = live > 0.0f ? base + m : used;
-            }
+            SGS_BLEND_WAVE()
             const bool still_live = __ballot(live > 0.0f) != 0ull;
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
             tile_done = s_any[par] == 0u;
             ++it;
+            // a tile that keeps consuming batches is on the kernel's critical path: let its waves win the issue
+            // arbitration against the short-lived tiles they share the SIMDs with
+            if (it == 1) __builtin_amdgcn_s_setprio(1); else if (it == 2) __builtin_amdgcn_s_setprio(2); else if (it == 4) __builtin_amdgcn_s_setprio(3);
             SGS_PROF_MARK(pt_blend);
             lo = hi;
             continue;
@@ -1221,50 +1236,12 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
-                if (__ballot(live > 0.0f) != 0ull) {
-                    // Predicates stay on the VALU (compare -> select): the scalar unit is shared by the CU's
-                    // four SIMDs and exec-mask algebra there was the bottleneck of this loop.  Two splats per
-                    // trip; an odd tail pairs with the zero-opacity dummy at index SGS_BATCH.
-#define SGS_BLEND(J)                                                                                   \
-    {                                                                                                  \
-        const float4 A = s_a[J], B = s_b[J];                                                           \
-        const float cb_ = s_c[J];                                                                      \
-        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
-        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
-        float alpha = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);   /* min(amax, .) */   \
-        alpha = power <= 0.0f ? alpha : 0.0f;      /* S6: skip if power > 0 */                          \
-        alpha = alpha >= amin ? alpha : 0.0f;      /* S6: skip if alpha < 1/255 */                      \
-        alpha *= live;                             /* finished (or outside) pixels take nothing */      \
-        const float testT = T * (1.0f - alpha);                                                        \
-        const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
-        const float wgt = stop ? 0.0f : alpha * T;                                                     \
-        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * cb_;                                             \
-        T = stop ? T : testT;                                                                          \
-        used = stop ? base + (J) + 1u : used;                                                          \
-        live = stop ? 0.0f : live;                                                                     \
-    }
-                    bool wave_done = false;
-                    for (int gw = 0; gw < 4 && !wave_done; ++gw) {
-                        unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);
-                        unsigned cn = 0;
-                        while (mask != 0ull) {
-                            const unsigned j0 = (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1);
-                            mask &= mask - 1ull;
-                            const unsigned j1 = mask != 0ull ? (unsigned)gw * 64u + (unsigned)(__ffsll((long long)mask) - 1)
-                                                             : (unsigned)SGS_BATCH;
-                            mask &= mask - 1ull;
-                            SGS_BLEND(j0)
-                            SGS_BLEND(j1)
-                            if ((++cn & 3u) == 0u && __ballot(live > 0.0f) == 0ull) { wave_done = true; break; }
-                        }
-                    }
-#undef SGS_BLEND
-                    used = live > 0.0f ? base + m : used;     // still live: the whole batch counts as examined
-                }
+                SGS_BLEND_WAVE()
                 const bool still_live = __ballot(live > 0.0f) != 0ull;
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
+                if (it == 0) __builtin_amdgcn_s_setprio(1); else if (it == 1) __builtin_amdgcn_s_setprio(2); else if (it == 3) __builtin_amdgcn_s_setprio(3);
 #ifdef SGS_TILE_PROF
                 ++pn_batches;
 #endif

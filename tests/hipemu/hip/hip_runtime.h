@@ -226,6 +226,7 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
 static inline unsigned long long clock64() { return 0; }
+#define __builtin_amdgcn_s_setprio(p_) ((void)0)
 #define __builtin_amdgcn_s_getreg(reg_) (blockIdx.x & 7u)      /* emulated XCC id */
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
