@@ -84,11 +84,17 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # SGS_BENCH_SHARE_GPU=1 (debugging only): all ranks on cuda:0 under gloo, to exercise the N>1 code path on a 1-GPU box
+    share = os.environ.get("SGS_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- workload: deterministic synthetic scene + pose list (identical on every rank) ---------------
     scene = scenes.make_room(args.gaussians, seed=2)
@@ -138,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     avg = r.sync() if issued[0] else None                 # checks EVERY frame of the region for overflow
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

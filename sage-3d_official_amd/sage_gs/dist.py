@@ -70,7 +70,16 @@ class FrameGather:
     def gather(self) -> Optional[torch.Tensor]:
         """Collective.  Returns the assembled [H,W,C] frame on rank dst (a view, no copy), else None."""
         if self.world > 1:
-            dist.gather(self.slab, self._views if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            if self.slab.is_cuda and dist.get_backend(self.group) == "gloo":
+                # debugging aid (several ranks on one GPU under gloo): stage through the host
+                host = self.slab.cpu()
+                outs = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+                dist.gather(host, outs, dst=self.dst, group=self.group)
+                if self.rank == self.dst:
+                    for i, o in enumerate(outs):
+                        self._views[i].copy_(o)
+            else:
+                dist.gather(self.slab, self._views if self.rank == self.dst else None, dst=self.dst, group=self.group)
         if self.rank != self.dst:
             return None
         return self.padded.view(self.world * self.slab_rows, self.w, -1)[: self.h]
