@@ -196,7 +196,7 @@ def main():
             ach = stages[dom]["GBps"] or 0.0
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if world == 1 and os.path.exists(tpath):
                 try:
                     traffic = json.load(open(tpath)).get(dom)
                 except Exception:

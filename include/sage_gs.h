@@ -132,6 +132,14 @@ int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
                int tile_row_begin, int tile_row_end, float* out_rgb, sgs_stats* stats,
                void* hip_stream);
 
+/* As sgs_render, plus out_aux: a DEVICE buffer of height*width*2 floats — per pixel the expected view
+ * depth sum_i T_i alpha_i z_i (metres along the optical axis) and the coverage 1 - T_final.  This is the
+ * natural Gaussian-scene counterpart of the reference's depth channel, which renders the depth of the
+ * collision mesh instead (simple_env.py:1395-1589: get_depth, clipped to [0.1, 6.5] m). */
+int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
+                    int tile_row_begin, int tile_row_end, float* out_rgb, float* out_aux,
+                    sgs_stats* stats, void* hip_stream);
+
 /* B frames of one scene, back to back, one synchronisation at the end — the frame loop of
  * generate_images.py:408-436.  out_rgb holds B consecutive frames; stats (nullable) B entries. */
 int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,

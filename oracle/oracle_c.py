@@ -35,7 +35,7 @@ class OrcFrame(C.Structure):
                 ("ids", C.POINTER(C.c_int32)), ("consumed", C.POINTER(C.c_int64)),
                 ("image", C.POINTER(C.c_float)), ("final_T", C.POINTER(C.c_float)),
                 ("n_contrib", C.POINTER(C.c_int32)), ("width", C.c_int32), ("height", C.c_int32),
-                ("margin", C.POINTER(C.c_float))]
+                ("depth_img", C.POINTER(C.c_float)), ("margin", C.POINTER(C.c_float))]
 
 
 def build(force=False):
@@ -129,5 +129,7 @@ def render(means, scales, quats, opacities, sh, sh_degree, cam, cfg=None, tile_r
             ids=_np(f.ids, (int(f.D),), np.int32), consumed=_np(f.consumed, (T,), np.int64),
             final_T=_np(f.final_T, (H, W), np.float32), n_contrib=_np(f.n_contrib, (H, W), np.int32))
     aux["margin"] = _np(f.margin, (H, W), np.float32)
+    aux["depth_image"] = _np(f.depth_img, (H, W), np.float32)
+    aux["final_T"] = _np(f.final_T, (H, W), np.float32)
     lib.orc_frame_free(fp)
     return img, aux

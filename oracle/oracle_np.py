@@ -230,7 +230,8 @@ def bin_and_sort(pre, cam: Camera, tile_row_begin=0, tile_row_end=None):
 def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, tile_row_end=None):
     """S6 front-to-back alpha composite, fp64, tile by tile.
 
-    Returns dict(image[H,W,3], final_T[H,W], n_contrib[H,W] (index+1 of the last blended record),
+    Returns dict(image[H,W,3], final_T[H,W], depth_image[H,W] (sum T alpha z),
+    n_contrib[H,W] (index+1 of the last blended record),
     consumed[T] (records any pixel of the tile examined = the D_f term), margin[H,W]).
     `margin` is the smallest relative distance |alpha/alpha_min - 1| of any examined (pixel,
     Gaussian) pair to the alpha cut-off: fp32 and fp64 evaluations may legitimately decide
@@ -243,6 +244,7 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
         tile_row_end = gy
     H, W = cam.height, cam.width
     img = np.zeros((H, W, 3)); finT = np.ones((H, W)); ncon = np.zeros((H, W), np.int64)
+    zimg = np.zeros((H, W)); zs = pre["depth"].astype(np.float64)
     margin = np.full((H, W), np.inf)
     consumed = np.zeros(gx * gy, np.int64)
     xy = pre["xy"].astype(np.float64); con = pre["conic"].astype(np.float64)
@@ -254,7 +256,7 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
             ys = np.arange(ty * TILE, min((ty + 1) * TILE, H))
             xs = np.arange(tx * TILE, min((tx + 1) * TILE, W))
             PX, PY = np.meshgrid(xs.astype(np.float64), ys.astype(np.float64))
-            T = np.ones_like(PX); C = np.zeros(PX.shape + (3,))
+            T = np.ones_like(PX); C = np.zeros(PX.shape + (3,)); Z = np.zeros_like(PX)
             done = np.zeros(PX.shape, bool); nc = np.zeros(PX.shape, np.int64)
             mg = np.full(PX.shape, np.inf)
             q = ids[offsets[t]:offsets[t + 1]]
@@ -273,14 +275,15 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
                 stop = hit & (testT < cfg.t_min)
                 blend = hit & ~stop
                 C = np.where(blend[..., None], C + (alpha * T)[..., None] * rgb[g], C)
+                Z = np.where(blend, Z + alpha * T * zs[g], Z)
                 T = np.where(blend, testT, T)
                 nc = np.where(blend, k + 1, nc)
                 done |= stop
             consumed[t] = used
             sl = (slice(ys[0], ys[-1] + 1), slice(xs[0], xs[-1] + 1))
             img[sl] = C + T[..., None] * bg
-            finT[sl] = T; ncon[sl] = nc; margin[sl] = mg
-    return dict(image=img, final_T=finT, n_contrib=ncon, consumed=consumed, margin=margin)
+            finT[sl] = T; ncon[sl] = nc; margin[sl] = mg; zimg[sl] = Z
+    return dict(image=img, final_T=finT, n_contrib=ncon, consumed=consumed, margin=margin, depth_image=zimg)
 
 
 def render(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg: Config = None,

@@ -52,6 +52,7 @@ typedef struct {
     /* per pixel */
     float* image; float* final_T; int32_t* n_contrib;
     int32_t width, height;
+    float* depth_img;            /* per pixel: sum T alpha z */
     float* margin;               /* per pixel: min |alpha/alpha_min - 1| over examined pairs (checker build) */
 } orc_frame;
 
@@ -177,7 +178,7 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
     int64_t used_max = 0;
     for (int py = ty * TILE; py < (ty + 1) * TILE && py < f->height; ++py)
         for (int px = tx * TILE; px < (tx + 1) * TILE && px < f->width; ++px) {
-            real T = 1, C[3] = {0, 0, 0};
+            real T = 1, C[3] = {0, 0, 0}, Z = 0;
             int32_t nc = 0; int64_t k;
             double mg = 1e30;
             for (k = 0; k < n; ++k) {
@@ -197,6 +198,7 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
                 if (testT < (real)cfg->t_min) { ++k; break; }
                 real wgt = alpha * T;
                 C[0] += wgt * (real)f->rgb[3 * g]; C[1] += wgt * (real)f->rgb[3 * g + 1]; C[2] += wgt * (real)f->rgb[3 * g + 2];
+                { float zf; memcpy(&zf, &f->depth_bits[g], 4); Z += wgt * (real)zf; }
                 T = testT; nc = (int32_t)(k + 1);
             }
             if (k > used_max) used_max = k;
@@ -204,7 +206,7 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
             f->image[3 * p] = (float)(C[0] + T * (real)cfg->bg[0]);
             f->image[3 * p + 1] = (float)(C[1] + T * (real)cfg->bg[1]);
             f->image[3 * p + 2] = (float)(C[2] + T * (real)cfg->bg[2]);
-            f->final_T[p] = (float)T; f->n_contrib[p] = nc; f->margin[p] = (float)mg;
+            f->final_T[p] = (float)T; f->n_contrib[p] = nc; f->margin[p] = (float)mg; f->depth_img[p] = (float)Z;
         }
     f->consumed[t] = used_max;
 }
@@ -213,7 +215,7 @@ void orc_frame_free(orc_frame* f) {
     if (!f) return;
     free(f->depth_bits); free(f->rect); free(f->tiles); free(f->xy); free(f->conic); free(f->opacity);
     free(f->rgb); free(f->offsets); free(f->ids); free(f->consumed); free(f->image); free(f->final_T);
-    free(f->n_contrib); free(f->margin); free(f);
+    free(f->n_contrib); free(f->margin); free(f->depth_img); free(f);
 }
 
 int orc_real_bytes(void) { return (int)sizeof(real); }
@@ -246,7 +248,7 @@ orc_frame* orc_render(int64_t N, int sh_degree, const float* means, const float*
     f->depth_bits = calloc(n1, 4); f->rect = calloc(n1 * 4, 4); f->tiles = calloc(n1, 4);
     f->xy = calloc(n1 * 2, 4); f->conic = calloc(n1 * 3, 4); f->opacity = calloc(n1, 4); f->rgb = calloc(n1 * 3, 4);
     f->offsets = calloc(ntile + 1, 8); f->consumed = calloc(ntile, 8);
-    f->image = calloc(P * 3 + 1, 4); f->final_T = calloc(P + 1, 4); f->n_contrib = calloc(P + 1, 4); f->margin = calloc(P + 1, 4);
+    f->image = calloc(P * 3 + 1, 4); f->final_T = calloc(P + 1, 4); f->n_contrib = calloc(P + 1, 4); f->margin = calloc(P + 1, 4); f->depth_img = calloc(P + 1, 4);
     int K = (sh_degree + 1) * (sh_degree + 1);
     int deg = cfg->sh_degree < 0 ? sh_degree : (cfg->sh_degree < sh_degree ? cfg->sh_degree : sh_degree);
     const float* V = cam->view;

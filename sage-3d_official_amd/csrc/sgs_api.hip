@@ -207,7 +207,8 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const sgs_scene* scene, con
 
 // Enqueue one frame on `stream`; the frame's status lands in ring slot `slot`.
 int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg,
-                  int row_begin, int row_end, float* out_rgb, int slot, hipStream_t stream, bool timed) {
+                  int row_begin, int row_end, float* out_rgb, int slot, hipStream_t stream, bool timed,
+                  float* out_aux = nullptr) {
     int rc;
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE, gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
     if ((rc = ensure_splats(ctx, scene->n)) != SGS_OK) return rc;
@@ -255,8 +256,12 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        hipLaunchKernelGGL(sgs::k_tile_render, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->tile_order, ctx->rec,
-                           ctx->alt, ctx->part, ctx->sorted_out, ctx->splats, out_rgb, st, ctx->tile_prof);
+        if (out_aux)
+            hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->tile_order,
+                               ctx->rec, ctx->alt, ctx->part, ctx->sorted_out, ctx->splats, out_rgb, out_aux, st, ctx->tile_prof);
+        else
+            hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid), dim3(256), 0, stream, P, ctx->tile_offset, ctx->tile_order,
+                               ctx->rec, ctx->alt, ctx->part, ctx->sorted_out, ctx->splats, out_rgb, out_aux, st, ctx->tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
@@ -472,8 +477,9 @@ int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats) {
     return SGS_OK;
 }
 
-int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg_in,
-               int tile_row_begin, int tile_row_end, float* out_rgb, sgs_stats* stats, void* hip_stream) {
+int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg_in,
+                    int tile_row_begin, int tile_row_end, float* out_rgb, float* out_aux, sgs_stats* stats,
+                    void* hip_stream) {
     if (!ctx) return SGS_ERR_INVALID;
     int rc;
     if ((rc = validate(ctx, scene, cam, cfg_in, tile_row_begin, tile_row_end, out_rgb)) != SGS_OK) return rc;
@@ -491,7 +497,7 @@ int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
         ctx->next_slot = (ctx->next_slot + 1) % kStatusRing;
         if (ctx->pending_count == 0) ctx->pending_begin = slot;
         ctx->pending_count++;
-        if ((rc = enqueue_frame(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, timed)) != SGS_OK)
+        if ((rc = enqueue_frame(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, timed, out_aux)) != SGS_OK)
             return rc;
         if (cfg.flags & SGS_FLAG_ASYNC) return SGS_OK;
         rc = sgs_frame_sync(ctx, stats);
@@ -503,6 +509,11 @@ int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
         if ((rc = ensure_records(ctx)) != SGS_OK) return rc;
         if (++ctx->last_retries > 4) SGS_FAIL(ctx, SGS_ERR_OVERFLOW, "record capacity still too small after 4 retries");
     }
+}
+
+int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
+               int tile_row_begin, int tile_row_end, float* out_rgb, sgs_stats* stats, void* hip_stream) {
+    return sgs_render_rgbd(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, nullptr, stats, hip_stream);
 }
 
 int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,

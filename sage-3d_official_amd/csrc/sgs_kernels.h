@@ -807,6 +807,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
         const float wgt = stop ? 0.0f : al * T;                                                        \
         C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * s_c[J];                                          \
+        if (AUX) Dz += wgt * s_d[J];               /* expected depth (template instantiation only) */    \
         T = stop ? T : testT;                                                                          \
         used = stop ? base + (J) + 1u : used;                                                          \
         live = stop ? 0.0f : live;                                                                     \
@@ -873,6 +874,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
+template <bool AUX>
 __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      const unsigned* __restrict__ tile_offset,
                                                      const unsigned* __restrict__ tile_order,
@@ -881,6 +883,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      unsigned* sorted_out,
                                                      const Splat* __restrict__ splats,
                                                      float* __restrict__ out_rgb,
+                                                     float* __restrict__ out_aux,
                                                      FrameStatus* st, unsigned long long* prof) {
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     float* const s_c = reinterpret_cast<float*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
     __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
+    __shared__ float s_d[AUX ? SGS_BATCH + 1 : 1];    // AUX: view depth of the staged splats
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 
     const unsigned beg = tile_offset[(size_t)tile * SGS_XCDS];              // the tile's 8 per-XCD sub-queues are adjacent
     const unsigned n = tile_offset[(size_t)tile * SGS_XCDS + SGS_XCDS] - beg;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     float live = inside ? 1.0f : 0.0f;   // 1 while the pixel still accepts splats
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
@@ -1065,8 +1069,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
                 s_c[SGS_BATCH] = 0.f;
             }
+            if (AUX && tid == 0) s_d[SGS_BATCH] = 0.f;
             if (have) {
                 s_a[rank] = nA; s_b[rank] = nB; s_c[rank] = nC;
+                if (AUX) s_d[rank] = __uint_as_float((unsigned)(mine >> 32));
                 const float K = 2.0f * __logf(nB.y) + k_cut;
                 const float detq = nA.z * nB.x - nA.w * nA.w;
                 if (K > 0.0f) {
@@ -1188,10 +1194,12 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
-            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
+            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f, nD = 0.f;
             if ((unsigned)tid < min((unsigned)SGS_BATCH, cnt)) {
                 const float4* sp = reinterpret_cast<const float4*>(splats + gv[tid]);
-                nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+                nA = sp[0]; nB = sp[1];
+                const float4 c4 = sp[2];
+                nC = c4.x; nD = c4.y;                      // .y = fp32 view depth (the sort key's bits)
             }
             for (unsigned gb = 0; gb < cnt && !tile_done; gb += SGS_BATCH, ++it) {
                 const unsigned par = it & 1u;
@@ -1203,9 +1211,11 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 if (tid == 0) {                       // the zero-opacity dummy (the arena is shared with the sort scratch)
                     s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
                     s_c[SGS_BATCH] = 0.f;
+                    if (AUX) s_d[SGS_BATCH] = 0.f;
                 }
                 if (have) {
                     s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
+                    if (AUX) s_d[tid] = nD;
                     // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
                     const float K = 2.0f * __logf(nB.y) + k_cut;
                     const float detq = nA.z * nB.x - nA.w * nA.w;
@@ -1232,7 +1242,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 const unsigned ngb = gb + SGS_BATCH;
                 if (ngb < cnt && (unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb)) {
                     const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + tid]);
-                    nA = sp[0]; nB = sp[1]; nC = sp[2].x;
+                    nA = sp[0]; nB = sp[1];
+                    const float4 c4 = sp[2];
+                    nC = c4.x; nD = c4.y;
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
@@ -1260,6 +1272,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     if (inside) {
         float* o = out_rgb + ((size_t)py * P.width + px) * 3;
         o[0] = C0 + T * P.bg[0]; o[1] = C1 + T * P.bg[1]; o[2] = C2 + T * P.bg[2];
+        if (AUX) {                        // expected depth sum(T alpha z) and coverage 1 - T_final
+            float* a = out_aux + ((size_t)py * P.width + px) * 2;
+            a[0] = Dz; a[1] = 1.0f - T;
+        }
     }
     if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
         const unsigned wu = wave_max(inside ? used : 0u);

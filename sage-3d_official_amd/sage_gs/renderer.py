@@ -178,7 +178,8 @@ class Renderer:
     # -- frames -----------------------------------------------------------------------------------
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
-               tile_rows=None, timing=False, sync=True, full_sort=False) -> torch.Tensor:
+               tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
+               return_aux=False):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
@@ -207,6 +208,16 @@ class Renderer:
         flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
                 (_capi.FLAG_FULL_SORT if full_sort else 0)     # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
+        if return_aux or out_aux is not None:
+            # f-4: [H,W,2] = expected view depth sum(T alpha z), coverage 1 - T_final (full-frame buffers only)
+            if out_band is not None:
+                raise ValueError("aux output is not available together with out_band")
+            if out_aux is None:
+                out_aux = torch.zeros((camera.height, camera.width, 2), dtype=torch.float32, device=self.device)
+            self._lib.check(self._lib.sgs_render_rgbd(self._ctx, scene.handle, C.byref(cam), C.byref(cfg), r0, r1, ptr,
+                                                      out_aux.data_ptr(), C.byref(st), self._stream()), self._ctx)
+            self.last_stats = st.as_dict() if sync else None
+            return ret, out_aux
         self._lib.check(self._lib.sgs_render(self._ctx, scene.handle, C.byref(cam), C.byref(cfg), r0, r1,
                                              ptr, C.byref(st), self._stream()), self._ctx)
         self.last_stats = st.as_dict() if sync else None

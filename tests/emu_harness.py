@@ -86,6 +86,17 @@ class EmuRenderer:
                                            out.ctypes.data, C.byref(st), None), self.ctx)
         return out, st.as_dict()
 
+    def render_aux(self, cam, cfg=None):
+        c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
+                              np.asarray(cam.view, np.float32).reshape(4, 4).tolist())
+        k = self.lib.default_config()
+        out = np.zeros((cam.height, cam.width, 3), np.float32)
+        aux = np.zeros((cam.height, cam.width, 2), np.float32)
+        st = _capi.SgsStats()
+        self.lib.check(self.lib.sgs_render_rgbd(self.ctx, self.scene, C.byref(c), C.byref(k), 0, -1, out.ctypes.data,
+                                                aux.ctypes.data, C.byref(st), None), self.ctx)
+        return out, aux
+
     def set_record_capacity(self, n):
         self.lib.check(self.lib.sgs_set_record_capacity(self.ctx, int(n)), self.ctx)
 

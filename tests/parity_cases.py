@@ -225,6 +225,24 @@ def case_overflow_retry(drv):
     assert st2["retries"] == 0 and (img2 == img).all()
 
 
+def case_depth_aux(drv, n=1500, res=(96, 80)):
+    """f-4: expected view depth sum(T alpha z) and coverage 1 - T_final, against the oracle; the RGB of the
+    aux kernel instantiation must equal the RGB-only kernel's bit for bit."""
+    scene = random_scene(n, 55, 1, scale=(0.03, 0.3))
+    w, h = res
+    cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    rgb0, _ = drv.render(cam)
+    rgb, aux = drv.render_aux(cam)
+    assert (rgb == rgb0).all()
+    ref, o = oracle_c.render(*scene, cam)
+    safe = o["margin"] >= 1e-4
+    zmax = float(np.max(scene[0][:, 2]))
+    assert np.abs(aux[..., 0] - o["depth_image"])[safe].max() < 1e-3 * zmax
+    assert np.abs(aux[..., 1] - (1.0 - o["final_T"]))[safe].max() < 1e-3
+    assert np.abs(aux[..., 0] - o["depth_image"]).max() < zmax / 255.0 + 1e-3 * zmax
+
+
 def case_determinism(drv, n=4000):
     scene = random_scene(n, 31, 1, scale=(0.03, 0.3))
     cam = onp.Camera(176, 144, 120.0, 120.0, 88.0, 72.0, np.eye(4, dtype=np.float32))

@@ -57,6 +57,10 @@ def test_two_binning_windows(drv):
     pc.case_full_grid_splat(drv, res=(2064, 1040))
 
 
+def test_depth_and_coverage_outputs(drv):
+    pc.case_depth_aux(drv, n=1500, res=(96, 80))
+
+
 def test_determinism(drv):
     pc.case_determinism(drv, n=1500)
 

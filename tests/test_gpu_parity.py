@@ -40,6 +40,12 @@ class GpuDriver:
                             full_sort=full_sort)
         return img.cpu().numpy(), self.r.last_stats
 
+    def render_aux(self, cam, cfg=None):
+        from sage_gs import Camera
+        c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
+        img, aux = self.r.render(c, self.scene, return_aux=True)
+        return img.cpu().numpy(), aux.cpu().numpy()
+
     def intermediates(self):
         return self.r.intermediates()
 
@@ -102,6 +108,10 @@ def test_sort_classes(drv):
 def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(1920, 1080))
     pc.case_full_grid_splat(drv, res=(3840, 2160))
+
+
+def test_depth_and_coverage_outputs(drv):
+    pc.case_depth_aux(drv, n=20_000, res=(320, 240))
 
 
 def test_determinism(drv):
@@ -238,3 +248,66 @@ def test_render_function_surface():
     ocam = onp.Camera(256, 256, 128.0, 128.0, 128.0, 128.0, np.eye(4, dtype=np.float32))
     ref, aux = oracle_c.render(*sc.as_tuple(), ocam)
     assert_frame_close(img.cpu().numpy(), ref, aux["margin"], cmax=2.5, what="render()")
+
+
+# ---- "next" rows on the GPU ------------------------------------------------------------
+def test_ply_scene_renders_like_the_arrays(drv, tmp_path):
+    """f-1: a scene written to a standard 3DGS PLY and loaded back renders the same frame."""
+    from sage_gs import Camera, ply, scenes
+    sc = scenes.make_room(30_000, seed=6)
+    path = str(tmp_path / "room.ply")
+    ply.save_ply(path, *sc.as_tuple())
+    arrays = ply.load_ply(path)
+    cam = scenes.room_cameras(sc, 640, 480, n_positions=1, n_yaw=4, seed=6)[1]
+    a = drv.r.render(cam, scenes.to_gaussians(sc, "cuda:0"))
+    b = drv.r.render(cam, ply.to_gaussians(arrays, "cuda:0", sc.model_to_world))
+    assert float((a - b).abs().max()) < 2e-4          # log/exp and logit/sigmoid round trips of scale and opacity
+
+
+def test_gscamera_adapter_protocol(drv):
+    """f-3: the Isaac Camera protocol (set_world_pose / get_rgba / get_current_frame) over the renderer."""
+    from sage_gs import scenes
+    from sage_gs.adapter import GsCamera
+    from sage_gs import camera as cc
+    sc = scenes.make_room(30_000, seed=6)
+    scene = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    cam = GsCamera(drv.r, scene, prim_path="/World/NaVILACamera", frequency=30, resolution=(320, 240))
+    cam.initialize()
+    pos, orient = cc.datagen_pose({"position": [2.0, 2.5, 0.0], "rotation": cc.rotation_from_yaw(0.7)})
+    cam.set_world_pose(position=np.array(pos, np.float32), orientation=np.array(orient, np.float32))
+    p, o = cam.get_world_pose()
+    assert np.allclose(p, pos) and np.allclose(o, orient)
+    rgba = cam.get_rgba()
+    assert rgba.shape == (240, 320, 4) and rgba.dtype == np.uint8 and (rgba[..., 3] == 255).all() and rgba[..., :3].max() > 0
+    ref = drv.r.render(cc.reference_camera(320, 240, pos, orient), scene)
+    exp = (np.clip(ref.cpu().numpy(), 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert (rgba[..., :3] == exp).all()
+    frame = cam.get_current_frame()
+    assert (frame["rgba"] == rgba).all() and frame["distance_to_image_plane"].shape == (240, 320)
+    assert frame["distance_to_image_plane"].max() > 0.5
+    scene.free()
+
+
+def test_sweep_driver_writes_the_reference_layout(drv, tmp_path):
+    """f-2: action_groundtruth.json -> trajectory_<id>/<scene>_<traj>_<idx>.jpg + image_metadata.json."""
+    import json, os
+    from sage_gs import scenes, sweep
+    from sage_gs import camera as cc
+    sc = scenes.make_room(30_000, seed=6)
+    scene = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    pts = [{"point_id": i, "position": [1.5 + 0.2 * i, 2.0, 0.0], "rotation": cc.rotation_from_yaw(0.2 * i)} for i in range(5)]
+    gt = {"groundtruth_data": [{"trajectory_id": "3", "instruction_index": 0, "sampled_points": pts},
+                               {"trajectory_id": "3", "instruction_index": 1, "sampled_points": pts}]}
+    ap = tmp_path / "action_groundtruth.json"; ap.write_text(json.dumps(gt))
+    out = tmp_path / "images"
+    n = sweep.run(drv.r, scene, sweep.load_trajectories(str(ap)), "0007", str(out), resolution=(256, 192))
+    assert n == 5
+    files = sorted(os.listdir(out / "trajectory_3"))
+    assert files == [f"0007_3_{i:03d}.jpg" for i in range(5)]
+    meta = json.load(open(out / "image_metadata.json"))
+    assert meta["scene_id"] == "0007" and meta["image_resolution"] == [256, 192] and meta["camera_settings"] == {"focal_length": 8.0, "height": 1.2}
+    assert meta["sequences"][0]["frame_filenames"] == files and len(meta["sequences"][0]["trajectory_sampled_points"]) == 5
+    from PIL import Image
+    im = np.asarray(Image.open(out / "trajectory_3" / files[2]))
+    assert im.shape == (192, 256, 3) and im.max() > 0
+    scene.free()
