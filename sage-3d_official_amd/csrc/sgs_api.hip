@@ -12,6 +12,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/sage_gs.h"
 #include "sgs_kernels.h"
@@ -33,6 +35,7 @@ struct sgs_scene {
     int sh_degree = 0, sh_rows = 0;
     float4* geom = nullptr;
     float4* shq = nullptr;
+    unsigned* perm_host = nullptr;      // Z-order: layout position -> original index (nullptr = identity)
 };
 
 struct sgs_ctx {
@@ -55,6 +58,8 @@ struct sgs_ctx {
     uint2* blk_list = nullptr;
     unsigned* blk_len = nullptr;
     // per-record scratch
+    bool morton = true;                      // Z-order the scene at upload (SGS_MORTON=0 disables)
+    const sgs_scene* last_scene = nullptr;
     int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
     unsigned long long *rec = nullptr;                   // tile queues of (depth bits << 32 | slot) records
     unsigned long long *alt = nullptr, *part = nullptr;  // scratch of the HBM radix path (oversized depth buckets only)
@@ -270,6 +275,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     ctx->last_slot = slot; ctx->last_timed = timed; ctx->last_stream = stream;
     ctx->last_n = scene->n; ctx->last_tiles = (int)ntiles; ctx->last_sh_rows = scene->sh_rows;
     ctx->last_T = gx * gy;
+    ctx->last_scene = scene;
     const int y0 = row_begin * SGS_TILE, y1 = std::min(row_end * SGS_TILE, cam->height);
     ctx->last_pixels = (int64_t)std::max(0, y1 - y0) * cam->width;
     return SGS_OK;
@@ -348,6 +354,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
+    if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
     if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
         const long long v = atoll(env);
         if (v > 0) ctx->rec_cap_wanted = v;
@@ -420,9 +427,58 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
             }
             dev[i] = staged[i];
         }
+        unsigned* d_perm = nullptr;
+        if (rc == SGS_OK && ctx->morton && n > SGS_WAVE) {
+            // Z-order (Morton) permutation of the means, computed on the host once per scene: 64 consecutive
+            // Gaussians then occupy a compact cell, so a chunk is visible or culled as a whole (no half-used SH
+            // cache lines in k_preprocess) and its splats overlap on screen (binning).
+            std::vector<float> hm((size_t)n * 3);
+            e = hipMemcpy(hm.data(), dev[0], (size_t)n * 12, on_device ? hipMemcpyDeviceToHost : hipMemcpyDeviceToHost);
+            if (e == hipSuccess) {
+                float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+                for (int64_t i = 0; i < n; ++i)
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = hm[(size_t)i * 3 + c];
+                        if (v == v) { lo[c] = std::min(lo[c], v); hi[c] = std::max(hi[c], v); }
+                    }
+                float inv[3];
+                for (int c = 0; c < 3; ++c) inv[c] = hi[c] > lo[c] ? 2097151.0f / (hi[c] - lo[c]) : 0.f;
+                auto spread = [](uint64_t v) {          // 21 bits -> every third bit
+                    v &= 0x1fffffull;
+                    v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+                    v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+                    v = (v | v << 2) & 0x1249249249249249ull;
+                    return v;
+                };
+                std::vector<std::pair<uint64_t, unsigned>> keys((size_t)n);
+                for (int64_t i = 0; i < n; ++i) {
+                    uint64_t q[3];
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = hm[(size_t)i * 3 + c];
+                        const float u = v == v ? (v - lo[c]) * inv[c] : 0.f;
+                        q[c] = (uint64_t)std::min(2097151.0f, std::max(0.0f, u));
+                    }
+                    keys[(size_t)i] = {spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2, (unsigned)i};
+                }
+                std::sort(keys.begin(), keys.end());
+                sc->perm_host = (unsigned*)malloc((size_t)n * 4);
+                if (!sc->perm_host) { ctx->err = "sgs_scene_upload: out of host memory"; rc = SGS_ERR_OOM; }
+                else {
+                    for (int64_t i = 0; i < n; ++i) sc->perm_host[i] = keys[(size_t)i].second;
+                    if ((e = hipMalloc(reinterpret_cast<void**>(&d_perm), (size_t)n * 4)) != hipSuccess ||
+                        (e = hipMemcpy(d_perm, sc->perm_host, (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess) {
+                        ctx->err = std::string("sgs_scene_upload: permutation: ") + hipGetErrorString(e);
+                        rc = e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
+                    }
+                }
+            } else {
+                ctx->err = std::string("sgs_scene_upload: reading means: ") + hipGetErrorString(e);
+                rc = SGS_ERR_HIP;
+            }
+        }
         if (rc == SGS_OK) {
             const unsigned grid = (unsigned)((npad + 255) / 256);
-            hipLaunchKernelGGL(sgs::k_scene_layout, dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows,
+            hipLaunchKernelGGL(sgs::k_scene_layout, dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows, d_perm,
                                dev[0], dev[1], dev[2], dev[3], dev[4], sc->geom, sc->shq);
             if ((e = hipDeviceSynchronize()) != hipSuccess) {
                 ctx->err = std::string("sgs_scene_upload: k_scene_layout: ") + hipGetErrorString(e);
@@ -430,6 +486,7 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
             }
         }
         for (float* p : staged) if (p) (void)hipFree(p);
+        if (d_perm) (void)hipFree(d_perm);
         if (rc != SGS_OK) return bail(rc);
     }
     *out = sc;
@@ -441,6 +498,8 @@ int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene) {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); }
     if (scene->geom) (void)hipFree(scene->geom);
     if (scene->shq) (void)hipFree(scene->shq);
+    if (scene->perm_host) free(scene->perm_host);
+    if (ctx && ctx->last_scene == scene) ctx->last_scene = nullptr;
     delete scene;
     return SGS_OK;
 }
@@ -606,10 +665,14 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         hipError_t e = hipMemcpy(vm, ctx->vismask, (size_t)n_chunks * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { free(vm); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
         char* dst = (char*)host_dst;
+        // vismask is indexed by layout position; slots by original index
+        const unsigned* perm = ctx->last_scene ? ctx->last_scene->perm_host : nullptr;
+        std::vector<unsigned char> live((size_t)n_slots, 0);
+        for (int64_t p = 0; p < ctx->last_n; ++p)
+            if ((vm[p >> 6] >> (p & 63)) & 1ull) live[perm ? perm[p] : (size_t)p] = 1;
         for (int64_t i = 0; i < n_slots && (i + 1) * elem <= n; ++i) {
-            const bool live = (vm[i >> 6] >> (i & 63)) & 1ull;
-            if (what == SGS_BUF_SLOT_IDS) ((unsigned*)dst)[i] = live ? (unsigned)i : 0xFFFFFFFFu;
-            else if (!live) memset(dst + i * elem, 0, (size_t)elem);
+            if (what == SGS_BUF_SLOT_IDS) ((unsigned*)dst)[i] = live[(size_t)i] ? (unsigned)i : 0xFFFFFFFFu;
+            else if (!live[(size_t)i]) memset(dst + i * elem, 0, (size_t)elem);
         }
         free(vm);
     }

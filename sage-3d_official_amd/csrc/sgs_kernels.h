@@ -56,9 +56,10 @@ __device__ __forceinline__ unsigned wave_min(unsigned x) {
 
 // ------------------------------------------------------------------------------------------------
 // Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
-// row (64 lanes x 16 B).  geom rows: (mx,my,mz,opacity) (sx,sy,sz,qw) (qx,qy,qz,0).
+// row (64 lanes x 16 B).  geom rows: (mx,my,mz,opacity) (sx,sy,sz,qw) (qx,qy,qz,original index).
 // sh rows: the (deg+1)^2*3 floats of a Gaussian, 4 per row, zero padded.
 __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floats, int sh_rows,
+                                                      const unsigned* __restrict__ perm,
                                                       const float* __restrict__ means,
                                                       const float* __restrict__ scales,
                                                       const float* __restrict__ quats,
@@ -66,17 +67,20 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
                                                       const float* __restrict__ sh,
                                                       float4* __restrict__ geom,
                                                       float4* __restrict__ shq) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // position in the laid-out scene
     const long long n_pad = ((n + SGS_WAVE - 1) / SGS_WAVE) * SGS_WAVE;
-    if (i >= n_pad) return;
-    const long long chunk = i >> 6;
-    const int lane = (int)(i & 63);
+    if (p >= n_pad) return;
+    const long long chunk = p >> 6;
+    const int lane = (int)(p & 63);
+    // position p holds Gaussian i = perm[p] (Z-order of the means; identity when perm == nullptr); the
+    // original index travels in the last word of the geometry rows: splats, records and depth ties use it.
+    const long long i = p < n ? (perm ? (long long)perm[p] : p) : -1;
     float4 g0 = make_float4(0.f, 0.f, -1.0e30f, 0.f), g1 = make_float4(1.f, 1.f, 1.f, 1.f),
            g2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n) {
+    if (i >= 0) {
         g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
         g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
-        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], 0.f);
+        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)i));
     }
     geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
     geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = 4 * r + c;
-            v[c] = (i < n && k < n_sh_floats) ? sh[i * n_sh_floats + k] : 0.f;
+            v[c] = (i >= 0 && k < n_sh_floats) ? sh[i * n_sh_floats + k] : 0.f;
         }
         shq[(chunk * sh_rows + r) * SGS_WAVE + lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -151,21 +155,22 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                                                  unsigned long long* __restrict__ bigmask, unsigned* __restrict__ big_list,
                                                  uint4* __restrict__ binrec,
                                                  FrameStatus* __restrict__ st, long long chunk, int lane) {
-    const long long id = chunk * SGS_WAVE + lane;
+    const long long pos = chunk * SGS_WAVE + lane;      // position in the (Z-ordered) scene layout
 
     const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
     const double mx = g0.x, my = g0.y, mz = g0.z;
     const double tx = (double)P.view[0] * mx + (double)P.view[1] * my + (double)P.view[2] * mz + (double)P.view[3];
     const double ty = (double)P.view[4] * mx + (double)P.view[5] * my + (double)P.view[6] * mz + (double)P.view[7];
     const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
-    const bool front = id < P.n && tz > (double)P.near_z && tz <= (double)P.far_z;
+    const bool front = tz > (double)P.near_z && tz <= (double)P.far_z;     // padding slots sit at z = -1e30
 
     bool vis = false, big = false;
-    unsigned rect01 = 0, rect23 = 0;
+    unsigned rect01 = 0, rect23 = 0, slot = 0;         // slot = the Gaussian's ORIGINAL index
     float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     if (front) {
         const float4 g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
         const float4 g2 = geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane];
+        slot = __float_as_uint(g2.w);
         // S2: Sigma = R S S^T R^T
         const double qw0 = g1.w, qx0 = g2.x, qy0 = g2.y, qz0 = g2.z;
         const double qn = sqrt(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
@@ -227,16 +232,15 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         }
     }
 
-    // No compaction: a splat lives at its Gaussian's index (slot == index), and the wave's ballot is
-    // the chunk's visibility mask.  Ties on depth can then break on the slot number itself.
+    // No compaction: a splat lives at its Gaussian's ORIGINAL index (slot), and the wave's ballot is the
+    // chunk's visibility mask.  Ties on depth can then break on the slot number itself.
     const unsigned long long vmask = __ballot(vis);
-    const unsigned slot = (unsigned)id;
     // A splat whose rect covers hundreds of tiles (a near-camera Gaussian) would keep ONE wave of the
     // binning kernels busy for its whole expansion; those few go to a global list instead and are
     // expanded by entire workgroups.  bigmask tells the per-chunk walk to skip them.
     if (big) {
         const unsigned k = atomicAdd(&st->n_big, 1u);
-        if (k < SGS_BIG_CAP) big_list[k] = slot; else big = false;
+        if (k < SGS_BIG_CAP) big_list[k] = (unsigned)pos; else big = false;
     }
     const unsigned long long bmask = __ballot(big);
     if (lane == 0) { vismask[chunk] = vmask; bigmask[chunk] = bmask; }
@@ -260,7 +264,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         sp[1] = make_float4(cc, g0.w, r, g);
         sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
-        binrec[slot] = uint4{__float_as_uint(depth), rect01, rect23, 0u};
+        binrec[pos] = uint4{__float_as_uint(depth), rect01, rect23, slot};
     }
 
 }
@@ -435,10 +439,10 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
     for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
-        const unsigned slot = lc.chunk[k] * SGS_WAVE + (unsigned)lane;
-        unsigned key = 0, x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
+        unsigned slot = 0, key = 0, x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
         if ((lc.mask[k] >> lane) & 1ull) {
-            const uint4 br = binrec[slot];
+            const uint4 br = binrec[lc.chunk[k] * SGS_WAVE + (unsigned)lane];
+            slot = br.w;
             const int ya = max((int)(br.y >> 16), wr0), yb = min((int)(br.z >> 16), wr1);
             if (yb > ya) {
                 key = br.x; x0 = br.y & 0xffffu; x1 = br.z & 0xffffu;
@@ -502,9 +506,8 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
                                              int wr0, int wr1, F&& f) {
     n_big = min(n_big, (unsigned)SGS_BIG_CAP);
     for (unsigned i = blockIdx.x; i < n_big; i += gridDim.x) {
-        const unsigned slot = big_list[i];
-        const uint4 br = binrec[slot];
-        const unsigned key = br.x, r01 = br.y, r23 = br.z;
+        const uint4 br = binrec[big_list[i]];
+        const unsigned key = br.x, r01 = br.y, r23 = br.z, slot = br.w;
         const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
         const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
         if (yb <= ya) continue;                              // workgroup-uniform
