@@ -58,7 +58,7 @@ struct sgs_ctx {
     uint2* blk_list = nullptr;
     unsigned* blk_len = nullptr;
     // per-record scratch
-    bool morton = true;                      // Z-order the scene at upload (SGS_MORTON=0 disables)
+    bool morton = false;                     // Z-order the scene at upload (SGS_MORTON=1): for scenes stored in no spatial order
     const sgs_scene* last_scene = nullptr;
     int64_t rec_cap = 0, rec_cap_wanted = 16ll << 20;
     unsigned long long *rec = nullptr;                   // tile queues of (depth bits << 32 | slot) records
