@@ -160,7 +160,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     const double tx = (double)P.view[0] * mx + (double)P.view[1] * my + (double)P.view[2] * mz + (double)P.view[3];
     const double ty = (double)P.view[4] * mx + (double)P.view[5] * my + (double)P.view[6] * mz + (double)P.view[7];
     const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
-    const bool front = tz > (double)P.near_z && tz <= (double)P.far_z;     // padding slots sit at z = -1e30
+    const bool front = pos < P.n && tz > (double)P.near_z && tz <= (double)P.far_z;   // pos >= n: padding of the last chunk
 
     bool vis = false, big = false;
     unsigned rect01 = 0, rect23 = 0, slot = 0;         // slot = the Gaussian's ORIGINAL index

@@ -103,6 +103,16 @@ def case_ragged(drv):
         check_against_oracle(drv, scene, cam, what=f"ragged n={n} {w}x{h}")
 
 
+def case_padding_lanes(drv):
+    """N not a multiple of 64 with a camera looking down -z: the padding lanes of the last chunk must stay
+    culled (their placeholder mean projects to a huge POSITIVE depth for such a view)."""
+    scene = random_scene(70, 77, 0, box=((-1, 1), (-1, 1), (-6, -2)), scale=(0.05, 0.3))
+    view = np.diag([-1.0, 1.0, -1.0, 1.0]).astype(np.float32)        # rotate pi about y: looks down -z
+    cam = onp.Camera(64, 64, 50.0, 50.0, 32.0, 32.0, view)
+    img, st, aux, _ = check_against_oracle(drv, scene, cam, what="padding lanes")
+    assert st["n_visible"] == aux["n_visible"] <= 70
+
+
 def case_empty(drv):
     empty = (np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32),
              np.zeros((0,), np.float32), np.zeros((0, 1, 3), np.float32), 0)

@@ -85,6 +85,10 @@ def test_ragged_sizes(drv):
     pc.case_ragged(drv)
 
 
+def test_padding_lanes_stay_culled(drv):
+    pc.case_padding_lanes(drv)
+
+
 def test_empty_and_all_culled(drv):
     pc.case_empty(drv)
 
