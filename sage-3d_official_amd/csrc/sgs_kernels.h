@@ -25,9 +25,9 @@ __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1u
 // The XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0).  Each tile queue has one sub-queue per XCD:
 // the records an XCD's workgroups emit into a queue are contiguous, so that XCD's L2 can write-combine
 // them (measured: emit write amplification 6x -> 2.7x).  A placement hint only — any value 0..7 is correct.
-// (An earlier version also bumped the sub-counters with XCD-local, workgroup-scope L2 atomics; a line
-// zeroed by k_tile_scan on another XCD could then be served stale from this XCD's L2 in the next frame —
-// caught by the batch == single-frame test — so the counters use ordinary device-scope atomics.)
+// (An earlier version also bumped the sub-counters with XCD-local, workgroup-scope L2 atomics; that bought
+// nothing measurable and leans on undocumented cross-kernel L2 behaviour, so the counters use ordinary
+// device-scope atomics.)
 __device__ __forceinline__ unsigned xcc_id() {
     return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & (SGS_XCDS - 1);
 }
@@ -785,52 +785,85 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 }
 
 // ---- the blend loop of k_tile_render -----------------------------------------------------------------
-// Walks this wave's splats of the staged batch (bit mask per gathering wave) four at a time: the four
-// alphas are independent (ILP hides the LDS and transcendental latency — a long tile's critical path is one
-// wave's dependent chain), then the short sequential part (T, colour, stop) is applied in depth order.
+// The staged batch is PAIR-INTERLEAVED in LDS: for splats 2p and 2p+1
+//     s_p0[p] = (x0, x1, y0, y1)   s_p1[p] = (ca0, ca1, cb0, cb1)   s_p2[p] = (cc0, cc1, o0, o1)
+// so one ds_read_b128 lands both splats' fields in adjacent registers and the alpha evaluation of the pair
+// runs on packed FP32 ops (v_pk_add/mul/fma_f32 — CDNA4 only reaches its FP32 rate with packed math; the
+// scalar version of this loop was 33 VALU + 15 SALU per splat).  Colours (and view depth) are per splat:
+// s_col[j] = (r, g, b, z).  A wave walks ITS pairs of the batch two pairs per trip: the four alphas are
+// independent (ILP hides the LDS and transcendental latency — a long tile's critical path is one wave's
+// dependent chain), then the short sequential part (T, colour, stop) is applied in depth order.
 // Predicates stay on the VALU (compare -> select): the scalar unit is shared by the CU's four SIMDs and
-// exec-mask algebra there was the bottleneck of an earlier version.  Lists shorter than a multiple of four
-// are padded with the zero-opacity dummy splat at index SGS_BATCH.
-#define SGS_ALPHA(J, A, B, AL)                                                                         \
-    const float4 A = s_a[J], B = s_b[J];                                                               \
-    float AL;                                                                                          \
+// exec-mask algebra there was the bottleneck of an earlier version.  Odd tails pair with the zero-opacity
+// dummy pair at index SGS_BATCH / 2.
+#ifdef SGS_HIPEMU
+typedef float sgs_v2f __attribute__((vector_size(8)));
+#else
+typedef float sgs_v2f __attribute__((ext_vector_type(2)));
+#endif
+#define SGS_ALPHA2(PI, AL)                                                                             \
+    sgs_v2f AL;                                                                                        \
     {                                                                                                  \
-        const float dx = A.x - fpx, dy = A.y - fpy;                                                    \
-        const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;                   \
-        AL = __builtin_amdgcn_fmed3f(B.y * __expf(power), 0.0f, amax);   /* min(amax, .) */            \
-        AL = power <= 0.0f ? AL : 0.0f;            /* S6: skip if power > 0 */                          \
-        AL = AL >= amin ? AL : 0.0f;               /* S6: skip if alpha < 1/255 */                      \
+        const float4 q0 = s_p0[PI], q1 = s_p1[PI], q2 = s_p2[PI];                                      \
+        const sgs_v2f X = {q0.x, q0.y}, Y = {q0.z, q0.w}, CA = {q1.x, q1.y}, CB = {q1.z, q1.w};        \
+        const sgs_v2f CC = {q2.x, q2.y}, O = {q2.z, q2.w};                                             \
+        const sgs_v2f dx = X - fpx2, dy = Y - fpy2;                                                    \
+        const sgs_v2f power = mhalf2 * (CA * dx * dx + CC * dy * dy) - CB * dx * dy;                   \
+        const sgs_v2f ex = {__expf(power[0]), __expf(power[1])};                                       \
+        const sgs_v2f oe = O * ex;                                                                     \
+        float a0 = __builtin_amdgcn_fmed3f(oe[0], 0.0f, amax), a1 = __builtin_amdgcn_fmed3f(oe[1], 0.0f, amax); \
+        a0 = power[0] <= 0.0f ? a0 : 0.0f; a1 = power[1] <= 0.0f ? a1 : 0.0f;   /* S6: skip if power > 0 */   \
+        a0 = a0 >= amin ? a0 : 0.0f; a1 = a1 >= amin ? a1 : 0.0f;               /* S6: skip if alpha < 1/255 */ \
+        AL[0] = a0; AL[1] = a1;                                                                        \
     }
-#define SGS_APPLY(J, B, AL)                                                                            \
+#define SGS_APPLY(J, ALV)                                                                              \
     {                                                                                                  \
-        const float al = AL * live;                /* finished (or outside) pixels take nothing */      \
+        const float4 col = s_col[J];                                                                   \
+        const float al = (ALV) * live;             /* finished (or outside) pixels take nothing */      \
         const float testT = T * (1.0f - al);                                                           \
         const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
         const float wgt = stop ? 0.0f : al * T;                                                        \
-        C0 += wgt * B.z; C1 += wgt * B.w; C2 += wgt * s_c[J];                                          \
-        if (AUX) Dz += wgt * s_d[J];               /* expected depth (template instantiation only) */    \
+        C0 += wgt * col.x; C1 += wgt * col.y; C2 += wgt * col.z;                                       \
+        if (AUX) Dz += wgt * col.w;                /* expected depth (template instantiation only) */    \
         T = stop ? T : testT;                                                                          \
         used = stop ? base + (J) + 1u : used;                                                          \
         live = stop ? 0.0f : live;                                                                     \
     }
-#define SGS_NEXT_BIT(JV)                                                                               \
-    const unsigned JV = mask != 0ull ? gwb + (unsigned)(__ffsll((long long)mask) - 1) : (unsigned)SGS_BATCH; \
-    mask &= mask - 1ull;
+#define SGS_NEXT_PAIR(PV)                                                                              \
+    const unsigned PV = pm != 0ull ? gwp + (unsigned)((__ffsll((long long)pm) - 1) >> 1) : (unsigned)(SGS_BATCH / 2); \
+    pm &= pm - 1ull;
 #define SGS_BLEND_WAVE()                                                                               \
     if (__ballot(live > 0.0f) != 0ull) {                                                               \
+        const sgs_v2f fpx2 = {fpx, fpx}, fpy2 = {fpy, fpy}, mhalf2 = {-0.5f, -0.5f};                   \
         bool wave_done = false;                                                                        \
         for (int gw = 0; gw < 4 && !wave_done; ++gw) {                                                 \
-            unsigned long long mask = uniform_u64(s_ball[par][wave][gw]);                              \
-            const unsigned gwb = (unsigned)gw * 64u;                                                   \
-            while (mask != 0ull) {                                                                     \
-                SGS_NEXT_BIT(j0) SGS_NEXT_BIT(j1) SGS_NEXT_BIT(j2) SGS_NEXT_BIT(j3)                    \
-                SGS_ALPHA(j0, A0, B0, al0) SGS_ALPHA(j1, A1, B1, al1)                                  \
-                SGS_ALPHA(j2, A2, B2, al2) SGS_ALPHA(j3, A3, B3, al3)                                  \
-                SGS_APPLY(j0, B0, al0) SGS_APPLY(j1, B1, al1) SGS_APPLY(j2, B2, al2) SGS_APPLY(j3, B3, al3) \
+            const unsigned long long m64 = uniform_u64(s_ball[par][wave][gw]);                         \
+            unsigned long long pm = (m64 | (m64 >> 1)) & 0x5555555555555555ull;   /* pairs with a splat of ours */ \
+            const unsigned gwp = (unsigned)gw * 32u;                                                   \
+            while (pm != 0ull) {                                                                       \
+                SGS_NEXT_PAIR(pa) SGS_NEXT_PAIR(pb)                                                    \
+                SGS_ALPHA2(pa, alA) SGS_ALPHA2(pb, alB)                                                \
+                SGS_APPLY(2u * pa, alA[0]) SGS_APPLY(2u * pa + 1u, alA[1])                             \
+                SGS_APPLY(2u * pb, alB[0]) SGS_APPLY(2u * pb + 1u, alB[1])                             \
                 if (__ballot(live > 0.0f) == 0ull) { wave_done = true; break; }                        \
             }                                                                                          \
         }                                                                                              \
         used = live > 0.0f ? base + m : used;     /* still live: the whole batch counts as examined */  \
+    }
+// staging helpers: write splat J (registers A = x,y,ca,cb  B = cc,o,r,g  c = b, z = view depth)
+#define SGS_STAGE(J, A, B, CBLUE, ZV)                                                                  \
+    {                                                                                                  \
+        float* w0 = reinterpret_cast<float*>(&s_p0[(J) >> 1]) + ((J) & 1u);                            \
+        float* w1 = reinterpret_cast<float*>(&s_p1[(J) >> 1]) + ((J) & 1u);                            \
+        float* w2 = reinterpret_cast<float*>(&s_p2[(J) >> 1]) + ((J) & 1u);                            \
+        w0[0] = A.x; w0[2] = A.y; w1[0] = A.z; w1[2] = A.w; w2[0] = B.x; w2[2] = B.y;                  \
+        s_col[J] = make_float4(B.z, B.w, CBLUE, ZV);                                                   \
+    }
+#define SGS_STAGE_DUMMY()                                                                              \
+    {                                                                                                  \
+        s_p0[SGS_BATCH / 2] = make_float4(0.f, 0.f, 0.f, 0.f); s_p1[SGS_BATCH / 2] = make_float4(1.f, 1.f, 0.f, 0.f); \
+        s_p2[SGS_BATCH / 2] = make_float4(1.f, 1.f, 0.f, 0.f);                                         \
+        s_col[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_col[SGS_BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f); \
     }
 
 // ------------------------------------------------------------------------------------------------
@@ -888,14 +921,14 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      FrameStatus* st, unsigned long long* prof) {
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
-    __shared__ float4 s_arena[2 * (SGS_BATCH + 1) + (SGS_BATCH + 4) / 4];
-    static_assert(sizeof(float4) * (2 * (SGS_BATCH + 1) + (SGS_BATCH + 4) / 4) >= sizeof(SortShared), "arena");
-    float4* const s_a = s_arena;                      // blend phase: the staged batch of splats (+1 dummy)
-    float4* const s_b = s_arena + (SGS_BATCH + 1);
-    float* const s_c = reinterpret_cast<float*>(s_arena + 2 * (SGS_BATCH + 1));
+    __shared__ float4 s_arena[3 * (SGS_BATCH / 2 + 1) + (SGS_BATCH + 2)];
+    static_assert(sizeof(float4) * (3 * (SGS_BATCH / 2 + 1) + (SGS_BATCH + 2)) >= sizeof(SortShared), "arena");
+    float4* const s_p0 = s_arena;                                     // blend phase: the staged batch, pair-interleaved
+    float4* const s_p1 = s_arena + (SGS_BATCH / 2 + 1);
+    float4* const s_p2 = s_arena + 2 * (SGS_BATCH / 2 + 1);
+    float4* const s_col = s_arena + 3 * (SGS_BATCH / 2 + 1);         // per splat: r, g, b, view depth (+2 dummies)
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
     __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
-    __shared__ float s_d[AUX ? SGS_BATCH + 1 : 1];    // AUX: view depth of the staged splats
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
@@ -1066,14 +1099,13 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             }
             __syncthreads();             // every lane has read its record: the staging arena may be written
                                          // (s_q and the arena are distinct, but s_ball was just cleared)
-            if (tid == 0) {
-                s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
-                s_c[SGS_BATCH] = 0.f;
+            if (tid == 0) SGS_STAGE_DUMMY()
+            if (tid == 1 && (cnt & 1u)) {         // odd batch: the last splat's pair partner is a zero-opacity blank
+                const float4 z4 = make_float4(0.f, 0.f, 1.f, 0.f), o4 = make_float4(1.f, 0.f, 0.f, 0.f);
+                SGS_STAGE(cnt, z4, o4, 0.f, 0.f)
             }
-            if (AUX && tid == 0) s_d[SGS_BATCH] = 0.f;
             if (have) {
-                s_a[rank] = nA; s_b[rank] = nB; s_c[rank] = nC;
-                if (AUX) s_d[rank] = __uint_as_float((unsigned)(mine >> 32));
+                SGS_STAGE(rank, nA, nB, nC, __uint_as_float((unsigned)(mine >> 32)))
                 const float K = 2.0f * __logf(nB.y) + k_cut;
                 const float detq = nA.z * nB.x - nA.w * nA.w;
                 if (K > 0.0f) {
@@ -1209,14 +1241,13 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 // stage the prefetched batch + per-quadrant overlap ballots
                 const bool have = (unsigned)tid < m;
                 unsigned qbits = 0;
-                if (tid == 0) {                       // the zero-opacity dummy (the arena is shared with the sort scratch)
-                    s_a[SGS_BATCH] = make_float4(0.f, 0.f, 1.f, 0.f); s_b[SGS_BATCH] = make_float4(1.f, 0.f, 0.f, 0.f);
-                    s_c[SGS_BATCH] = 0.f;
-                    if (AUX) s_d[SGS_BATCH] = 0.f;
+                if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
+                if (tid == 1 && (m & 1u)) {
+                    const float4 z4 = make_float4(0.f, 0.f, 1.f, 0.f), o4 = make_float4(1.f, 0.f, 0.f, 0.f);
+                    SGS_STAGE(m, z4, o4, 0.f, 0.f)
                 }
                 if (have) {
-                    s_a[tid] = nA; s_b[tid] = nB; s_c[tid] = nC;
-                    if (AUX) s_d[tid] = nD;
+                    SGS_STAGE((unsigned)tid, nA, nB, nC, nD)
                     // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
                     const float K = 2.0f * __logf(nB.y) + k_cut;
                     const float detq = nA.z * nB.x - nA.w * nA.w;
