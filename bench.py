@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
+                         "independent frames in flight on the library's internal streams)")
     return ap.parse_args()
 
 
@@ -105,7 +108,10 @@ def main():
     timing = not args.no_events
 
     sharded = ShardedRenderer(r, args.height, args.width) if (world > 1 and args.shard == "rows") else None
-    frame = torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device)
+    # frames of the sweep are independent: up to four are in flight, each with its own output buffer
+    pipelined = not args.no_pipeline and sharded is None
+    frames = [torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
+    frame = frames[0]
 
     issued = [0]
 
@@ -119,10 +125,10 @@ def main():
             sharded.g.gather()
         elif world > 1:                      # camera shards: rank renders every world-th frame of the sweep
             if i % world == rank:
-                r.render(cam, gs, out=frame, sync=False, timing=timed)
+                r.render(cam, gs, out=frames[issued[0] % len(frames)], sync=False, timing=timed, pipelined=pipelined)
                 issued[0] += 1
         else:
-            r.render(cam, gs, out=frame, sync=False, timing=timed)
+            r.render(cam, gs, out=frames[issued[0] % len(frames)], sync=False, timing=timed, pipelined=pipelined)
             issued[0] += 1
 
     def fence():
@@ -140,9 +146,9 @@ def main():
     t0 = time.perf_counter()
     for i in range(K):
         step(W + i, timing)
-    fence()
+    avg = r.sync() if issued[0] else None                 # completes the frames in flight (all lanes) and checks
+    fence()                                               # EVERY frame of the region for overflow
     elapsed = time.perf_counter() - t0
-    avg = r.sync() if issued[0] else None                 # checks EVERY frame of the region for overflow
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,6 +156,7 @@ def main():
 
     # ---- per-frame algorithmic bytes of the same K frames (deterministic; outside the timed region) --
     stage_bytes = {n: 0 for n in STAGE_NAMES}
+    iso_ms = {n: 0.0 for n in STAGE_NAMES}                 # the same launches one frame at a time (no overlap)
     counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
     if rank == 0:
         rows = None if sharded is None else sharded.g.band
@@ -158,10 +165,12 @@ def main():
                 continue
             cam = cams[(W + i) % len(cams)]
             if rows is None:
-                r.render(cam, gs, out=frame)
+                r.render(cam, gs, out=frame, timing=timing)
             else:
-                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=rows)
+                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=rows, timing=timing)
             st = r.last_stats
+            for n in STAGE_NAMES:
+                iso_ms[n] += st["ms"][n]
             for n in STAGE_NAMES:
                 stage_bytes[n] += st["bytes"][n]
             for k in ("n_visible", "d_total", "d_fetched"):
@@ -191,7 +200,8 @@ def main():
             stages = {}
             for n in STAGE_NAMES:
                 b = stage_bytes[n] / frames_here
-                stages[n] = {"ms": ms[n], "alg_bytes": b, "GBps": (b / (ms[n] * 1e-3) / 1e9) if ms[n] > 0 else None}
+                stages[n] = {"ms": ms[n], "alg_bytes": b, "GBps": (b / (ms[n] * 1e-3) / 1e9) if ms[n] > 0 else None,
+                             "ms_alone": iso_ms[n] / frames_here}
             dom = max(STAGE_NAMES, key=lambda n: ms[n])
             ach = stages[dom]["GBps"] or 0.0
             traffic = None
@@ -204,7 +214,11 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
-                               "stages": stages, "gpu_ms_per_frame": avg["ms_total"]}
+                               "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
+                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
+                               "note": "ms = HIP-event duration inside the timed region (frames overlap when "
+                                       "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
+                                       "with nothing else running"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[W:], args.cpu_seconds)
         print(json.dumps(out), flush=True)

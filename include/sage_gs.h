@@ -45,8 +45,14 @@ enum {
     SGS_FLAG_ASYNC  = 1u << 0,     /* do not synchronise the stream; collect with sgs_frame_sync() */
     SGS_FLAG_TIMING = 1u << 1,     /* bracket every stage with HIP events (fills sgs_stats.ms[]) */
     SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite) */
-    SGS_FLAG_FULL_SORT = 1u << 3   /* tests: order every queue completely (the production path sorts
+    SGS_FLAG_FULL_SORT = 1u << 3,  /* tests: order every queue completely (the production path sorts
                                       lazily and stops once a tile's pixels have all terminated) */
+    SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
+                                    * the library's internal streams (a few frames in flight, each with its own
+                                    * intermediates: one frame's binning fills the compute units another frame's
+                                    * composite leaves idle).  It starts after the work already submitted to `stream`;
+                                    * its output is complete — and ordered before later work — only after
+                                    * sgs_frame_sync().  sgs_render_batch() always works this way. */
 };
 
 /* Pipeline stages, in launch order (index of sgs_stats.ms[] / .bytes[]). */

@@ -995,8 +995,18 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     if ((unsigned)tid + 256u * (unsigned)r < n)
                         atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(rq[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
             } else {
-                for (unsigned i = tid; i < n; i += 256)
-                    atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(rec[beg + i] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                for (unsigned i0 = 0; i0 < n; i0 += 1024) {                 // four loads in flight per lane
+                    unsigned long long x[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                        x[r] = i < n ? rec[beg + i] : ~0ull;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (i0 + (unsigned)tid + 256u * (unsigned)r < n)
+                            atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(x[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                }
             }
             __syncthreads();
             {
@@ -1025,8 +1035,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     }
                 if (tid < 8) s_q[n + tid] = ~0ull;
             }
-            // longer queues stay where they are: each group re-scans the queue and keeps its bucket range
-            // (coalesced, L2-friendly reads; a scatter of 8-byte records into HBM measured 8x write amplification)
+            // longer queues stay where they are: s_q holds a WINDOW of whole buckets (<= SGS_QCAP records) that one
+            // coalesced re-scan of the queue fills, placing records with the bucket cursors; several groups are
+            // served from a window (a scatter of 8-byte records into HBM measured 8x write amplification)
         }
     }
     __syncthreads();
@@ -1038,45 +1049,50 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     unsigned it = 0;                     // batch counter (parity of the LDS flags)
     bool tile_done = false;
     unsigned e_next = 0, lo = 0;         // next non-empty bucket (index into s_ne_*) / its queue position
+    unsigned win_lo = 0, win_hi = in_lds ? n : 0u;   // queue range resident in s_q (the whole queue when it fits)
     while (lo < n && (!tile_done || full_sort)) {
         unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
         else {
             hi = s_ne_end[e1];
-            while (e1 + 1 < n_ne && s_ne_end[e1 + 1] - lo <= SGS_GROUP) { ++e1; hi = s_ne_end[e1]; }
+            // (a group that starts inside the resident window also ends inside it: buckets are placed once)
+            while (e1 + 1 < n_ne && s_ne_end[e1 + 1] - lo <= SGS_GROUP && (lo >= win_hi || s_ne_end[e1 + 1] <= win_hi)) {
+                ++e1; hi = s_ne_end[e1];
+            }
             e_next = e1 + 1;
         }
         const unsigned cnt = hi - lo;
         const unsigned* gv = nullptr;    // the group's slots in (depth, index) order
+        if (cnt <= SGS_QCAP && hi > win_hi) {
+            // long queue, group not resident: slide the window to start at this group and take as many whole
+            // buckets as fit.  Each bucket is placed exactly once, so the partition cursors stay valid.
+            unsigned ew = e1;
+            while (ew + 1 < n_ne && s_ne_end[ew + 1] - lo <= SGS_QCAP) ++ew;
+            const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[ew];
+            win_lo = lo; win_hi = s_ne_end[ew];
+            for (unsigned i0 = 0; i0 < n; i0 += 1024) {
+                unsigned long long x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                    x[r] = i < n ? rec[beg + i] : ~0ull;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && bk >= b0 && bk <= b1)
+                        s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
+                }
+            }
+            if (tid < 8) s_q[win_hi - win_lo + tid] = ~0ull;
+            __syncthreads();
+        }
         // Common case — the group is a single batch: every lane owns one record, issues the gather of ITS
         // splat first, ranks its record against the group while the loads are in flight, and stores the
         // splat at staging[rank].  No sorted index list, no exposed gather latency.
         const bool direct = cnt <= SGS_BATCH && !tile_done && !full_sort;
         if (direct) {
-            const unsigned long long* kk = s_q + lo;
-            if (!in_lds) {
-                kk = s_q;
-                const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[e1];
-                if (tid == 0) s_fill = 0;
-                __syncthreads();
-                for (unsigned i0 = 0; i0 < n; i0 += 256) {          // uniform trip count: ballots inside
-                    const unsigned i = i0 + (unsigned)tid;
-                    unsigned long long x = 0ull;
-                    bool take = false;
-                    if (i < n) {
-                        x = rec[beg + i];
-                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
-                        take = bk >= b0 && bk <= b1;
-                    }
-                    const unsigned long long m = __ballot(take);
-                    unsigned base = 0;
-                    if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
-                    base = __shfl(base, 0);
-                    if (take) s_q[base + (unsigned)__popcll(m & lanemask_lt(lane))] = x;
-                }
-                if (tid < 8) s_q[cnt + tid] = ~0ull;
-                __syncthreads();
-            }
+            const unsigned long long* kk = s_q + (lo - win_lo);
             const unsigned par = it & 1u;
             const bool have = (unsigned)tid < cnt;
             const unsigned long long mine = have ? kk[tid] : ~0ull;
@@ -1147,30 +1163,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             continue;
         }
         if (cnt <= SGS_QCAP) {
-            const unsigned long long* kk = s_q + lo;       // in LDS already: sort the slice in place;
-            if (!in_lds) {                                  // the records that follow it are deeper, so they
-                kk = s_q;                                   // act as the sentinels the 8-wide walk needs
-                const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[e1];
-                if (tid == 0) s_fill = 0;
-                __syncthreads();
-                for (unsigned i0 = 0; i0 < n; i0 += 256) {          // uniform trip count: ballots inside
-                    const unsigned i = i0 + (unsigned)tid;
-                    unsigned long long x = 0ull;
-                    bool take = false;
-                    if (i < n) {
-                        x = rec[beg + i];
-                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
-                        take = bk >= b0 && bk <= b1;
-                    }
-                    const unsigned long long m = __ballot(take);
-                    unsigned base = 0;
-                    if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
-                    base = __shfl(base, 0);
-                    if (take) s_q[base + (unsigned)__popcll(m & lanemask_lt(lane))] = x;
-                }
-                if (tid < 8) s_q[cnt + tid] = ~0ull;
-                __syncthreads();
-            }
+            const unsigned long long* kk = s_q + (lo - win_lo);   // resident: sort the slice in place; the records
+                                                                  // behind it are deeper (or ~0), the sentinels the 8-wide walk needs
             if (cnt <= 256) rank_sort<1>(kk, s_sorted, cnt);
             else if (cnt <= 512) rank_sort<2>(kk, s_sorted, cnt);
             else rank_sort<4>(kk, s_sorted, cnt);

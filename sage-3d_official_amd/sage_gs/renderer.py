@@ -179,13 +179,15 @@ class Renderer:
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
-               return_aux=False):
+               return_aux=False, pipelined=False):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
         of `out` are left untouched.  With `out_band` (a [>=band rows, W, 3] slab) only the band is
         stored, at the top of the slab, and the slab is returned.  sync=False enqueues on the current
-        stream without waiting (collect with .sync())."""
+        stream without waiting (collect with .sync()).  pipelined=True (with sync=False) lets the frame overlap
+        with other pipelined frames on the library's internal streams: for sweeps of independent frames; the
+        output is complete only after .sync()."""
         scene = self._scene_of(gaussians)
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
         if out_band is not None:
@@ -206,7 +208,8 @@ class Renderer:
                 raise ValueError("out must be a contiguous float32 [H,W,3] tensor on the renderer's device")
             ptr, ret = out.data_ptr(), out
         flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
-                (_capi.FLAG_FULL_SORT if full_sort else 0)     # full_sort: test hook, orders every queue completely
+                (_capi.FLAG_FULL_SORT if full_sort else 0) | \
+                (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         if return_aux or out_aux is not None:
             # f-4: [H,W,2] = expected view depth sum(T alpha z), coverage 1 - T_final (full-frame buffers only)

@@ -232,6 +232,35 @@ def test_batch_equals_single_frames(drv):
     scene.free()
 
 
+def test_pipelined_frames_equal_sequential_frames(drv):
+    """SGS_FLAG_PIPELINED: frames in flight on the library's lanes (own streams, own intermediates) must
+    produce exactly the frames that one-at-a-time rendering produces, also when ordinary frames are mixed in."""
+    import torch
+    from sage_gs import scenes
+    sc = scenes.make_room(150_000, seed=6)
+    cams = scenes.room_cameras(sc, 800, 608, n_positions=2, n_yaw=6, seed=6)
+    scene = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    seq = [drv.r.render(c, scene).clone() for c in cams]
+    outs = [torch.full((608, 800, 3), -1.0, device="cuda:0") for _ in cams]
+    for rep in range(2):                       # second round reuses lanes whose buffers are warm
+        for c, o in zip(cams, outs):
+            drv.r.render(c, scene, out=o, sync=False, pipelined=True)
+        st = drv.r.sync()
+        assert st["d_total"] > 0
+        for a, b in zip(seq, outs):
+            assert (a == b).all()
+        # an ordinary frame right after pipelined ones (lane 0 may still be busy when it is enqueued)
+        drv.r.render(cams[0], scene, out=outs[0], sync=False, pipelined=True)
+        drv.r.render(cams[1], scene, out=outs[1], sync=False, pipelined=True)
+        drv.r.render(cams[2], scene, out=outs[2], sync=False, pipelined=True)
+        drv.r.render(cams[3], scene, out=outs[3], sync=False, pipelined=True)
+        plain = drv.r.render(cams[4], scene)   # synchronous, lane 0, caller's stream
+        assert (plain == seq[4]).all()
+        for k in range(4):
+            assert (outs[k] == seq[k]).all()
+    scene.free()
+
+
 def test_pack_rgba8(drv):
     import torch
     rgb = torch.rand((37, 53, 3), device="cuda:0") * 1.4 - 0.2
