@@ -785,86 +785,106 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 }
 
 // ---- the blend loop of k_tile_render -----------------------------------------------------------------
-// The staged batch is PAIR-INTERLEAVED in LDS: for splats 2p and 2p+1
-//     s_p0[p] = (x0, x1, y0, y1)   s_p1[p] = (ca0, ca1, cb0, cb1)   s_p2[p] = (cc0, cc1, o0, o1)
-// so one ds_read_b128 lands both splats' fields in adjacent registers and the alpha evaluation of the pair
-// runs on packed FP32 ops (v_pk_add/mul/fma_f32 — CDNA4 only reaches its FP32 rate with packed math; the
-// scalar version of this loop was 33 VALU + 15 SALU per splat).  Colours (and view depth) are per splat:
-// s_col[j] = (r, g, b, z).  A wave walks ITS pairs of the batch two pairs per trip: the four alphas are
-// independent (ILP hides the LDS and transcendental latency — a long tile's critical path is one wave's
-// dependent chain), then the short sequential part (T, colour, stop) is applied in depth order.
-// Predicates stay on the VALU (compare -> select): the scalar unit is shared by the CU's four SIMDs and
-// exec-mask algebra there was the bottleneck of an earlier version.  Odd tails pair with the zero-opacity
-// dummy pair at index SGS_BATCH / 2.
+// Issue costs measured on gfx950 (scripts/ubench.hip, 6 waves per SIMD, plain v_fma_f32 = 1): packed fp32
+// (v_pk_*) 1.8 — no gain over two plain ops —, v_cmp / v_min / v_max / v_cndmask and any SGPR operand 1.6,
+// v_exp_f32 3, a broadcast ds_read_b128 ~6 on the CU's shared LDS pipe.  The composite is issue-bound, so the
+// per-pixel work is written for the smallest issue count rather than the fewest flops:
+//   * staging folds every constant into the splat (per splat, not per pixel):
+//         A = ca * log2(e)/2,  B = cb * log2(e),  C = cc * log2(e)/2      q2 = A dx^2 + B dx dy + C dy^2 = -power * log2(e)
+//         qcut = bits(log2(o / alpha_min)) + 1
+//     so alpha = o * 2^-q2 needs no scaling, and BOTH skip tests of S6 are one unsigned compare:
+//         power <= 0  and  alpha >= alpha_min   <=>   bits(q2) < qcut     (a negative q2 has the sign bit set);
+//   * a finished (or outside) pixel carries its transmittance NEGATED: T (1 - alpha) is then negative too, and one
+//     SIGNED integer compare bits(T (1 - alpha)) < bits(t_min) is true both for the splat that ends a pixel and for
+//     every later splat — their weight is forced to 0 by the same select, T keeps -|T|.  No live mask, and |T| at
+//     the end is exactly the transmittance the pixel stopped with;
+//   * D_f (how far into the queue the tile's pixels read) is not tracked per splat: when a trip leaves a wave with
+//     no live pixel — once per wave and tile — the trip is replayed from the saved T to find the splat that ended
+//     the last pixel.
+// s_a[j] = (x, y, A, B)   s_b[j] = (C, o, qcut, r)   s_c[j] = (g, b[, view depth, 0])
+// A wave walks the splats of the batch that can touch ITS quadrant four per trip: the four alphas are
+// independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
+// is applied in depth order.  Predicates stay on the VALU (compare -> select).  A short tail reads the inert
+// dummy splat at index SGS_BATCH.
 #ifdef SGS_HIPEMU
-typedef float sgs_v2f __attribute__((vector_size(8)));
+#define SGS_EXP2(x) exp2f(x)
 #else
-typedef float sgs_v2f __attribute__((ext_vector_type(2)));
+#define SGS_EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif
-#define SGS_ALPHA2(PI, AL)                                                                             \
-    sgs_v2f AL;                                                                                        \
+#define SGS_LOG2E 1.44269504088896341f
+#define SGS_NEXT(JV)                                                                                   \
+    const unsigned JV = mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH; \
+    mm &= mm - 1ull;
+#define SGS_ALPHA(J, AL, RED)                                                                          \
+    float AL, RED;                                                                                     \
     {                                                                                                  \
-        const float4 q0 = s_p0[PI], q1 = s_p1[PI], q2 = s_p2[PI];                                      \
-        const sgs_v2f X = {q0.x, q0.y}, Y = {q0.z, q0.w}, CA = {q1.x, q1.y}, CB = {q1.z, q1.w};        \
-        const sgs_v2f CC = {q2.x, q2.y}, O = {q2.z, q2.w};                                             \
-        const sgs_v2f dx = X - fpx2, dy = Y - fpy2;                                                    \
-        const sgs_v2f power = mhalf2 * (CA * dx * dx + CC * dy * dy) - CB * dx * dy;                   \
-        const sgs_v2f ex = {__expf(power[0]), __expf(power[1])};                                       \
-        const sgs_v2f oe = O * ex;                                                                     \
-        float a0 = __builtin_amdgcn_fmed3f(oe[0], 0.0f, amax), a1 = __builtin_amdgcn_fmed3f(oe[1], 0.0f, amax); \
-        a0 = power[0] <= 0.0f ? a0 : 0.0f; a1 = power[1] <= 0.0f ? a1 : 0.0f;   /* S6: skip if power > 0 */   \
-        a0 = a0 >= amin ? a0 : 0.0f; a1 = a1 >= amin ? a1 : 0.0f;               /* S6: skip if alpha < 1/255 */ \
-        AL[0] = a0; AL[1] = a1;                                                                        \
+        const float4 qa = s_a[J], qb = s_b[J];                                                         \
+        const float dx = qa.x - fpx, dy = qa.y - fpy;                                                  \
+        const float q2 = __builtin_fmaf(dx, __builtin_fmaf(qa.w, dy, qa.z * dx), (qb.x * dy) * dy);    \
+        const bool valid = __float_as_uint(q2) < __float_as_uint(qb.z);   /* S6: power <= 0 and alpha >= 1/255 */ \
+        const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
+        AL = valid ? a : 0.0f;                                                                         \
+        RED = qb.w;                                                                                    \
     }
-#define SGS_APPLY(J, ALV)                                                                              \
+#define SGS_APPLY(J, AL, RED)                                                                          \
     {                                                                                                  \
-        const float4 col = s_col[J];                                                                   \
-        const float al = (ALV) * live;             /* finished (or outside) pixels take nothing */      \
-        const float testT = T * (1.0f - al);                                                           \
-        const bool stop = testT < tmin;            /* only a live pixel that was hit can get here */    \
-        const float wgt = stop ? 0.0f : al * T;                                                        \
-        C0 += wgt * col.x; C1 += wgt * col.y; C2 += wgt * col.z;                                       \
-        if (AUX) Dz += wgt * col.w;                /* expected depth (template instantiation only) */    \
-        T = stop ? T : testT;                                                                          \
-        used = stop ? base + (J) + 1u : used;                                                          \
-        live = stop ? 0.0f : live;                                                                     \
+        const ColT qc = s_c[J];                                                                        \
+        const float testT = __builtin_fmaf(-(AL), T, T);                                               \
+        const bool stop = (int)__float_as_uint(testT) < tmin_bits;   /* ends here, or ended before (negative) */ \
+        float wgt = (AL) * T;                                                                          \
+        wgt = stop ? 0.0f : wgt;                   /* the splat that would end the pixel is not blended */ \
+        C0 = __builtin_fmaf(wgt, RED, C0); C1 = __builtin_fmaf(wgt, qc.x, C1); C2 = __builtin_fmaf(wgt, qc.y, C2); \
+        if (AUX) Dz = __builtin_fmaf(wgt, col_z(qc), Dz);   /* expected depth (template instantiation only) */ \
+        T = stop ? -__builtin_fabsf(T) : testT;                                                        \
     }
-#define SGS_NEXT_PAIR(PV)                                                                              \
-    const unsigned PV = pm != 0ull ? gwp + (unsigned)((__ffsll((long long)pm) - 1) >> 1) : (unsigned)(SGS_BATCH / 2); \
-    pm &= pm - 1ull;
+#define SGS_REPLAY(J, AL)                                                                              \
+    {                                                                                                  \
+        if (__ballot(Ts > 0.0f) != 0ull) last = (J) + 1u;                                              \
+        const float testT = __builtin_fmaf(-(AL), Ts, Ts);                                             \
+        Ts = (int)__float_as_uint(testT) < tmin_bits ? -__builtin_fabsf(Ts) : testT;                   \
+    }
 #define SGS_BLEND_WAVE()                                                                               \
-    if (__ballot(live > 0.0f) != 0ull) {                                                               \
-        const sgs_v2f fpx2 = {fpx, fpx}, fpy2 = {fpy, fpy}, mhalf2 = {-0.5f, -0.5f};                   \
+    if (__ballot(T > 0.0f) != 0ull) {                                                                  \
         bool wave_done = false;                                                                        \
         for (int gw = 0; gw < 4 && !wave_done; ++gw) {                                                 \
-            const unsigned long long m64 = uniform_u64(s_ball[par][wave][gw]);                         \
-            unsigned long long pm = (m64 | (m64 >> 1)) & 0x5555555555555555ull;   /* pairs with a splat of ours */ \
-            const unsigned gwp = (unsigned)gw * 32u;                                                   \
-            while (pm != 0ull) {                                                                       \
-                SGS_NEXT_PAIR(pa) SGS_NEXT_PAIR(pb)                                                    \
-                SGS_ALPHA2(pa, alA) SGS_ALPHA2(pb, alB)                                                \
-                SGS_APPLY(2u * pa, alA[0]) SGS_APPLY(2u * pa + 1u, alA[1])                             \
-                SGS_APPLY(2u * pb, alB[0]) SGS_APPLY(2u * pb + 1u, alB[1])                             \
-                if (__ballot(live > 0.0f) == 0ull) { wave_done = true; break; }                        \
+            unsigned long long mm = uniform_u64(s_ball[par][wave][gw]);   /* splats with a footprint in this quadrant */ \
+            const unsigned gwb = (unsigned)gw * 64u;                                                   \
+            while (mm != 0ull) {                                                                       \
+                const float Tb = T;                                                                    \
+                SGS_NEXT(j0) SGS_NEXT(j1) SGS_NEXT(j2) SGS_NEXT(j3)                                    \
+                SGS_ALPHA(j0, al0, r0) SGS_ALPHA(j1, al1, r1) SGS_ALPHA(j2, al2, r2) SGS_ALPHA(j3, al3, r3) \
+                SGS_APPLY(j0, al0, r0) SGS_APPLY(j1, al1, r1) SGS_APPLY(j2, al2, r2) SGS_APPLY(j3, al3, r3) \
+                if (__ballot(T > 0.0f) == 0ull) {                                                      \
+                    /* the wave's last pixel ended in this trip: replay it to find the splat that did it */ \
+                    float Ts = Tb; unsigned last = 0u;                                                 \
+                    SGS_REPLAY(j0, al0) SGS_REPLAY(j1, al1) SGS_REPLAY(j2, al2) SGS_REPLAY(j3, al3)    \
+                    used = base + last;                                                                \
+                    wave_done = true; break;                                                           \
+                }                                                                                      \
             }                                                                                          \
         }                                                                                              \
-        used = live > 0.0f ? base + m : used;     /* still live: the whole batch counts as examined */  \
+        used = T > 0.0f ? base + m : used;       /* still live: the whole batch counts as examined */    \
     }
-// staging helpers: write splat J (registers A = x,y,ca,cb  B = cc,o,r,g  c = b, z = view depth)
-#define SGS_STAGE(J, A, B, CBLUE, ZV)                                                                  \
+// staging: write splat J (registers A_ = x,y,ca,cb  B_ = cc,o,r,g  CBLUE = b, ZV = view depth); QMAX = log2(o / alpha_min)
+#define SGS_STAGE(J, A_, B_, CBLUE, ZV, QMAX)                                                          \
     {                                                                                                  \
-        float* w0 = reinterpret_cast<float*>(&s_p0[(J) >> 1]) + ((J) & 1u);                            \
-        float* w1 = reinterpret_cast<float*>(&s_p1[(J) >> 1]) + ((J) & 1u);                            \
-        float* w2 = reinterpret_cast<float*>(&s_p2[(J) >> 1]) + ((J) & 1u);                            \
-        w0[0] = A.x; w0[2] = A.y; w1[0] = A.z; w1[2] = A.w; w2[0] = B.x; w2[2] = B.y;                  \
-        s_col[J] = make_float4(B.z, B.w, CBLUE, ZV);                                                   \
+        const unsigned qcut_ = (QMAX) >= 0.0f ? __float_as_uint(QMAX) + 1u : 0u;                       \
+        s_a[J] = make_float4(A_.x, A_.y, (0.5f * SGS_LOG2E) * A_.z, SGS_LOG2E * A_.w);                 \
+        s_b[J] = make_float4((0.5f * SGS_LOG2E) * B_.x, B_.y, __uint_as_float(qcut_), B_.z);           \
+        s_c[J] = make_col<ColT>(B_.w, CBLUE, ZV);                                                      \
     }
 #define SGS_STAGE_DUMMY()                                                                              \
     {                                                                                                  \
-        s_p0[SGS_BATCH / 2] = make_float4(0.f, 0.f, 0.f, 0.f); s_p1[SGS_BATCH / 2] = make_float4(1.f, 1.f, 0.f, 0.f); \
-        s_p2[SGS_BATCH / 2] = make_float4(1.f, 1.f, 0.f, 0.f);                                         \
-        s_col[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_col[SGS_BATCH + 1] = make_float4(0.f, 0.f, 0.f, 0.f); \
+        s_a[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_b[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); \
+        s_c[SGS_BATCH] = make_col<ColT>(0.f, 0.f, 0.f);                                                \
     }
+template <class C> __device__ __forceinline__ C make_col(float g, float b, float z);
+template <> __device__ __forceinline__ float2 make_col<float2>(float g, float b, float) { return make_float2(g, b); }
+template <> __device__ __forceinline__ float4 make_col<float4>(float g, float b, float z) { return make_float4(g, b, z, 0.f); }
+__device__ __forceinline__ float col_z(const float2&) { return 0.f; }
+__device__ __forceinline__ float col_z(const float4& c) { return c.z; }
+template <bool AUX> struct ColOf { typedef float2 type; };
+template <> struct ColOf<true> { typedef float4 type; };
 
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.
@@ -921,12 +941,12 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      FrameStatus* st, unsigned long long* prof) {
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
-    __shared__ float4 s_arena[3 * (SGS_BATCH / 2 + 1) + (SGS_BATCH + 2)];
-    static_assert(sizeof(float4) * (3 * (SGS_BATCH / 2 + 1) + (SGS_BATCH + 2)) >= sizeof(SortShared), "arena");
-    float4* const s_p0 = s_arena;                                     // blend phase: the staged batch, pair-interleaved
-    float4* const s_p1 = s_arena + (SGS_BATCH / 2 + 1);
-    float4* const s_p2 = s_arena + 2 * (SGS_BATCH / 2 + 1);
-    float4* const s_col = s_arena + 3 * (SGS_BATCH / 2 + 1);         // per splat: r, g, b, view depth (+2 dummies)
+    typedef typename ColOf<AUX>::type ColT;
+    __shared__ float4 s_arena[2 * (SGS_BATCH + 1) + ((SGS_BATCH + 1) * sizeof(ColT) + 15) / 16];
+    static_assert(sizeof(float4) * 2 * (SGS_BATCH + 1) >= sizeof(SortShared), "arena");
+    float4* const s_a = s_arena;                                      // blend phase: the staged batch (+1 inert dummy)
+    float4* const s_b = s_arena + (SGS_BATCH + 1);
+    ColT* const s_c = reinterpret_cast<ColT*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
     __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
@@ -956,13 +976,14 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     const float fpx = (float)px, fpy = (float)py;
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(tile_y * 16u);
     const float amin = P.alpha_min, amax = P.alpha_max, tmin = P.t_min;
-    const float k_cut = -2.0f * __logf(amin);          // alpha >= amin  <=>  d^T Q d <= 2 ln(o) + k_cut
+    const int tmin_bits = (int)__float_as_uint(tmin);
+    const float l2_inv_amin = -__log2f(amin);          // alpha >= amin  <=>  q2 <= log2(o) + l2_inv_amin
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
 
     const unsigned beg = tile_offset[(size_t)tile * SGS_XCDS];              // the tile's 8 per-XCD sub-queues are adjacent
     const unsigned n = tile_offset[(size_t)tile * SGS_XCDS + SGS_XCDS] - beg;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
-    float live = inside ? 1.0f : 0.0f;   // 1 while the pixel still accepts splats
+    float T = inside ? 1.0f : -1.0f;     // transmittance; negative = finished (or outside the image): takes nothing more
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
@@ -1116,13 +1137,10 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             __syncthreads();             // every lane has read its record: the staging arena may be written
                                          // (s_q and the arena are distinct, but s_ball was just cleared)
             if (tid == 0) SGS_STAGE_DUMMY()
-            if (tid == 1 && (cnt & 1u)) {         // odd batch: the last splat's pair partner is a zero-opacity blank
-                const float4 z4 = make_float4(0.f, 0.f, 1.f, 0.f), o4 = make_float4(1.f, 0.f, 0.f, 0.f);
-                SGS_STAGE(cnt, z4, o4, 0.f, 0.f)
-            }
             if (have) {
-                SGS_STAGE(rank, nA, nB, nC, __uint_as_float((unsigned)(mine >> 32)))
-                const float K = 2.0f * __logf(nB.y) + k_cut;
+                const float qmax = __log2f(nB.y) + l2_inv_amin;
+                SGS_STAGE(rank, nA, nB, nC, __uint_as_float((unsigned)(mine >> 32)), qmax)
+                const float K = 1.38629436112f * qmax;     // d^T Q d <= 2 ln(o / amin)
                 const float detq = nA.z * nB.x - nA.w * nA.w;
                 if (K > 0.0f) {
                     float hx = 3.0e38f, hy = 3.0e38f;
@@ -1150,7 +1168,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             if (tid == 0) s_any[par ^ 1u] = 0;
             const unsigned base = lo, m = cnt;
             SGS_BLEND_WAVE()
-            const bool still_live = __ballot(live > 0.0f) != 0ull;
+            const bool still_live = __ballot(T > 0.0f) != 0ull;
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
             tile_done = s_any[par] == 0u;
@@ -1236,14 +1254,11 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 const bool have = (unsigned)tid < m;
                 unsigned qbits = 0;
                 if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
-                if (tid == 1 && (m & 1u)) {
-                    const float4 z4 = make_float4(0.f, 0.f, 1.f, 0.f), o4 = make_float4(1.f, 0.f, 0.f, 0.f);
-                    SGS_STAGE(m, z4, o4, 0.f, 0.f)
-                }
                 if (have) {
-                    SGS_STAGE((unsigned)tid, nA, nB, nC, nD)
+                    const float qmax = __log2f(nB.y) + l2_inv_amin;
+                    SGS_STAGE((unsigned)tid, nA, nB, nC, nD, qmax)
                     // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
-                    const float K = 2.0f * __logf(nB.y) + k_cut;
+                    const float K = 1.38629436112f * qmax;     // 2 ln(o / amin)
                     const float detq = nA.z * nB.x - nA.w * nA.w;
                     if (K > 0.0f) {
                         float hx = 3.0e38f, hy = 3.0e38f;
@@ -1275,7 +1290,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
                 SGS_BLEND_WAVE()
-                const bool still_live = __ballot(live > 0.0f) != 0ull;
+                const bool still_live = __ballot(T > 0.0f) != 0ull;
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
@@ -1297,10 +1312,11 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #endif
     if (inside) {
         float* o = out_rgb + ((size_t)py * P.width + px) * 3;
-        o[0] = C0 + T * P.bg[0]; o[1] = C1 + T * P.bg[1]; o[2] = C2 + T * P.bg[2];
+        const float Tf = __builtin_fabsf(T);            // a finished pixel holds its final transmittance negated
+        o[0] = C0 + Tf * P.bg[0]; o[1] = C1 + Tf * P.bg[1]; o[2] = C2 + Tf * P.bg[2];
         if (AUX) {                        // expected depth sum(T alpha z) and coverage 1 - T_final
             float* a = out_aux + ((size_t)py * P.width + px) * 2;
-            a[0] = Dz; a[1] = 1.0f - T;
+            a[0] = Dz; a[1] = 1.0f - Tf;
         }
     }
     if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined

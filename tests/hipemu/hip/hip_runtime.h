@@ -40,6 +40,8 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) uint4 { unsigned x, y, z, w; };
@@ -225,6 +227,7 @@ static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4);
 static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
+#define __log2f(x) log2f(x)
 static inline unsigned long long clock64() { return 0; }
 #define __builtin_amdgcn_s_setprio(p_) ((void)0)
 #define __builtin_amdgcn_s_getreg(reg_) (blockIdx.x & 7u)      /* emulated XCC id */
