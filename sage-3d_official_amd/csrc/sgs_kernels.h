@@ -920,6 +920,7 @@ template <> struct ColOf<true> { typedef float4 type; };
 #define SGS_BUCKET_SHIFT 18
 #define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
+#define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
@@ -940,7 +941,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                                                      float* __restrict__ out_aux,
                                                      FrameStatus* st, unsigned long long* prof) {
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
-    __shared__ unsigned long long s_q[SGS_QCAP + 8];  // records: depth bits << 32 | slot (+8 sentinels)
+    __shared__ unsigned long long s_q[SGS_QCAP + 8 + SGS_RANK_BUCKET_MAX];  // records: depth bits << 32 | slot (+8 sentinels, + slack
+                                                                          // for the masked reads past a short bucket)
     typedef typename ColOf<AUX>::type ColT;
     __shared__ float4 s_arena[2 * (SGS_BATCH + 1) + ((SGS_BATCH + 1) * sizeof(ColT) + 15) / 16];
     static_assert(sizeof(float4) * 2 * (SGS_BATCH + 1) >= sizeof(SortShared), "arena");
@@ -1123,8 +1125,28 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 nA = sp[0]; nB = sp[1]; nC = sp[2].x;
             }
             if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // 4 quadrants x 4 x 64 bits
+            // Rank of my record inside the group.  The resident queue is bucket-contiguous (MSD partition) and the
+            // buckets are disjoint depth ranges, so rank = (records of shallower buckets) + (rank inside MY bucket):
+            // a lane walks only its own bucket's slice — typically a few dozen records instead of the group's ~256.
+            // Decided per wave (no barrier inside): a wave with one long bucket falls back to the broadcast walk.
             unsigned rank = 0;
-            {
+            unsigned bbeg = win_lo, blen = 0;
+            if (parted && have) {
+                const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(mine >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                bbeg = bk ? s_bcnt[bk - 1] : 0u;            // cursors after the scatter = bucket ends = next bucket's start
+                blen = s_bcnt[bk] - bbeg;
+            }
+            const unsigned maxlen = wave_max(blen);
+            if (parted && maxlen * 2u <= cnt && maxlen <= SGS_RANK_BUCKET_MAX) {
+                const unsigned long long* bq = s_q + (bbeg - win_lo);
+                unsigned r = 0;
+                for (unsigned t = 0; t < maxlen; t += 2) {
+                    const unsigned long long x0 = bq[t], x1 = bq[t + 1];     // (reads past a short bucket are masked out)
+                    r += (t < blen && x0 < mine) ? 1u : 0u;
+                    r += (t + 1u < blen && x1 < mine) ? 1u : 0u;
+                }
+                rank = (bbeg - lo) + r;
+            } else if ((unsigned)wave * 64u < cnt) {
                 const unsigned cnt8 = (cnt + 7u) & ~7u;
                 for (unsigned j = 0; j < cnt8; j += 8) {
                     unsigned long long x[8];
