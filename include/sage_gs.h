@@ -47,6 +47,9 @@ enum {
     SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite) */
     SGS_FLAG_FULL_SORT = 1u << 3,  /* tests: order every queue completely (the production path sorts
                                       lazily and stops once a tile's pixels have all terminated) */
+    SGS_FLAG_LOOSE_CULL = 1u << 5, /* tests: inside a tile, decide which 8x8 quadrants a splat can reach from its axis-aligned
+                                    * extent only (the production path refines it with the exact ellipse/rectangle test);
+                                    * frames must be bit-identical either way */
     SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
                                     * the library's internal streams (a few frames in flight, each with its own
                                     * intermediates: one frame's binning fills the compute units another frame's

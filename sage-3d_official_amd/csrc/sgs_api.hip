@@ -156,7 +156,7 @@ int ensure_tiles(sgs_ctx* ctx, Lane& L, int tiles) {
     int rc;
     if ((rc = grow(ctx, L.tile_count, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.tile_prof, (size_t)tiles * 8)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.tile_prof, (size_t)tiles * SGS_PROF_WORDS)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_order, (size_t)tiles)) != SGS_OK) return rc;
     // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
@@ -716,7 +716,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_SORTED_SLOTS: src = L.sorted_out; have = (s.overflow || !L.sorted_out) ? 0 : (int64_t)s.d_total * 4; break;
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: src = L.splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
-        case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 64; break;    // profiling build only
+        case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
     }

@@ -812,6 +812,15 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_EXP2(x) __builtin_amdgcn_exp2f(x)
 #endif
 #define SGS_LOG2E 1.44269504088896341f
+#ifdef SGS_TILE_PROF   // profiling build: how many (wave, splat) evaluations had no pixel inside the alpha cut-off
+#define SGS_PROF_EVAL(valid, J)                                                                        \
+    if ((J) != (unsigned)SGS_BATCH) {                                                                  \
+        const unsigned long long vb_ = __ballot(valid), lb_ = __ballot((valid) && T > 0.0f);           \
+        ++pe_eval; pe_empty += vb_ == 0ull; pe_valid += (unsigned)__popcll(vb_); pe_useful += (unsigned)__popcll(lb_); \
+    }
+#else
+#define SGS_PROF_EVAL(valid, J)
+#endif
 #define SGS_NEXT(JV)                                                                                   \
     const unsigned JV = mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH; \
     mm &= mm - 1ull;
@@ -825,6 +834,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
         AL = valid ? a : 0.0f;                                                                         \
         RED = qb.w;                                                                                    \
+        SGS_PROF_EVAL(valid, J)                                                                        \
     }
 #define SGS_APPLY(J, AL, RED)                                                                          \
     {                                                                                                  \
@@ -878,6 +888,37 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         s_a[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_b[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); \
         s_c[SGS_BATCH] = make_col<ColT>(0.f, 0.f, 0.f);                                                \
     }
+// ---- which 8x8 quadrants of the tile can a splat reach? -------------------------------------------------
+// The axis-aligned extent of {alpha >= alpha_min} is a loose test for elongated splats (measured: 27 % of the
+// (wave, splat) evaluations it let through had no pixel inside the cut-off).  This is the exact one: the minimum of
+//     q2(d) = A dx^2 + B dx dy + C dy^2        (the staged coefficients, q2 <= qmax  <=>  alpha >= alpha_min)
+// over the rectangle of a quadrant's pixel centres is 0 if the centre lies inside, else it is attained on one of
+// the four edges, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  Every comparison carries
+// a bound on the rounding error of both this evaluation and the per-pixel one, so a quadrant holding a pixel the
+// blend would accept is never rejected (a NaN anywhere accepts).
+__device__ __forceinline__ float sgs_edge_min(float e, float d0, float d1, float P_, float B_, float R_, float k) {
+    const float t = __builtin_amdgcn_fmed3f(k * e, d0, d1);
+    const float a = P_ * e * e, b = B_ * e * t, c = R_ * t * t;
+    return (a + b + c) - 4.0e-6f * (a + fabsf(b) + c);
+}
+__device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float B, float C, float qmax) {
+    // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15]
+    const float kv = __fdividef(-0.5f * B, C), kh = __fdividef(-0.5f * B, A);
+    const float xs[4] = {0.0f - rx, 7.0f - rx, 8.0f - rx, 15.0f - rx};
+    const float ys[4] = {0.0f - ry, 7.0f - ry, 8.0f - ry, 15.0f - ry};
+    unsigned bits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float xa = xs[2 * (q & 1)], xb = xs[2 * (q & 1) + 1], ya = ys[2 * (q >> 1)], yb = ys[2 * (q >> 1) + 1];
+        const bool inside = xa <= 0.0f && xb >= 0.0f && ya <= 0.0f && yb >= 0.0f;
+        const float m = fminf(fminf(sgs_edge_min(xa, ya, yb, A, B, C, kv), sgs_edge_min(xb, ya, yb, A, B, C, kv)),
+                              fminf(sgs_edge_min(ya, xa, xb, C, B, A, kh), sgs_edge_min(yb, xa, xb, C, B, A, kh)));
+        const float fx = fmaxf(fabsf(xa), fabsf(xb)), fy = fmaxf(fabsf(ya), fabsf(yb));      // farthest pixel of the quadrant
+        const float thr = qmax + 2.0e-6f * (A * fx * fx + fabsf(B) * fx * fy + C * fy * fy) + 1.0e-5f;
+        if (inside || !(m > thr)) bits |= 1u << q;
+    }
+    return bits;
+}
 template <class C> __device__ __forceinline__ C make_col(float g, float b, float z);
 template <> __device__ __forceinline__ float2 make_col<float2>(float g, float b, float) { return make_float2(g, b); }
 template <> __device__ __forceinline__ float4 make_col<float4>(float g, float b, float z) { return make_float4(g, b, z, 0.f); }
@@ -961,6 +1002,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
+    unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
+    __shared__ unsigned s_pe[4];
+    if (threadIdx.x < 4) s_pe[threadIdx.x] = 0;
 #define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
 #else
 #define SGS_PROF_MARK(acc) do { } while (0)
@@ -981,6 +1025,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     const int tmin_bits = (int)__float_as_uint(tmin);
     const float l2_inv_amin = -__log2f(amin);          // alpha >= amin  <=>  q2 <= log2(o) + l2_inv_amin
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
+    const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
 
     const unsigned beg = tile_offset[(size_t)tile * SGS_XCDS];              // the tile's 8 per-XCD sub-queues are adjacent
     const unsigned n = tile_offset[(size_t)tile * SGS_XCDS + SGS_XCDS] - beg;
@@ -1174,12 +1219,15 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
                     const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
                     const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
+                    unsigned qb4 = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
+                                   ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
+                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits(rx, ry, (0.5f * SGS_LOG2E) * nA.z, SGS_LOG2E * nA.w, (0.5f * SGS_LOG2E) * nB.x, qmax);
                     unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
                     const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
-                    if (x_lo && y_lo) atomicOr(&bw[0 * 8 + word], bit);
-                    if (x_hi && y_lo) atomicOr(&bw[1 * 8 + word], bit);
-                    if (x_lo && y_hi) atomicOr(&bw[2 * 8 + word], bit);
-                    if (x_hi && y_hi) atomicOr(&bw[3 * 8 + word], bit);
+                    if (qb4 & 1u) atomicOr(&bw[0 * 8 + word], bit);
+                    if (qb4 & 2u) atomicOr(&bw[1 * 8 + word], bit);
+                    if (qb4 & 4u) atomicOr(&bw[2 * 8 + word], bit);
+                    if (qb4 & 8u) atomicOr(&bw[3 * 8 + word], bit);
                 }
             }
             __syncthreads();             // batch staged in depth order
@@ -1294,6 +1342,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                         const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
                         qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                 ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
+                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits(rx, ry, (0.5f * SGS_LOG2E) * nA.z, SGS_LOG2E * nA.w, (0.5f * SGS_LOG2E) * nB.x, qmax);
                     }
                 }
 #pragma unroll
@@ -1326,10 +1375,13 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         lo = hi;
     }
 #ifdef SGS_TILE_PROF
+    if (lane == 0) { atomicAdd(&s_pe[0], pe_eval); atomicAdd(&s_pe[1], pe_empty); atomicAdd(&s_pe[2], pe_valid); atomicAdd(&s_pe[3], pe_useful); }
+    __syncthreads();
     if (tid == 0 && prof) {
-        unsigned long long* o = prof + (size_t)tile * 8;
+        unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
+        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3];
     }
 #endif
     if (inside) {

@@ -12,7 +12,7 @@ import os
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
-FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED = 1, 2, 4, 8, 16
+FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL = 1, 2, 4, 8, 16, 32
 BACKEND_CPU, BACKEND_HIP = 0, 1
 BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS = 0, 1, 2, 3
 

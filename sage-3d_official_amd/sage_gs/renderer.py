@@ -179,7 +179,7 @@ class Renderer:
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
-               return_aux=False, pipelined=False):
+               return_aux=False, pipelined=False, loose_cull=False):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
@@ -209,6 +209,7 @@ class Renderer:
             ptr, ret = out.data_ptr(), out
         flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
                 (_capi.FLAG_FULL_SORT if full_sort else 0) | \
+                (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         if return_aux or out_aux is not None:

@@ -67,8 +67,9 @@ class EmuRenderer:
         self.scene = sc
         self.n = arrs[0].shape[0]
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False):
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
+        flags |= _capi.FLAG_LOOSE_CULL if loose_cull else 0
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                               np.asarray(cam.view, np.float32).reshape(4, 4).tolist())
         k = self.lib.default_config()

@@ -228,6 +228,7 @@ static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); re
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
 #define __log2f(x) log2f(x)
+#define __fdividef(a, b) ((a) / (b))
 static inline unsigned long long clock64() { return 0; }
 #define __builtin_amdgcn_s_setprio(p_) ((void)0)
 #define __builtin_amdgcn_s_getreg(reg_) (blockIdx.x & 7u)      /* emulated XCC id */

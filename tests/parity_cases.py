@@ -49,6 +49,10 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     img_full, st_full = drv.render(cam, cfg, rows, full_sort=True)
     assert (img_full == img).all(), f"{what}: lazy and full sort must blend the same records in the same order"
     assert st_full["d_fetched"] == st["d_fetched"] and st_full["d_total"] == st["d_total"]
+    # test hook: the exact quadrant test may only drop (wave, splat) pairs that contribute to no pixel
+    img_loose, st_loose = drv.render(cam, cfg, rows, loose_cull=True)
+    assert (img_loose == img).all(), f"{what}: the exact quadrant test changed the frame"
+    assert st_loose["d_fetched"] == st["d_fetched"]
     ref, aux = oracle_c.render(*scene, cam, cfg, rows[0], rows[1])
     assert st["n_visible"] == aux["n_visible"], (what, st["n_visible"], aux["n_visible"])
     assert st["d_total"] == aux["D"], (what, st["d_total"], aux["D"])

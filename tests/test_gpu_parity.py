@@ -30,14 +30,14 @@ class GpuDriver:
             self.scene.free()
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
                                                   cfg.alpha_max, cfg.t_min, cfg.background, cfg.sh_degree)
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
         img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
-                            full_sort=full_sort)
+                            full_sort=full_sort, loose_cull=loose_cull)
         return img.cpu().numpy(), self.r.last_stats
 
     def render_aux(self, cam, cfg=None):
@@ -187,6 +187,9 @@ def test_3m_scene_properties(drv, big_scene):
         # (4) idempotence / determinism
         again, _ = drv.render(ocam)
         assert (again == full).all()
+        # (5) the exact quadrant test only removes (wave, splat) pairs without a pixel inside the alpha cut-off
+        loose, st_loose = drv.render(ocam, loose_cull=True)
+        assert (loose == full).all() and st_loose["d_fetched"] == st["d_fetched"]
 
 
 def test_3m_scene_crop_vs_oracle(drv, big_scene):
