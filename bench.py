@@ -137,17 +137,44 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for i in range(W):
-        step(i, False)
-    if issued[0]:
-        r.sync()                                          # also grows nothing: capacity is fixed up front
-    issued[0] = 0
+    batched_rows = sharded is not None and not args.no_pipeline
+
+    def run(first, count, timed):
+        """Issue frames first .. first+count-1 and complete them; returns the per-frame average statistics of the
+        frames this rank rendered (every frame of the region is checked for overflow)."""
+        if batched_rows:
+            # tile-row shards of a sweep: the bands of `batch` frames are rendered through the pipelined lanes and
+            # travel in one asynchronous gather, double-buffered against the next batch
+            acc, n_acc, i = None, 0, 0
+            while i < count:
+                nb = min(sharded.batch, count - i)
+                sharded.last_stats = None
+                sharded.render_batch([cams[(first + i + j) % len(cams)] for j in range(nb)], gs, timing=timed)
+                st = sharded.last_stats
+                if st is not None:
+                    if acc is None:
+                        acc = {"ms": {n: 0.0 for n in STAGE_NAMES}, "ms_total": 0.0}
+                    for n in STAGE_NAMES:
+                        acc["ms"][n] += st["ms"][n] * nb
+                    acc["ms_total"] += st["ms_total"] * nb
+                    n_acc += nb
+                i += nb
+            sharded.finish()
+            if acc is not None:
+                for n in STAGE_NAMES:
+                    acc["ms"][n] /= n_acc
+                acc["ms_total"] /= n_acc
+            return acc
+        issued[0] = 0
+        for i in range(count):
+            step(first + i, timed)
+        return r.sync() if issued[0] else None            # completes the frames in flight (all lanes)
+
+    run(0, W, False)
     fence()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(W + i, timing)
-    avg = r.sync() if issued[0] else None                 # completes the frames in flight (all lanes) and checks
-    fence()                                               # EVERY frame of the region for overflow
+    avg = run(W, K, timing)
+    fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
@@ -191,7 +218,9 @@ def main():
             "config": {"workload": f"configs[2]: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
                                    f"SH deg 3, {args.width}x{args.height}, reference lens (8/20.955), 256-pose yaw sweep",
                        "parallelism": "1 GPU" if world == 1 else
-                                      (f"tile-row shard x{world} + RCCL gather to rank 0" if args.shard == "rows"
+                                      (f"tile-row shard x{world} + RCCL gather to rank 0"
+                                       + (f" (bands of {sharded.batch} frames per collective)" if batched_rows else "")
+                                       if args.shard == "rows"
                                        else f"camera shard x{world}"),
                        "per_frame": {k: (v / max(1, frames_here) if k not in ("max_tile_len",) else v) for k, v in counts.items()}},
         }
@@ -215,7 +244,7 @@ def main():
                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
                                "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
-                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
+                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if (pipelined or batched_rows) else 1),
                                "note": "ms = HIP-event duration inside the timed region (frames overlap when "
                                        "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
                                        "with nothing else running"}

@@ -12,6 +12,9 @@ so there is no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.3 MB per rank at
 peers land on seven distinct xGMI links of rank 0 concurrently, so the step is latency-, not
 bandwidth-bound — one collective per frame, no ring.
 
+For a sweep of independent frames (`ShardedRenderer.render_batch`) the bands of B frames are rendered through the
+renderer's pipelined lanes and travel in one asynchronous collective, double-buffered against the next batch.
+
 `shard_cameras` is the other natural partition (frames of a sweep are independent units): no
 data-path collective at all.
 """
@@ -41,60 +44,135 @@ def shard_cameras(n_cameras: int, rank: int, world: int) -> range:
 
 
 class FrameGather:
-    """Buffers and the collective for gathering tile-row bands of H x W frames to rank `dst`."""
+    """Buffers and the collective for gathering tile-row bands of H x W frames to rank `dst`.
+
+    batch=None: one frame, slab = [slab_rows, W, C].  batch=B: B frames per collective, slab = [B, slab_rows, W, C]
+    (a sweep's frames are independent, so their bands can travel together: one collective per B frames)."""
 
     def __init__(self, height: int, width: int, device, rank: Optional[int] = None, world: Optional[int] = None,
-                 group=None, dst: int = 0, channels: int = 3, dtype=torch.float32):
+                 group=None, dst: int = 0, channels: int = 3, dtype=torch.float32, batch: Optional[int] = None):
         self.group = group
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.dst, self.h, self.w = dst, height, width
+        self.batch = batch
         self.n_tile_rows = (height + TILE - 1) // TILE
         self.bands = row_partition(self.n_tile_rows, self.world)
         self.slab_rows = ((self.n_tile_rows + self.world - 1) // self.world) * TILE      # pixel rows per slab
         self.band = self.bands[self.rank]
-        # every rank's slab has the same shape; rank dst owns the padded frame the slabs land in
+        lead = () if batch is None else (int(batch),)
+        # every rank's slab has the same shape; rank dst owns the padded buffer the slabs land in
         if self.rank == dst:
-            self.padded = torch.zeros((self.world, self.slab_rows, width, channels), dtype=dtype, device=device)
+            self.padded = torch.zeros((self.world,) + lead + (self.slab_rows, width, channels), dtype=dtype, device=device)
             self.slab = self.padded[self.rank]
             self._views = [self.padded[i] for i in range(self.world)]
         else:
             self.padded = None
-            self.slab = torch.zeros((self.slab_rows, width, channels), dtype=dtype, device=device)
+            self.slab = torch.zeros(lead + (self.slab_rows, width, channels), dtype=dtype, device=device)
             self._views = None
 
     @property
     def band_pixel_rows(self) -> Tuple[int, int]:
         return self.band[0] * TILE, min(self.band[1] * TILE, self.h)
 
+    def _collective(self, n: Optional[int], async_op: bool):
+        src = self.slab if n is None else self.slab[:n]
+        outs = None
+        if self.rank == self.dst:
+            outs = self._views if n is None else [v[:n] for v in self._views]
+        if src.is_cuda and dist.get_backend(self.group) == "gloo":
+            # debugging aid (several ranks on one GPU under gloo): stage through the host
+            host = src.cpu()
+            houts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
+            dist.gather(host, houts, dst=self.dst, group=self.group)
+            if self.rank == self.dst:
+                for o, h in zip(outs, houts):
+                    o.copy_(h)
+            return None
+        return dist.gather(src, outs, dst=self.dst, group=self.group, async_op=async_op)
+
     def gather(self) -> Optional[torch.Tensor]:
-        """Collective.  Returns the assembled [H,W,C] frame on rank dst (a view, no copy), else None."""
+        """Collective (single-frame buffers).  Returns the assembled [H,W,C] frame on rank dst (a view, no copy)."""
+        if self.batch is not None:
+            raise ValueError("gather() is for single-frame buffers; use gather_batch()")
         if self.world > 1:
-            if self.slab.is_cuda and dist.get_backend(self.group) == "gloo":
-                # debugging aid (several ranks on one GPU under gloo): stage through the host
-                host = self.slab.cpu()
-                outs = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-                dist.gather(host, outs, dst=self.dst, group=self.group)
-                if self.rank == self.dst:
-                    for i, o in enumerate(outs):
-                        self._views[i].copy_(o)
-            else:
-                dist.gather(self.slab, self._views if self.rank == self.dst else None, dst=self.dst, group=self.group)
+            self._collective(None, False)
         if self.rank != self.dst:
             return None
         return self.padded.view(self.world * self.slab_rows, self.w, -1)[: self.h]
 
+    def gather_batch(self, n: Optional[int] = None, async_op: bool = False):
+        """Collective over the first n frames of a batched buffer.  Returns the work handle (None when complete)."""
+        if self.batch is None:
+            raise ValueError("gather_batch() needs batch=B buffers")
+        if self.world > 1:
+            return self._collective(n, async_op)
+        return None
+
+    def frames(self, n: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Rank dst: the gathered batch as a [n, world, slab_rows, W, C] view (frame b = rows of [b] stacked, cut at H)."""
+        if self.rank != self.dst:
+            return None
+        v = self.padded.permute(1, 0, 2, 3, 4)
+        return v if n is None else v[:n]
+
+    def frame(self, b: int) -> Optional[torch.Tensor]:
+        """Rank dst: frame b of the gathered batch, assembled to [H,W,C] (one copy)."""
+        if self.rank != self.dst:
+            return None
+        return self.padded[:, b].reshape(self.world * self.slab_rows, self.w, -1)[: self.h]
+
 
 class ShardedRenderer:
-    """Tile-row-sharded rendering of one frame across the ranks of a process group."""
+    """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows,
+    the bands are gathered to rank `dst`."""
 
-    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0):
+    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8):
         self.r = renderer
+        self.h, self.w, self.group, self.dst = height, width, group, dst
         self.g = FrameGather(height, width, renderer.device, group=group, dst=dst)
+        self.batch = int(batch)
+        self._ring = None            # two batched buffers: one travels while the other is rendered into
+        self._pending = [None, None]
+        self._turn = 0
+        self.last_stats = None       # statistics of the last batch this rank rendered (per-frame averages)
 
     def render(self, camera, scene, *, config=None, sync=False):
-        """Every rank renders its band into its slab and joins the gather; rank dst gets the frame."""
+        """One frame: every rank renders its band into its slab and joins the gather; rank dst gets the frame."""
         r0, r1 = self.g.band
         if r1 > r0:
             self.r.render(camera, scene, config=config, out_band=self.g.slab, tile_rows=(r0, r1), sync=sync)
         return self.g.gather()
+
+    def render_batch(self, cameras, scene, *, config=None, timing=False):
+        """Up to `batch` independent frames (a sweep): the bands are rendered through the renderer's pipelined lanes
+        and travel in ONE asynchronous collective, which overlaps with the next call's rendering (two buffers
+        alternate).  Returns the FrameGather holding this batch; its contents are complete after .finish() (or the
+        next-but-one render_batch call)."""
+        n = len(cameras)
+        if n == 0 or n > self.batch:
+            raise ValueError(f"1..{self.batch} cameras per batch")
+        if self._ring is None:
+            self._ring = [FrameGather(self.h, self.w, self.r.device, group=self.group, dst=self.dst, batch=self.batch)
+                          for _ in range(2)]
+        k = self._turn
+        self._turn ^= 1
+        if self._pending[k] is not None:           # the collective that last read this buffer
+            self._pending[k].wait()
+            self._pending[k] = None
+        g = self._ring[k]
+        r0, r1 = g.band
+        if r1 > r0:
+            for b, cam in enumerate(cameras):
+                self.r.render(cam, scene, config=config, out_band=g.slab[b], tile_rows=(r0, r1), sync=False, pipelined=True,
+                              timing=timing)
+            self.last_stats = self.r.sync()        # bands complete (all lanes) before the collective reads them
+        self._pending[k] = g.gather_batch(n, async_op=True)
+        return g
+
+    def finish(self):
+        """Wait for the collectives in flight."""
+        for k in (0, 1):
+            if self._pending[k] is not None:
+                self._pending[k].wait()
+                self._pending[k] = None

@@ -74,3 +74,55 @@ def test_tile_row_gather_gloo(world, res):
         p.join(180)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def _batch_worker(rank, world, port, h, w, q):
+    """Batched bands: B frames per collective, asynchronous, partial last batch (FrameGather(batch=B))."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B = 4
+        g = FrameGather(h, w, torch.device("cpu"), batch=B)
+        y0, y1 = g.band_pixel_rows
+        ok = True
+        for n in (B, 3):                                       # a full batch, then a partial one reusing the buffer
+            g.slab.fill_(-7.0)
+            for b in range(n):
+                # frame b, pixel row y: value 1000 b + y (+ channel/column pattern) -> any misplaced slab shows
+                rows = torch.arange(y0, y1, dtype=torch.float32).view(-1, 1, 1)
+                g.slab[b, : y1 - y0] = 1000.0 * b + rows + 0.001 * torch.arange(w, dtype=torch.float32).view(1, -1, 1) \
+                    + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
+            work = g.gather_batch(n, async_op=True)
+            if work is not None:
+                work.wait()
+            if rank == 0:
+                exp_rows = torch.arange(h, dtype=torch.float32).view(-1, 1, 1)
+                for b in range(n):
+                    exp = 1000.0 * b + exp_rows + 0.001 * torch.arange(w, dtype=torch.float32).view(1, -1, 1) \
+                        + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
+                    f = g.frame(b)
+                    ok = ok and tuple(f.shape) == (h, w, 3) and bool((f == exp).all())
+                v = g.frames(n)
+                ok = ok and tuple(v.shape) == (n, world, g.slab_rows, w, 3)
+            else:
+                assert g.frame(0) is None and g.frames() is None
+        if rank == 0:
+            q.put(ok)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,res", [(2, (112, 160)), (3, (100, 72))])
+def test_batched_tile_row_gather_gloo(world, res):
+    h, w = res
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, h, w, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
