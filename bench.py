@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--shard", choices=("rows", "cameras"), default="rows",
                     help="N>1: tile-row shards + RCCL gather (default, BASELINE configs[3]) or camera shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
@@ -48,7 +48,7 @@ def parse():
 
 def cpu_baseline(scene, cams, budget_s):
     """The oracle's C port (fp32 build, OpenMP over all host cores) on a bounded sample of the SAME
-    workload: whole frames of the same scene/poses until the budget is spent (>= 1, <= 4 frames)."""
+    workload: whole frames of the same scene/poses until the budget is spent (>= 1, <= 32 frames)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle_c
@@ -56,7 +56,7 @@ def cpu_baseline(scene, cams, budget_s):
     oracle_c.build()
     cores = oracle_c.max_threads()
     n, t_total = 0, 0.0
-    for cam in cams[:4]:
+    for cam in cams[:32]:
         view = (np.asarray(cam.view) @ scene.model_to_world).astype(np.float32)
         ocam = oracle_np.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
         t0 = time.perf_counter()
