@@ -842,24 +842,26 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #else
 #define SGS_PROF_EVAL(valid, J)
 #endif
-#define SGS_NEXT(JV)                                                                                   \
-    const unsigned JV = mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH; \
+#define SGS_AT(arr, T_, off) (*reinterpret_cast<const T_*>(reinterpret_cast<const char*>(arr) + (off)))
+#define SGS_NEXT(OV)                                                                                   \
+    const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 4; \
     mm &= mm - 1ull;
-#define SGS_ALPHA(J, AL, RED)                                                                          \
+// O = byte offset of the splat's slot in the staging arrays (16 B per splat in s_a and s_b)
+#define SGS_ALPHA(O, AL, RED)                                                                          \
     float AL, RED;                                                                                     \
     {                                                                                                  \
-        const float4 qa = s_a[J], qb = s_b[J];                                                         \
+        const float4 qa = SGS_AT(s_a, float4, O), qb = SGS_AT(s_b, float4, O);                         \
         const float dx = qa.x - fpx, dy = qa.y - fpy;                                                  \
         const float q2 = __builtin_fmaf(dx, __builtin_fmaf(qa.w, dy, qa.z * dx), (qb.x * dy) * dy);    \
         const bool valid = __float_as_uint(q2) < __float_as_uint(qb.z);   /* S6: power <= 0 and alpha >= 1/255 */ \
         const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
         AL = valid ? a : 0.0f;                                                                         \
         RED = qb.w;                                                                                    \
-        SGS_PROF_EVAL(valid, J)                                                                        \
+        SGS_PROF_EVAL(valid, (O) >> 4)                                                                 \
     }
-#define SGS_APPLY(J, AL, RED)                                                                          \
+#define SGS_APPLY(O, AL, RED)                                                                          \
     {                                                                                                  \
-        const ColT qc = s_c[J];                                                                        \
+        const ColT qc = SGS_AT(s_c, ColT, AUX ? (O) : ((O) >> 1));                                     \
         const float testT = __builtin_fmaf(-(AL), T, T);                                               \
         const bool stop = (int)__float_as_uint(testT) < tmin_bits;   /* ends here, or ended before (negative) */ \
         float wgt = (AL) * T;                                                                          \
@@ -868,33 +870,60 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         if (AUX) Dz = __builtin_fmaf(wgt, col_z(qc), Dz);   /* expected depth (template instantiation only) */ \
         T = stop ? -__builtin_fabsf(T) : testT;                                                        \
     }
-#define SGS_REPLAY(J, AL)                                                                              \
+#define SGS_REPLAY(O, AL)                                                                              \
     {                                                                                                  \
-        if (__ballot(Ts > 0.0f) != 0ull) last = (J) + 1u;                                              \
+        if (__ballot(Ts > 0.0f) != 0ull) last = ((O) >> 4) + 1u;                                       \
         const float testT = __builtin_fmaf(-(AL), Ts, Ts);                                             \
         Ts = (int)__float_as_uint(testT) < tmin_bits ? -__builtin_fabsf(Ts) : testT;                   \
     }
-#define SGS_BLEND_WAVE()                                                                               \
+#define SGS_TRIP(o0, o1, o2, o3)                                                                       \
+    const float Tb = T;                                                                                \
+    SGS_ALPHA(o0, al0, r0) SGS_ALPHA(o1, al1, r1) SGS_ALPHA(o2, al2, r2) SGS_ALPHA(o3, al3, r3)        \
+    SGS_APPLY(o0, al0, r0) SGS_APPLY(o1, al1, r1) SGS_APPLY(o2, al2, r2) SGS_APPLY(o3, al3, r3)        \
+    if (__ballot(T > 0.0f) == 0ull) {                                                                  \
+        /* the wave's last pixel ended in this trip: replay it to find the splat that did it */        \
+        float Ts = Tb; unsigned last = 0u;                                                             \
+        SGS_REPLAY(o0, al0) SGS_REPLAY(o1, al1) SGS_REPLAY(o2, al2) SGS_REPLAY(o3, al3)                \
+        used = base + last;                                                                            \
+        wave_done = true; break;                                                                       \
+    }
+// multi-batch groups: walk the quadrant's 64-bit masks with scalar bit scans
+#define SGS_BLEND_WAVE_SCAN()                                                                          \
     if (__ballot(T > 0.0f) != 0ull) {                                                                  \
         bool wave_done = false;                                                                        \
         for (int gw = 0; gw < 4 && !wave_done; ++gw) {                                                 \
             unsigned long long mm = uniform_u64(s_ball[par][wave][gw]);   /* splats with a footprint in this quadrant */ \
             const unsigned gwb = (unsigned)gw * 64u;                                                   \
             while (mm != 0ull) {                                                                       \
-                const float Tb = T;                                                                    \
-                SGS_NEXT(j0) SGS_NEXT(j1) SGS_NEXT(j2) SGS_NEXT(j3)                                    \
-                SGS_ALPHA(j0, al0, r0) SGS_ALPHA(j1, al1, r1) SGS_ALPHA(j2, al2, r2) SGS_ALPHA(j3, al3, r3) \
-                SGS_APPLY(j0, al0, r0) SGS_APPLY(j1, al1, r1) SGS_APPLY(j2, al2, r2) SGS_APPLY(j3, al3, r3) \
-                if (__ballot(T > 0.0f) == 0ull) {                                                      \
-                    /* the wave's last pixel ended in this trip: replay it to find the splat that did it */ \
-                    float Ts = Tb; unsigned last = 0u;                                                 \
-                    SGS_REPLAY(j0, al0) SGS_REPLAY(j1, al1) SGS_REPLAY(j2, al2) SGS_REPLAY(j3, al3)    \
-                    used = base + last;                                                                \
-                    wave_done = true; break;                                                           \
-                }                                                                                      \
+                SGS_NEXT(o0) SGS_NEXT(o1) SGS_NEXT(o2) SGS_NEXT(o3)                                    \
+                SGS_TRIP(o0, o1, o2, o3)                                                               \
             }                                                                                          \
         }                                                                                              \
         used = T > 0.0f ? base + m : used;       /* still live: the whole batch counts as examined */    \
+    }
+// single-batch groups (the common case): the wave first compacts ITS quadrant's splats into a private list of
+// staging offsets (u16, in the idle s_sorted storage) — then the loop has no bit scans on the CU-shared scalar unit,
+// no address moves, and one ragged tail per batch instead of one per 64-splat mask word
+#define SGS_BLEND_WAVE_LIST()                                                                          \
+    if (__ballot(T > 0.0f) != 0ull) {                                                                  \
+        unsigned short* const lst = reinterpret_cast<unsigned short*>(s_sorted) + (unsigned)wave * (SGS_BATCH + 8); \
+        unsigned cntq = 0;                                                                             \
+        for (int gw = 0; gw < 4; ++gw) {                                                               \
+            const unsigned long long mq = uniform_u64(s_ball[par][wave][gw]);                          \
+            if ((mq >> lane) & 1ull)                                                                   \
+                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = (unsigned short)(((unsigned)gw * 64u + (unsigned)lane) << 4); \
+            cntq += (unsigned)__popcll(mq);                                                            \
+        }                                                                                              \
+        if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned short)(SGS_BATCH << 4);   /* inert tail */ \
+        wave_lds_sync();                                                                               \
+        bool wave_done = false;                                                                        \
+        for (unsigned k = 0; k < cntq; k += 4) {                                                       \
+            const uint2 pk = *reinterpret_cast<const uint2*>(lst + k);                                 \
+            const unsigned o0 = pk.x & 0xffffu, o1 = pk.x >> 16, o2 = pk.y & 0xffffu, o3 = pk.y >> 16; \
+            SGS_TRIP(o0, o1, o2, o3)                                                                   \
+        }                                                                                              \
+        (void)wave_done;                                                                               \
+        used = T > 0.0f ? base + m : used;                                                             \
     }
 // staging: write splat J (registers A_ = x,y,ca,cb  B_ = cc,o,r,g  CBLUE = b, ZV = view depth); QMAX = log2(o / alpha_min)
 #define SGS_STAGE(J, A_, B_, CBLUE, ZV, QMAX)                                                          \
@@ -984,6 +1013,17 @@ template <> struct ColOf<true> { typedef float4 type; };
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
 #define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
 
+// orders a wave's own LDS writes before its later LDS reads by OTHER lanes of the same wave
+__device__ __forceinline__ void wave_lds_sync() {
+#ifdef SGS_HIPEMU
+    (void)__ballot(true);                  // a wave collective synchronises the wave's fibers
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     // the value is wave-uniform by construction; tell the compiler so the bit scan stays on the SALU
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
@@ -1012,7 +1052,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     float4* const s_b = s_arena + (SGS_BATCH + 1);
     ColT* const s_c = reinterpret_cast<ColT*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
-    __shared__ unsigned s_sorted[SGS_QCAP];           // the group's slots in (depth, index) order
+    __shared__ __attribute__((aligned(16))) unsigned s_sorted[SGS_QCAP];   // the group's slots in (depth, index) order; single-batch
+                                                                              // groups: the four waves' splat lists
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
@@ -1258,7 +1299,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #endif
             if (tid == 0) s_any[par ^ 1u] = 0;
             const unsigned base = lo, m = cnt;
-            SGS_BLEND_WAVE()
+            SGS_BLEND_WAVE_LIST()
             const bool still_live = __ballot(T > 0.0f) != 0ull;
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
@@ -1381,7 +1422,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
-                SGS_BLEND_WAVE()
+                SGS_BLEND_WAVE_SCAN()
                 const bool still_live = __ballot(T > 0.0f) != 0ull;
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
