@@ -902,24 +902,24 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         used = T > 0.0f ? base + m : used;       /* still live: the whole batch counts as examined */    \
     }
 // single-batch groups (the common case): the wave first compacts ITS quadrant's splats into a private list of
-// staging offsets (u16, in the idle s_sorted storage) — then the loop has no bit scans on the CU-shared scalar unit,
+// staging offsets (in the idle s_sorted storage) — then the loop has no bit scans on the CU-shared scalar unit,
 // no address moves, and one ragged tail per batch instead of one per 64-splat mask word
 #define SGS_BLEND_WAVE_LIST()                                                                          \
     if (__ballot(T > 0.0f) != 0ull) {                                                                  \
-        unsigned short* const lst = reinterpret_cast<unsigned short*>(s_sorted) + (unsigned)wave * (SGS_BATCH + 8); \
+        unsigned* const lst = s_sorted + (unsigned)wave * (SGS_BATCH + 4);                             \
         unsigned cntq = 0;                                                                             \
         for (int gw = 0; gw < 4; ++gw) {                                                               \
             const unsigned long long mq = uniform_u64(s_ball[par][wave][gw]);                          \
             if ((mq >> lane) & 1ull)                                                                   \
-                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = (unsigned short)(((unsigned)gw * 64u + (unsigned)lane) << 4); \
+                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = ((unsigned)gw * 64u + (unsigned)lane) << 4;        \
             cntq += (unsigned)__popcll(mq);                                                            \
         }                                                                                              \
-        if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned short)(SGS_BATCH << 4);   /* inert tail */ \
+        if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned)(SGS_BATCH << 4);         /* inert tail */ \
         wave_lds_sync();                                                                               \
         bool wave_done = false;                                                                        \
         for (unsigned k = 0; k < cntq; k += 4) {                                                       \
-            const uint2 pk = *reinterpret_cast<const uint2*>(lst + k);                                 \
-            const unsigned o0 = pk.x & 0xffffu, o1 = pk.x >> 16, o2 = pk.y & 0xffffu, o3 = pk.y >> 16; \
+            const uint4 pk = *reinterpret_cast<const uint4*>(lst + k);                                 \
+            const unsigned o0 = pk.x, o1 = pk.y, o2 = pk.z, o3 = pk.w;                                 \
             SGS_TRIP(o0, o1, o2, o3)                                                                   \
         }                                                                                              \
         (void)wave_done;                                                                               \
@@ -943,19 +943,20 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // (wave, splat) evaluations it let through had no pixel inside the cut-off).  This is the exact one: the minimum of
 //     q2(d) = A dx^2 + B dx dy + C dy^2        (the staged coefficients, q2 <= qmax  <=>  alpha >= alpha_min)
 // over the rectangle of a quadrant's pixel centres is 0 if the centre lies inside, else it is attained on one of
-// the four edges, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  Every comparison carries
-// a bound on the rounding error of both this evaluation and the per-pixel one, so a quadrant holding a pixel the
-// blend would accept is never rejected (a NaN anywhere accepts).
+// the four edges, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  The comparison carries a
+// bound on the rounding error of both this evaluation and the per-pixel one (a few ulps of the largest possible sum
+// of terms inside the quadrant), so a quadrant holding a pixel the blend would accept is never rejected (a NaN
+// anywhere accepts).
 __device__ __forceinline__ float sgs_edge_min(float e, float d0, float d1, float P_, float B_, float R_, float k) {
     const float t = __builtin_amdgcn_fmed3f(k * e, d0, d1);
-    const float a = P_ * e * e, b = B_ * e * t, c = R_ * t * t;
-    return (a + b + c) - 4.0e-6f * (a + fabsf(b) + c);
+    return (P_ * e + B_ * t) * e + (R_ * t) * t;
 }
 __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float B, float C, float qmax) {
     // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15]
     const float kv = __fdividef(-0.5f * B, C), kh = __fdividef(-0.5f * B, A);
     const float xs[4] = {0.0f - rx, 7.0f - rx, 8.0f - rx, 15.0f - rx};
     const float ys[4] = {0.0f - ry, 7.0f - ry, 8.0f - ry, 15.0f - ry};
+    const float aB = fabsf(B);
     unsigned bits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -963,8 +964,11 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
         const bool inside = xa <= 0.0f && xb >= 0.0f && ya <= 0.0f && yb >= 0.0f;
         const float m = fminf(fminf(sgs_edge_min(xa, ya, yb, A, B, C, kv), sgs_edge_min(xb, ya, yb, A, B, C, kv)),
                               fminf(sgs_edge_min(ya, xa, xb, C, B, A, kh), sgs_edge_min(yb, xa, xb, C, B, A, kh)));
+        // every term of any evaluation inside this quadrant (edge minima here, per-pixel q2 in the blend) is bounded
+        // by S: a few ulps of S cover the rounding of both sides of the comparison
         const float fx = fmaxf(fabsf(xa), fabsf(xb)), fy = fmaxf(fabsf(ya), fabsf(yb));      // farthest pixel of the quadrant
-        const float thr = qmax + 2.0e-6f * (A * fx * fx + fabsf(B) * fx * fy + C * fy * fy) + 1.0e-5f;
+        const float S = A * fx * fx + aB * fx * fy + C * fy * fy;
+        const float thr = qmax + 8.0e-6f * S + 1.0e-5f;
         if (inside || !(m > thr)) bits |= 1u << q;
     }
     return bits;
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     float4* const s_b = s_arena + (SGS_BATCH + 1);
     ColT* const s_c = reinterpret_cast<ColT*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
-    __shared__ __attribute__((aligned(16))) unsigned s_sorted[SGS_QCAP];   // the group's slots in (depth, index) order; single-batch
+    __shared__ __attribute__((aligned(16))) unsigned s_sorted[SGS_QCAP + 16];   // the group's slots in (depth, index) order; single-batch
                                                                               // groups: the four waves' splat lists
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
