@@ -47,9 +47,11 @@ enum {
     SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite) */
     SGS_FLAG_FULL_SORT = 1u << 3,  /* tests: order every queue completely (the production path sorts
                                       lazily and stops once a tile's pixels have all terminated) */
-    SGS_FLAG_LOOSE_CULL = 1u << 5, /* tests: inside a tile, decide which 8x8 quadrants a splat can reach from its axis-aligned
-                                    * extent only (the production path refines it with the exact ellipse/rectangle test);
-                                    * frames must be bit-identical either way */
+    SGS_FLAG_LOOSE_CULL = 1u << 5, /* tests: bin every splat over S3's reference rect (the production path bins the part of it
+                                    * the alpha >= alpha_min ellipse can reach) and decide the 8x8 quadrants inside a tile from
+                                    * the axis-aligned extent only (production: exact ellipse/rectangle test).  D, tile
+                                    * offsets and queues then are exactly the reference's; frames must be bit-identical
+                                    * either way */
     SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
                                     * the library's internal streams (a few frames in flight, each with its own
                                     * intermediates: one frame's binning fills the compute units another frame's
@@ -99,7 +101,7 @@ typedef struct sgs_config {
 typedef struct sgs_stats {
     int64_t n_gaussians;   /* N                                                          */
     int64_t n_visible;     /* N_v: survivors of culling                                  */
-    int64_t d_total;       /* D: sum of tiles touched = records sorted                   */
+    int64_t d_total;       /* D: records queued (tiles reachable by each splat; S3's rect areas under LOOSE_CULL) */
     int64_t d_fetched;     /* D_f (SGS_FLAG_STATS): records consumed before every pixel of their tile stopped */
     int64_t n_pixels;      /* pixels written by this call                                */
     int32_t n_tiles;       /* tiles in [tile_row_begin, tile_row_end)                    */

@@ -164,6 +164,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
 
     bool vis = false, big = false;
     unsigned rect01 = 0, rect23 = 0, slot = 0;         // slot = the Gaussian's ORIGINAL index
+    unsigned brect01 = 0, brect23 = 0;                 // the rect the binning kernels walk (see below)
+    int bnt = 0;
     float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
     // Cheap exclusion before the fp64 work (17-64 % of the chunks in front of the near plane end with no visible
     // lane, and visibility is dense inside a chunk, so whole waves skip): an fp32 UPPER bound of the 3-sigma radius,
@@ -242,9 +244,32 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
                 vis = true;
-                big = nt > SGS_BIG_RECT;
                 rect01 = (unsigned)x0 | ((unsigned)y0 << 16);
                 rect23 = (unsigned)x1 | ((unsigned)y1 << 16);
+                // What gets BINNED is tighter than S3's square of side 2 ceil(3 sqrt(lambda_max)): a pixel can only
+                // pass alpha >= alpha_min inside the ellipse d^T Sigma'^-1 d <= K = 2 ln(o / alpha_min), whose
+                // axis-aligned extent is sqrt(K a) x sqrt(K c) — 30 % fewer records on the indoor scenes (anisotropic
+                // and low-opacity splats), none of which any pixel could have used.  Tile t holds the pixel centres
+                // 16t .. 16t+15.  fp32 with outward padding; the reference rect stays in the splat record and is what
+                // SGS_FLAG_LOOSE_CULL (tests) bins.
+                brect01 = rect01; brect23 = rect23;
+                if (!(P.flags & 32u)) {
+                    const float Kc = 2.0f * __logf(g0.w / P.alpha_min) * 1.0001f + 1.0e-4f;
+                    if (Kc > 0.0f) {
+                        const float hx = sqrtf(Kc * (float)a) * 1.0001f + 0.02f, hy = sqrtf(Kc * (float)c) * 1.0001f + 0.02f;
+                        const float fpx = (float)px, fpy = (float)py;
+                        const float epx = 1.0e-6f * fabsf(fpx), epy = 1.0e-6f * fabsf(fpy);
+                        const float lo_x = ceilf((fpx - hx - epx - 15.0f) * (1.0f / SGS_TILE_PX)), hi_x = floorf((fpx + hx + epx) * (1.0f / SGS_TILE_PX)) + 1.0f;
+                        const float lo_y = ceilf((fpy - hy - epy - 15.0f) * (1.0f / SGS_TILE_PX)), hi_y = floorf((fpy + hy + epy) * (1.0f / SGS_TILE_PX)) + 1.0f;
+                        const int bx0 = max(x0, (int)fmaxf(lo_x, -1.0e6f)), bx1 = min(x1, (int)fminf(hi_x, 1.0e6f));
+                        const int by0 = max(y0, (int)fmaxf(lo_y, -1.0e6f)), by1 = min(y1, (int)fminf(hi_y, 1.0e6f));
+                        if (bx1 > bx0 && by1 > by0) {
+                            brect01 = (unsigned)bx0 | ((unsigned)by0 << 16); brect23 = (unsigned)bx1 | ((unsigned)by1 << 16);
+                            bnt = (bx1 - bx0) * (by1 - by0);
+                        } else { brect01 = 0u; brect23 = 0u; bnt = 0; }     // reaches no pixel: nothing to bin
+                    } else { brect01 = 0u; brect23 = 0u; bnt = 0; }         // opacity below alpha_min: never blended
+                } else bnt = nt;
+                big = bnt > SGS_BIG_RECT;
                 sx = (float)px; sy = (float)py;
                 ca = (float)(c / det); cb = (float)(-b / det); cc = (float)(a / det);
             }
@@ -283,7 +308,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         sp[1] = make_float4(cc, g0.w, r, g);
         sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
-        binrec[pos] = uint4{__float_as_uint(depth), rect01, rect23, slot};
+        binrec[pos] = uint4{__float_as_uint(depth), brect01, brect23, slot};
     }
 
 }
@@ -839,8 +864,12 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         const unsigned long long vb_ = __ballot(valid), lb_ = __ballot((valid) && T > 0.0f);           \
         ++pe_eval; pe_empty += vb_ == 0ull; pe_valid += (unsigned)__popcll(vb_); pe_useful += (unsigned)__popcll(lb_); \
     }
+#define SGS_PROF_STAGED_ALL() atomicAdd(&s_pe[4], 1u);
+#define SGS_PROF_STAGED(qb) if ((qb) != 0u) atomicAdd(&s_pe[5], 1u);
 #else
 #define SGS_PROF_EVAL(valid, J)
+#define SGS_PROF_STAGED_ALL()
+#define SGS_PROF_STAGED(qb)
 #endif
 #define SGS_AT(arr, T_, off) (*reinterpret_cast<const T_*>(reinterpret_cast<const char*>(arr) + (off)))
 #define SGS_NEXT(OV)                                                                                   \
@@ -1069,8 +1098,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
     unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
-    __shared__ unsigned s_pe[4];
-    if (threadIdx.x < 4) s_pe[threadIdx.x] = 0;
+    __shared__ unsigned s_pe[6];
+    if (threadIdx.x < 6) s_pe[threadIdx.x] = 0;
 #define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
 #else
 #define SGS_PROF_MARK(acc) do { } while (0)
@@ -1272,6 +1301,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             if (tid == 0) SGS_STAGE_DUMMY()
             if (have) {
                 const float qmax = __log2f(nB.y) + l2_inv_amin;
+                SGS_PROF_STAGED_ALL()
                 SGS_STAGE(rank, nA, nB, nC, __uint_as_float((unsigned)(mine >> 32)), qmax)
                 const float K = 1.38629436112f * qmax;     // d^T Q d <= 2 ln(o / amin)
                 const float detq = nA.z * nB.x - nA.w * nA.w;
@@ -1288,6 +1318,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     unsigned qb4 = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                    ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
                     if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits(rx, ry, (0.5f * SGS_LOG2E) * nA.z, SGS_LOG2E * nA.w, (0.5f * SGS_LOG2E) * nB.x, qmax);
+                    SGS_PROF_STAGED(qb4)
                     unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
                     const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
                     if (qb4 & 1u) atomicOr(&bw[0 * 8 + word], bit);
@@ -1447,7 +1478,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
-        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3];
+        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5];
     }
 #endif
     if (inside) {

@@ -95,7 +95,9 @@ def test_against_committed_golden_fixture(drv):
     scene, _ = onp.config1_scene(n=int(g["n"]), seed=int(g["seed"]))
     cam = onp.Camera(int(g["width"]), int(g["height"]), float(g["f"]), float(g["f"]), 64.0, 64.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    img, st = drv.render(cam, full_sort=True)
+    prod, st_prod = drv.render(cam)                                   # production: tight bin rects, lazy sort
+    img, st = drv.render(cam, full_sort=True, loose_cull=True)          # reference binning: the fixture's integer structures
+    assert (prod == img).all() and st_prod["d_total"] <= st["d_total"]
     off, ids, _, _ = drv.intermediates()
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
