@@ -18,7 +18,8 @@
 #define SGS_XCDS 8                  // sub-queues per tile: one per XCD the binning workgroups run on
 #define SGS_BIG_RECT 256            // splats touching more tiles than this are expanded by a whole workgroup
 #define SGS_BIG_CAP 65536           // entries of the per-frame big-splat list (overflow falls back to the wave path)
-#define SGS_MAX_LIVE 2048           // live chunks a binning workgroup can list (its share is n_chunks / SGS_BIN_BLOCKS)
+#define SGS_MAX_LIVE 512             // live-chunk list per pass (one sweep: 512 chunks = 32 K Gaussians per workgroup and pass); LDS is what
+                                     // decides how many composite workgroups fit beside a binning workgroup on a CU
 
 // Radix sort (S5)
 #define SGS_RADIX_BITS 8

@@ -566,6 +566,8 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
     }
 }
 
+// (~39 KB of LDS per workgroup: what a binning workgroup takes from a CU is what the composite workgroups of the
+// frames in flight cannot use)
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
                                                                const uint4* __restrict__ binrec,
                                                                const unsigned long long* __restrict__ vismask,
@@ -582,7 +584,6 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 #define SGS_BPROF(acc) do { } while (0)
 #endif
     __shared__ unsigned s_cnt[SGS_WT];
-    __shared__ unsigned short s_list[SGS_WT];
     __shared__ unsigned s_nlist;
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
@@ -605,20 +606,45 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
                      [&](const unsigned* tl, unsigned, unsigned, unsigned) { atomicAdd(&s_cnt[tl[0]], 1u); });
         __syncthreads();
-        // the touched tiles, by one sweep over the window's counters (no returning atomic in the hot loop)
-        for (unsigned i = tid; i < (unsigned)SGS_WT; i += SGS_BIN_THREADS)
-            if (s_cnt[i] != 0u) s_list[atomicAdd(&s_nlist, 1u)] = (unsigned short)i;
-        __syncthreads();
-        // flush: one device-scope atomic per touched tile; its return value is our base in the sub-queue
-        const unsigned nl = s_nlist;
+        // flush: one device-scope atomic per touched tile — its return value is our base in the tile's sub-queue.
+        // Every wave sweeps a 1/8 of the window's counters 64 at a time; the touched ones are compacted with a
+        // ballot straight into the workgroup's (tile, base) list (no LDS list of touched tiles: LDS is what limits
+        // how many composite workgroups share the CU with this kernel).
         uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
-        for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
-            const unsigned tl = s_list[i];
-            const unsigned c = s_cnt[tl];
-            s_cnt[tl] = 0;                                     // ready for the next window
-            const unsigned base = atomicAdd(&tile_count[((size_t)wr0 * P.gx + tl) * SGS_XCDS + xcd], c);
-            out[i] = make_uint2(tl, base);
+        {
+            const int lane = tid & 63, wave = tid >> 6;
+            constexpr int kPerWave = SGS_WT / (SGS_BIN_THREADS / 64);
+            for (int i0 = 0; i0 < kPerWave; i0 += 128) {           // two rounds per trip: two atomics in flight per lane
+                unsigned tl[2], c[2], pre[2], base[2];
+                unsigned long long m[2];
+                unsigned tot = 0;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    tl[u] = (unsigned)(wave * kPerWave + i0 + u * 64 + lane);
+                    c[u] = s_cnt[tl[u]];
+                    m[u] = __ballot(c[u] != 0u);
+                    pre[u] = tot + (unsigned)__popcll(m[u] & lanemask_lt(lane));
+                    tot += (unsigned)__popcll(m[u]);
+                }
+                if (tot == 0u) continue;                                // (wave-uniform)
+                unsigned k0 = 0;
+                if (lane == 0) k0 = atomicAdd(&s_nlist, tot);
+                k0 = __shfl(k0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    base[u] = 0;
+                    if (c[u] != 0u) {
+                        s_cnt[tl[u]] = 0;                             // ready for the next window
+                        base[u] = atomicAdd(&tile_count[((size_t)wr0 * P.gx + tl[u]) * SGS_XCDS + xcd], c[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (c[u] != 0u) out[k0 + pre[u]] = make_uint2(tl[u], base[u]);
+            }
         }
+        __syncthreads();
+        const unsigned nl = s_nlist;
         if (tid == 0) {
             blk_len[blockIdx.x * SGS_MAX_WINDOWS + w] = nl;
             if (w == 0) blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + blockIdx.x] = xcd;   // k_bin_emit must use the same sub-queue
