@@ -211,6 +211,39 @@ def test_3m_scene_crop_vs_oracle(drv, big_scene):
     assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="3M scene band")
 
 
+def test_4k_frame_multi_window_binning(drv):
+    """configs[4] geometry: 3840x2160 is 240 x 135 tiles = four binning windows of the LDS tile histogram.
+    Oracle-checked on a band that straddles a window boundary; size-independent properties on the full frame."""
+    from sage_gs import scenes
+    sc = scenes.make_room(300_000, seed=7)
+    cams = scenes.room_cameras(sc, 3840, 2160, n_positions=1, n_yaw=4, seed=7)
+    cam = cams[1]
+    view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
+    ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+    drv.upload(*sc.as_tuple())
+    full, st = drv.render(ocam)
+    ref_bin, st_ref = drv.render(ocam, full_sort=True, loose_cull=True)
+    assert (ref_bin == full).all() and 0 < st["d_total"] <= st_ref["d_total"]
+    off, ids, slot_ids, splats = drv.intermediates()
+    assert off[-1] == st_ref["d_total"] and len(off) == 240 * 135 + 1
+    x0, y0 = splats[:, 10] & 0xffff, splats[:, 10] >> 16
+    x1, y1 = splats[:, 11] & 0xffff, splats[:, 11] >> 16
+    assert int(((x1 - x0).astype(np.int64) * (y1 - y0)).sum()) == st_ref["d_total"]      # checksum of the binning
+    # bands (one of them cutting through window boundaries at tile rows 34 / 68 / 102) reproduce the frame
+    union = np.zeros_like(full)
+    for r0, r1 in ((0, 30), (30, 70), (70, 103), (103, 135)):
+        band, _ = drv.render(ocam, None, (r0, r1))
+        union[r0 * 16:min(r1 * 16, 2160)] = band[r0 * 16:min(r1 * 16, 2160)]
+    assert (union == full).all()
+    r0, r1 = 32, 36                                                # straddles the first window boundary
+    img, st_b = drv.render(ocam, None, (r0, r1))
+    _, st_bref = drv.render(ocam, None, (r0, r1), loose_cull=True)
+    ref, aux = oracle_c.render(*sc.as_tuple(), ocam, None, r0, r1, want="image")
+    assert st_bref["d_total"] == aux["D"] and st_b["n_visible"] == aux["n_visible"]
+    sl = slice(r0 * 16, r1 * 16)
+    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="4K band")
+
+
 def test_against_committed_golden_fixture(drv):
     """The HIP path against tests/golden/config1_golden.npz — no oracle run involved."""
     import os
