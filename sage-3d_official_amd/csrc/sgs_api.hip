@@ -79,6 +79,7 @@ struct sgs_ctx {
     Lane lanes[kMaxLanes];
     int n_lanes = 3, next_lane = 0;          // SGS_LANES=1..4
     int last_lane = 0;
+    int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
     bool morton = false;                     // Z-order the scene at upload (SGS_MORTON=1): for scenes stored in no spatial order
     const sgs_scene* last_scene = nullptr;
     int64_t rec_cap_wanted = 16ll << 20;
@@ -290,7 +291,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     ctx->slot_timed[slot] = timed;
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
-    const unsigned bin_blocks = (unsigned)std::min<int64_t>(SGS_BIN_BLOCKS, P.n_ranges);
+    const unsigned bin_blocks = (unsigned)std::min<int64_t>(ctx->bin_grid, P.n_ranges);
     if (P.n_chunks > 0)
         hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
                            scene->geom, scene->shq, L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, st);
@@ -411,6 +412,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
+    if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
         const long long v = atoll(env);
