@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
     unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
+    const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
     __shared__ unsigned s_pe[6];
     if (threadIdx.x < 6) s_pe[threadIdx.x] = 0;
 #define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
@@ -1504,7 +1505,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
-        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5];
+        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64();
     }
 #endif
     if (inside) {

@@ -15,14 +15,23 @@ for ci in (5, 20, 70, 140, 200):
     for _ in range(3):
         r.render(cams[ci], gs, timing=True)
     st = r.last_stats
-    p = r.debug_buffer(100, np.uint64).reshape(-1, 14).astype(np.float64)
-    n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit = p.T
+    p = r.debug_buffer(100, np.uint64).reshape(-1, 16).astype(np.float64)
+    n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1 = p.T
     clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
     print(f"cam {ci}: render {st['ms']['render']*1e3:.0f} us  D={st['d_total']} D_f={st['d_fetched']} | tile-cycles sum: part {part.sum()/1e6:.1f}M sort {sort.sum()/1e6:.1f}M blend {blend.sum()/1e6:.1f}M total {tot.sum()/1e6:.1f}M | "
           f"groups/tile {ng.mean():.2f} batches/tile {nb.mean():.2f} | max tile total {tot.max()/1e3:.0f}k cyc (n={int(n[tot.argmax()])}) | span {(t0+tot).max()-t0.min():.0f} cyc")
     print(f"     blend evaluations (wave x splat): {ev.sum()/1e6:.2f}M = {ev.sum()/max(1,st['d_fetched']):.2f} per consumed record; no pixel inside the cut-off: "
           f"{100*emp.sum()/max(1,ev.sum()):.1f} %; lanes inside the cut-off {100*val.sum()/max(1,64*ev.sum()):.1f} %, of them on live pixels {100*use.sum()/max(1,val.sum()):.1f} %")
     print(f"     staged splats (single-batch groups): {stg.sum()/1e6:.2f}M, reaching at least one quadrant: {100*hit.sum()/max(1,stg.sum()):.1f} %  (D = {st['d_total']/1e6:.2f}M records, D_f = {st['d_fetched']/1e6:.2f}M)")
+    # occupancy over the kernel's span: how many tiles (workgroups) are in flight
+    ev = np.concatenate([np.stack([rt0, np.ones_like(rt0)], 1), np.stack([rt1, -np.ones_like(rt0)], 1)])
+    ev = ev[np.argsort(ev[:, 0])]
+    act = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0], append=ev[-1, 0]); span = ev[-1, 0] - ev[0, 0]
+    peak = act.max()
+    print(f"     workgroups in flight: peak {int(peak)}, time-average {float((act * dt).sum() / span):.0f}; share of the span with < 50 % of the peak: "
+          f"{100 * dt[act < 0.5 * peak].sum() / span:.1f} %, < 90 %: {100 * dt[act < 0.9 * peak].sum() / span:.1f} %  (span {span / 100:.0f} us)")
+    q = np.quantile(rt1 - ev[0, 0], [0.5, 0.9, 0.99, 1.0]) / 100
+    print(f"     tiles finished by: 50 % {q[0]:.0f} us, 90 % {q[1]:.0f} us, 99 % {q[2]:.0f} us, all {q[3]:.0f} us; tiles started after 50 % of the span: {100 * (rt0 - ev[0, 0] > 0.5 * span).mean():.1f} %")
     order = np.argsort(-tot)[:5]
     for o in order:
         print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])}")
