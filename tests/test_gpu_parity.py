@@ -244,6 +244,57 @@ def test_4k_frame_multi_window_binning(drv):
     assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="4K band")
 
 
+def test_culling_never_changes_a_pixel_stress(drv):
+    """The tight bin rects and the exact quadrant test may only remove work no pixel can see: production frames must be
+    bit-identical to reference-binning frames over a sweep of poses and over splats built to sit on every edge of
+    those tests (needle-thin diagonal ellipses, opacities straddling alpha_min, splats larger than the image,
+    centres on tile and quadrant borders)."""
+    import torch
+    from sage_gs import Camera, Gaussians, scenes
+    # (a) a sweep through the indoor scene
+    sc = scenes.make_room(1_000_000, seed=11)
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=3, n_yaw=8, seed=11)
+    scene = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    for cam in cams:
+        prod = drv.r.render(cam, scene).clone()
+        ref = drv.r.render(cam, scene, loose_cull=True)
+        assert (prod == ref).all()
+    scene.free()
+    # (b) adversarial splats in front of a fixed camera
+    rng = np.random.default_rng(5)
+    n = 60_000
+    means = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(0.5, 9, n)], 1).astype(np.float32)
+    kind = rng.integers(0, 5, n)
+    s = np.exp(rng.uniform(np.log(0.002), np.log(0.05), (n, 3)))
+    s[kind == 0, 0] *= 60.0                                            # needles
+    s[kind == 1] *= np.array([40.0, 0.2, 1.0])                         # thin sheets
+    s[kind == 2] *= 30.0                                               # very large
+    quats = rng.normal(size=(n, 4)).astype(np.float32)
+    opac = rng.uniform(0.0, 1.0, n)
+    opac[kind == 3] = rng.uniform(0.9 / 255.0, 1.3 / 255.0, (kind == 3).sum())     # straddling alpha_min
+    opac[kind == 4] = rng.uniform(0.985, 1.0, (kind == 4).sum())                    # straddling alpha_max
+    # some centres exactly on tile / quadrant borders of the 640x480 image (fx = 400: x = (px - 320) z / 400)
+    sel = rng.choice(n, 4000, replace=False)
+    pxs = rng.choice([0, 7.5, 8, 15.5, 16, 31.5, 320, 639], 4000); pys = rng.choice([0, 7.5, 8, 15.5, 16, 239.5, 479], 4000)
+    means[sel, 0] = ((pxs + 0.5 - 320.0) * means[sel, 2] / 400.0).astype(np.float32)
+    means[sel, 1] = ((pys + 0.5 - 240.0) * means[sel, 2] / 400.0).astype(np.float32)
+    sh = (rng.normal(size=(n, 16, 3)) * 0.3).astype(np.float32); sh[:, 0] += 1.0
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to("cuda:0")
+    scene = drv.r.upload(Gaussians(t(means), t(s), t(quats), t(opac), t(sh), 3))
+    for yaw in (0.0, 0.35, -0.6):
+        c, si = np.cos(yaw), np.sin(yaw)
+        V = np.eye(4); V[:3, :3] = np.array([[c, 0, -si], [0, 1, 0], [si, 0, c]])
+        cam = Camera(640, 480, 400.0, 400.0, 320.0, 240.0, V)
+        prod = drv.r.render(cam, scene).clone()
+        st = drv.r.last_stats
+        ref = drv.r.render(cam, scene, loose_cull=True)
+        st_ref = drv.r.last_stats
+        assert (prod == ref).all(), f"yaw {yaw}: {(prod != ref).sum().item()} values differ"
+        assert st["n_visible"] == st_ref["n_visible"] and st["d_total"] < st_ref["d_total"]
+        assert torch.isfinite(prod).all()
+    scene.free()
+
+
 def test_against_committed_golden_fixture(drv):
     """The HIP path against tests/golden/config1_golden.npz — no oracle run involved."""
     import os
