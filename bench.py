@@ -233,19 +233,24 @@ def main():
                              "ms_alone": iso_ms[n] / frames_here}
             dom = max(STAGE_NAMES, key=lambda n: ms[n])
             ach = stages[dom]["GBps"] or 0.0
-            traffic = None
+            traffic = valu_busy = lds_conf = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(dom)
+                try:                         # PMC passes of the same frames (scripts/gpu_round_profile.sh), committed
+                    tj = json.load(open(tpath))
+                    traffic = tj.get(dom)
+                    valu_busy = tj.get("_valu_busy", {}).get(dom)
+                    lds_conf = tj.get("_lds_bank_conflict_share", {}).get(dom)
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                               "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf,
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
                                "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
                                "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if (pipelined or batched_rows) else 1),
-                               "note": "ms = HIP-event duration inside the timed region (frames overlap when "
+                               "note": "the dominant kernel is VALU-issue-bound, not HBM-bound (valu_busy = share of its cycles "
+                                       "with the vector ALU executing, from the committed PMC passes); ms = HIP-event duration inside the timed region (frames overlap when "
                                        "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
                                        "with nothing else running"}
         if world == 1 and not args.no_cpu_baseline:
