@@ -32,25 +32,56 @@ __device__ __forceinline__ unsigned xcc_id() {
     return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & (SGS_XCDS - 1);
 }
 
+// Wave-wide scan / reductions.  On the GPU they are DPP sequences (row shifts inside the 16-lane rows, then the two
+// row broadcasts): pure VALU, where __shfl_* would be ds_bpermute — six DEPENDENT round-trips through the LDS
+// pipe per call, and these sit in the partition of every tile and in the binning walk of every chunk.
+#ifdef SGS_HIPEMU
 __device__ __forceinline__ unsigned wave_incl_scan(unsigned x, int lane) {
-#pragma unroll
     for (int d = 1; d < SGS_WAVE; d <<= 1) {
         unsigned v = __shfl_up(x, d);
         if (lane >= d) x += v;
     }
     return x;
 }
-
 __device__ __forceinline__ unsigned wave_max(unsigned x) {
-#pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v > x ? v : x; }
     return x;
 }
 __device__ __forceinline__ unsigned wave_min(unsigned x) {
-#pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v < x ? v : x; }
     return x;
 }
+__device__ __forceinline__ unsigned wave_sum(unsigned x) {
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
+    return x;
+}
+#else
+// one step: combine x with the value `ctrl` selects; lanes whose source does not exist (or whose row is masked
+// off) combine with the identity
+#define SGS_DPP_STEP(OP, ID, CTRL, ROWMASK)                                                            \
+    x = OP(x, (unsigned)__builtin_amdgcn_update_dpp((int)(ID), (int)x, CTRL, ROWMASK, 0xf, false));
+#define SGS_DPP_SCAN(OP, ID)                                                                           \
+    SGS_DPP_STEP(OP, ID, 0x111, 0xf) SGS_DPP_STEP(OP, ID, 0x112, 0xf)   /* row_shr:1, row_shr:2 */      \
+    SGS_DPP_STEP(OP, ID, 0x114, 0xf) SGS_DPP_STEP(OP, ID, 0x118, 0xf)   /* row_shr:4, row_shr:8 */      \
+    SGS_DPP_STEP(OP, ID, 0x142, 0xa)                                    /* row_bcast:15 -> rows 1, 3 */ \
+    SGS_DPP_STEP(OP, ID, 0x143, 0xc)                                    /* row_bcast:31 -> rows 2, 3 */
+__device__ __forceinline__ unsigned sgs_op_add(unsigned a, unsigned b) { return a + b; }
+__device__ __forceinline__ unsigned sgs_op_max(unsigned a, unsigned b) { return a > b ? a : b; }
+__device__ __forceinline__ unsigned sgs_op_min(unsigned a, unsigned b) { return a < b ? a : b; }
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x, int) { SGS_DPP_SCAN(sgs_op_add, 0u) return x; }
+__device__ __forceinline__ unsigned wave_max(unsigned x) {
+    SGS_DPP_SCAN(sgs_op_max, 0u)
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ unsigned wave_min(unsigned x) {
+    SGS_DPP_SCAN(sgs_op_min, 0xffffffffu)
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ unsigned wave_sum(unsigned x) {
+    SGS_DPP_SCAN(sgs_op_add, 0u)
+    return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
@@ -460,12 +491,6 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     }
     if (vis) atomicAdd(&lc.n_vis, vis);
     __syncthreads();
-}
-
-__device__ __forceinline__ unsigned wave_sum(unsigned x) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    return x;
 }
 
 // Bins the records of the listed chunks that fall into tile rows [wr0, wr1) of the current window.
@@ -1123,6 +1148,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
+    unsigned long long pt_rank = 0, pt_bar1 = 0, pt_stage = 0;     // sub-phases of the single-batch path (pt_sort = the rest: barrier 2)
     unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
     const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
     __shared__ unsigned s_pe[6];
@@ -1244,11 +1270,19 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
         else {
-            hi = s_ne_end[e1];
-            // (a group that starts inside the resident window also ends inside it: buckets are placed once)
-            while (e1 + 1 < n_ne && s_ne_end[e1 + 1] - lo <= SGS_GROUP && (lo >= win_hi || s_ne_end[e1 + 1] <= win_hi)) {
-                ++e1; hi = s_ne_end[e1];
+            // The group = as many whole buckets from e0 on as stay within SGS_GROUP records (a group that starts inside
+            // the resident window also ends inside it: buckets are placed once); at least one bucket.  s_ne_end is
+            // increasing, so the buckets that fit are a prefix: every wave counts them with independent reads and
+            // ballots — two LDS round-trips instead of one per bucket.
+            const unsigned limit = lo < win_hi ? min(lo + (unsigned)SGS_GROUP, win_hi) : lo + (unsigned)SGS_GROUP;
+            unsigned fit = 0;
+#pragma unroll
+            for (int r = 0; r < SGS_NB / 64; ++r) {
+                const unsigned e = e0 + (unsigned)(r * 64 + lane);
+                fit += (unsigned)__popcll(__ballot(e < n_ne && s_ne_end[e] <= limit));
             }
+            e1 = e0 + (fit ? fit - 1u : 0u);
+            hi = s_ne_end[e1];
             e_next = e1 + 1;
         }
         const unsigned cnt = hi - lo;
@@ -1256,8 +1290,13 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         if (cnt <= SGS_QCAP && hi > win_hi) {
             // long queue, group not resident: slide the window to start at this group and take as many whole
             // buckets as fit.  Each bucket is placed exactly once, so the partition cursors stay valid.
-            unsigned ew = e1;
-            while (ew + 1 < n_ne && s_ne_end[ew + 1] - lo <= SGS_QCAP) ++ew;
+            unsigned wfit = 0;                                        // same prefix count, for the window's capacity
+#pragma unroll
+            for (int r = 0; r < SGS_NB / 64; ++r) {
+                const unsigned e = e1 + 1u + (unsigned)(r * 64 + lane);
+                wfit += (unsigned)__popcll(__ballot(e < n_ne && s_ne_end[e] - lo <= (unsigned)SGS_QCAP));
+            }
+            const unsigned ew = e1 + wfit;
             const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[ew];
             win_lo = lo; win_hi = s_ne_end[ew];
             for (unsigned i0 = 0; i0 < n; i0 += 1024) {
@@ -1286,11 +1325,12 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
             const unsigned par = it & 1u;
             const bool have = (unsigned)tid < cnt;
             const unsigned long long mine = have ? kk[tid] : ~0ull;
-            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f;
-            if (have) {
-                const float4* sp = reinterpret_cast<const float4*>(splats + (unsigned)mine);
-                nA = sp[0]; nB = sp[1]; nC = sp[2].x;
-            }
+            // UNCONDITIONAL loads (lanes without a record read slot 0 and never use it): inside `if (have)` the
+            // compiler has to merge the loaded registers with their defaults at the end of the branch, i.e. wait for
+            // the gather right here — instead of behind the ranking below, which is what hides its latency
+            const float4* const sp = reinterpret_cast<const float4*>(splats + (have ? (unsigned)mine : 0u));
+            const float4 nA = sp[0], nB = sp[1];
+            const float nC = sp[2].x;
             if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // 4 quadrants x 4 x 64 bits
             // Rank of my record inside the group.  The resident queue is bucket-contiguous (MSD partition) and the
             // buckets are disjoint depth ranges, so rank = (records of shallower buckets) + (rank inside MY bucket):
@@ -1303,14 +1343,15 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 bbeg = bk ? s_bcnt[bk - 1] : 0u;            // cursors after the scatter = bucket ends = next bucket's start
                 blen = s_bcnt[bk] - bbeg;
             }
-            const unsigned maxlen = wave_max(blen);
-            if (parted && maxlen * 2u <= cnt && maxlen <= SGS_RANK_BUCKET_MAX) {
+            if (parted && __ballot(blen * 2u > cnt || blen > SGS_RANK_BUCKET_MAX) == 0ull) {
                 const unsigned long long* bq = s_q + (bbeg - win_lo);
                 unsigned r = 0;
-                for (unsigned t = 0; t < maxlen; t += 2) {
-                    const unsigned long long x0 = bq[t], x1 = bq[t + 1];     // (reads past a short bucket are masked out)
-                    r += (t < blen && x0 < mine) ? 1u : 0u;
-                    r += (t + 1u < blen && x1 < mine) ? 1u : 0u;
+                for (unsigned t = 0; __ballot(t < blen) != 0ull; t += 4) {       // four independent reads per trip
+                    const unsigned long long x0 = bq[t], x1 = bq[t + 1], x2 = bq[t + 2], x3 = bq[t + 3];   // (reads past a
+                    r += (t < blen && x0 < mine) ? 1u : 0u;                                               //  short bucket
+                    r += (t + 1u < blen && x1 < mine) ? 1u : 0u;                                          //  are masked out)
+                    r += (t + 2u < blen && x2 < mine) ? 1u : 0u;
+                    r += (t + 3u < blen && x3 < mine) ? 1u : 0u;
                 }
                 rank = (bbeg - lo) + r;
             } else if ((unsigned)wave * 64u < cnt) {
@@ -1323,7 +1364,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     for (int u = 0; u < 8; ++u) rank += x[u] < mine ? 1u : 0u;
                 }
             }
+            SGS_PROF_MARK(pt_rank);
             __syncthreads();             // every lane has read its record: the staging arena may be written
+            SGS_PROF_MARK(pt_bar1);
                                          // (s_q and the arena are distinct, but s_ball was just cleared)
             if (tid == 0) SGS_STAGE_DUMMY()
             if (have) {
@@ -1354,6 +1397,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     if (qb4 & 8u) atomicOr(&bw[3 * 8 + word], bit);
                 }
             }
+            SGS_PROF_MARK(pt_stage);
             __syncthreads();             // batch staged in depth order
             SGS_PROF_MARK(pt_sort);
 #ifdef SGS_TILE_PROF
@@ -1361,7 +1405,11 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 #endif
             if (tid == 0) s_any[par ^ 1u] = 0;
             const unsigned base = lo, m = cnt;
+#ifndef SGS_EXPERIMENT_NO_BLEND
             SGS_BLEND_WAVE_LIST()
+#else
+            T = -1.0f;                       // timing experiment: everything but the blend loop
+#endif
             const bool still_live = __ballot(T > 0.0f) != 0ull;
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
@@ -1433,9 +1481,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
-            float4 nA = make_float4(0.f, 0.f, 0.f, 0.f), nB = nA; float nC = 0.f, nD = 0.f;
-            if ((unsigned)tid < min((unsigned)SGS_BATCH, cnt)) {
-                const float4* sp = reinterpret_cast<const float4*>(splats + gv[tid]);
+            float4 nA, nB; float nC, nD;
+            {   // unconditional (see the single-batch path): lanes past the batch read the group's first splat
+                const float4* sp = reinterpret_cast<const float4*>(splats + gv[(unsigned)tid < min((unsigned)SGS_BATCH, cnt) ? tid : 0]);
                 nA = sp[0]; nB = sp[1];
                 const float4 c4 = sp[2];
                 nC = c4.x; nD = c4.y;                      // .y = fp32 view depth (the sort key's bits)
@@ -1476,8 +1524,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 }
                 // prefetch the next batch of this group (loads stay in flight across the blend loop)
                 const unsigned ngb = gb + SGS_BATCH;
-                if (ngb < cnt && (unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb)) {
-                    const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + tid]);
+                if (ngb < cnt) {                 // (uniform) lanes past the next batch re-read its first splat
+                    const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + ((unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb) ? tid : 0)]);
                     nA = sp[0]; nB = sp[1];
                     const float4 c4 = sp[2];
                     nC = c4.x; nD = c4.y;
@@ -1505,7 +1553,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
         unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
-        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64();
+        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = 0;
     }
 #endif
     if (inside) {
