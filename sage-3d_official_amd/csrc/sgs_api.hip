@@ -52,7 +52,8 @@ struct Lane {
     uint4* binrec = nullptr;                 // per slot: depth bits, rect01, rect23 (dense copy for the binning kernels)
     // per-tile scratch
     int tile_cap = 0;
-    unsigned *tile_count = nullptr, *tile_offset = nullptr, *tile_order = nullptr;
+    unsigned *tile_count = nullptr, *tile_offset = nullptr;
+    uint4* tile_order = nullptr;                     // render order: (tile, first record, queue length) per position
     unsigned long long* tile_prof = nullptr;         // profiling build: 8 words per tile
     unsigned long long* bin_prof = nullptr;          // profiling build: 8 words per binning workgroup
     // binning scratch: per-workgroup (tile, base) lists
@@ -315,10 +316,10 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
         if (out_aux)
-            hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid), dim3(256), 0, stream, P, L.tile_offset, L.tile_order,
+            hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid), dim3(256), 0, stream, P, L.tile_order,
                                L.rec, L.alt, L.part, L.sorted_out, L.splats, out_rgb, out_aux, st, L.tile_prof);
         else
-            hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid), dim3(256), 0, stream, P, L.tile_offset, L.tile_order,
+            hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid), dim3(256), 0, stream, P, L.tile_order,
                                L.rec, L.alt, L.part, L.sorted_out, L.splats, out_rgb, out_aux, st, L.tile_prof);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));

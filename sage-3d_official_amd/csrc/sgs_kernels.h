@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
                                                                 unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
-                                                                unsigned* __restrict__ tile_order,
+                                                                uint4* __restrict__ tile_order,
                                                                 FrameStatus* __restrict__ st) {
     __shared__ unsigned s_wsum[2][SGS_SCAN_THREADS / SGS_WAVE];
     __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
         const unsigned b = tile_offset[(size_t)t * SGS_XCDS];
         const unsigned e = (t + 1 < T) ? tile_offset[(size_t)(t + 1) * SGS_XCDS] : carry;
         const unsigned c = e - b;
-        tile_order[atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u)] = (unsigned)t;
+        // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
+        tile_order[atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u)] = uint4{(unsigned)t, b, c, 0u};
     }
     if (tid == 0) {
         unsigned tmax = 0;
@@ -1117,8 +1118,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 
 template <bool AUX>
 __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
-                                                     const unsigned* __restrict__ tile_offset,
-                                                     const unsigned* __restrict__ tile_order,
+                                                     const uint4* __restrict__ tile_order,
                                                      const unsigned long long* __restrict__ rec,
                                                      unsigned long long* alt, unsigned long long* part,
                                                      unsigned* sorted_out,
@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     // blocks take the tiles longest queue first (k_tile_scan's order)
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
     if (blockIdx.x >= ntiles) return;    // workgroup-uniform
-    const unsigned tile = tile_order[blockIdx.x];
+    const uint4 job = tile_order[blockIdx.x];        // (tile, first record, queue length) from k_tile_scan
+    const unsigned tile = job.x;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
     const unsigned py = tile_y * 16u + (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
@@ -1175,8 +1176,7 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
     const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
 
-    const unsigned beg = tile_offset[(size_t)tile * SGS_XCDS];              // the tile's 8 per-XCD sub-queues are adjacent
-    const unsigned n = tile_offset[(size_t)tile * SGS_XCDS + SGS_XCDS] - beg;
+    const unsigned beg = job.y, n = job.z;            // the tile's 8 per-XCD sub-queues are adjacent: one queue
     float T = inside ? 1.0f : -1.0f;     // transmittance; negative = finished (or outside the image): takes nothing more
     float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
