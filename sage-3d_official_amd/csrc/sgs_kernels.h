@@ -1094,7 +1094,9 @@ template <> struct ColOf<true> { typedef float4 type; };
 #define SGS_BATCH 256
 #define SGS_NB 256
 #define SGS_BUCKET_SHIFT 18
+#ifndef SGS_GROUP
 #define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
+#endif
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
 #define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
 
