@@ -102,3 +102,40 @@ def test_against_committed_golden_fixture(drv):
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
     assert_frame_close(img, g["image"], g["margin"], cmax=2.5, what="golden config1")
+
+
+def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
+    """Host logic of the frames in flight (sgs_api.hip): SGS_FLAG_PIPELINED frames and sgs_render_batch rotate over the
+    context's lanes (own intermediates each; streams are synchronous under the emulator) and must produce the frames
+    that ordinary one-at-a-time rendering produces; ordinary frames mixed in use lane 0."""
+    import ctypes as C
+    from sage_gs import _capi
+    scene, _ = onp.config1_scene(n=3000, seed=4)
+    drv.upload(*scene)
+    lib, ctx = drv.lib, drv.ctx
+    cams = []
+    for k in range(5):
+        V = np.eye(4, dtype=np.float32); V[0, 3] = 0.15 * k - 0.3
+        cams.append(onp.Camera(96, 80, 70.0, 70.0, 48.0, 40.0, V))
+    seq = [drv.render(c)[0].copy() for c in cams]
+    outs = [np.full((80, 96, 3), -1.0, np.float32) for _ in cams]
+    cfg = lib.default_config()
+    cfg.flags = _capi.FLAG_ASYNC | _capi.FLAG_PIPELINED
+    for c, o in zip(cams, outs):
+        cc = _capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy, np.asarray(c.view, np.float32).reshape(4, 4).tolist())
+        lib.check(lib.sgs_render(ctx, drv.scene, C.byref(cc), C.byref(cfg), 0, -1, o.ctypes.data, None, None), ctx)
+    plain = drv.render(cams[2])[0]                       # an ordinary frame while pipelined ones are pending
+    st = _capi.SgsStats()
+    lib.check(lib.sgs_frame_sync(ctx, C.byref(st)), ctx)
+    assert (plain == seq[2]).all()
+    for a, b in zip(seq, outs):
+        assert (a == b).all()
+    # the batch entry point (always pipelined)
+    arr = (_capi.SgsCamera * len(cams))(*[_capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy,
+                                                            np.asarray(c.view, np.float32).reshape(4, 4).tolist()) for c in cams])
+    batch = np.zeros((len(cams), 80, 96, 3), np.float32)
+    stats = (_capi.SgsStats * len(cams))()
+    cfg2 = lib.default_config()
+    lib.check(lib.sgs_render_batch(ctx, drv.scene, arr, len(cams), C.byref(cfg2), 0, -1, batch.ctypes.data, stats, None), ctx)
+    for i in range(len(cams)):
+        assert (batch[i] == seq[i]).all() and stats[i].d_total > 0
