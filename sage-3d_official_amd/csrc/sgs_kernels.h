@@ -906,8 +906,12 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // dummy splat at index SGS_BATCH.
 #ifdef SGS_HIPEMU
 #define SGS_EXP2(x) exp2f(x)
+#define SGS_RCP(x) (1.0f / (x))
+#define SGS_SQRT(x) sqrtf(x)
 #else
 #define SGS_EXP2(x) __builtin_amdgcn_exp2f(x)
+#define SGS_RCP(x) __builtin_amdgcn_rcpf(x)         // 1 ulp; every use below is padded outward
+#define SGS_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #endif
 #define SGS_LOG2E 1.44269504088896341f
 #ifdef SGS_TILE_PROF   // profiling build: how many (wave, splat) evaluations had no pixel inside the alpha cut-off
@@ -1034,7 +1038,7 @@ __device__ __forceinline__ float sgs_edge_min(float e, float d0, float d1, float
 }
 __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float B, float C, float qmax) {
     // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15]
-    const float kv = __fdividef(-0.5f * B, C), kh = __fdividef(-0.5f * B, A);
+    const float kv = (-0.5f * B) * SGS_RCP(C), kh = (-0.5f * B) * SGS_RCP(A);   // (an ulp off the minimiser changes the minimum by O(ulp^2))
     const float xs[4] = {0.0f - rx, 7.0f - rx, 8.0f - rx, 15.0f - rx};
     const float ys[4] = {0.0f - ry, 7.0f - ry, 8.0f - ry, 15.0f - ry};
     const float aB = fabsf(B);
@@ -1380,9 +1384,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                 if (K > 0.0f) {
                     float hx = 3.0e38f, hy = 3.0e38f;
                     if (detq > 1.0e-12f * nA.z * nB.x) {
-                        const float inv = K / detq;
-                        hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
-                        hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
+                        const float inv = K * SGS_RCP(detq);
+                        hx = SGS_SQRT(inv * nB.x) * 1.01f + 0.5f;
+                        hy = SGS_SQRT(inv * nA.z) * 1.01f + 0.5f;
                     }
                     const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
                     const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
@@ -1507,9 +1511,9 @@ __global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
                     if (K > 0.0f) {
                         float hx = 3.0e38f, hy = 3.0e38f;
                         if (detq > 1.0e-12f * nA.z * nB.x) {   // otherwise fp32 cannot bound it: keep everywhere
-                            const float inv = K / detq;
-                            hx = sqrtf(inv * nB.x) * 1.01f + 0.5f;
-                            hy = sqrtf(inv * nA.z) * 1.01f + 0.5f;
+                            const float inv = K * SGS_RCP(detq);
+                            hx = SGS_SQRT(inv * nB.x) * 1.01f + 0.5f;
+                            hy = SGS_SQRT(inv * nA.z) * 1.01f + 0.5f;
                         }
                         const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
                         const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
