@@ -225,8 +225,9 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         slot = __float_as_uint(g2.w);
         // S2: Sigma = R S S^T R^T
         const double qw0 = g1.w, qx0 = g2.x, qy0 = g2.y, qz0 = g2.z;
-        const double qn = sqrt(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
-        const double w = qw0 / qn, x = qx0 / qn, y = qy0 / qn, z = qz0 / qn;
+        // (an fp64 division expands to ~35 instructions: one reciprocal per denominator, then multiplies)
+        const double iqn = 1.0 / sqrt(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
+        const double w = qw0 * iqn, x = qx0 * iqn, y = qy0 * iqn, z = qz0 * iqn;
         const double s0 = g1.x, s1 = g1.y, s2 = g1.z;
         const double M00 = (1 - 2 * (y * y + z * z)) * s0, M01 = (2 * (x * y - w * z)) * s1, M02 = (2 * (x * z + w * y)) * s2;
         const double M10 = (2 * (x * y + w * z)) * s0, M11 = (1 - 2 * (x * x + z * z)) * s1, M12 = (2 * (y * z - w * x)) * s2;
@@ -241,10 +242,12 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const double fx = P.fx, fy = P.fy;
         const double limx = (double)P.clamp * (0.5 * (double)P.width / fx);
         const double limy = (double)P.clamp * (0.5 * (double)P.height / fy);
-        const double txc = fmin(limx, fmax(-limx, tx / tz)) * tz;
-        const double tyc = fmin(limy, fmax(-limy, ty / tz)) * tz;
-        const double j00 = fx / tz, j02 = -fx * txc / (tz * tz);
-        const double j11 = fy / tz, j12 = -fy * tyc / (tz * tz);
+        const double itz = 1.0 / tz;
+        const double xz = tx * itz, yz = ty * itz;
+        const double txc = fmin(limx, fmax(-limx, xz)) * tz;
+        const double tyc = fmin(limy, fmax(-limy, yz)) * tz;
+        const double j00 = fx * itz, j02 = -fx * txc * (itz * itz);
+        const double j11 = fy * itz, j12 = -fy * tyc * (itz * itz);
         const double T00 = j00 * (double)P.view[0] + j02 * (double)P.view[8];
         const double T01 = j00 * (double)P.view[1] + j02 * (double)P.view[9];
         const double T02 = j00 * (double)P.view[2] + j02 * (double)P.view[10];
@@ -266,8 +269,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const double mid = 0.5 * (a + c);
             const double lam = mid + sqrt(fmax(0.1, mid * mid - det));
             const double radius = ceil(3.0 * sqrt(lam));
-            const double px = fx * tx / tz + (double)P.cx - 0.5;
-            const double py = fy * ty / tz + (double)P.cy - 0.5;
+            const double px = fx * xz + (double)P.cx - 0.5;
+            const double py = fy * yz + (double)P.cy - 0.5;
             const int x0 = tile_clamp((px - radius) / SGS_TILE_PX, 0, P.gx);
             const int x1 = tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gx);
             const int y0 = tile_clamp((py - radius) / SGS_TILE_PX, P.row_begin, P.row_end);
@@ -302,7 +305,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                 } else bnt = nt;
                 big = bnt > SGS_BIG_RECT;
                 sx = (float)px; sy = (float)py;
-                ca = (float)(c / det); cb = (float)(-b / det); cc = (float)(a / det);
+                const double idet = 1.0 / det;
+                ca = (float)(c * idet); cb = (float)(-b * idet); cc = (float)(a * idet);
             }
         }
     }
@@ -323,8 +327,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     if (vis) {
         // S1: view direction in model space (fp64 difference, fp32 polynomial)
         const double dx = mx - P.campos[0], dy = my - P.campos[1], dz = mz - P.campos[2];
-        const double dn = sqrt(dx * dx + dy * dy + dz * dz);
-        const float ux = (float)(dx / dn), uy = (float)(dy / dn), uz = (float)(dz / dn);
+        const double idn = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const float ux = (float)(dx * idn), uy = (float)(dy * idn), uz = (float)(dz * idn);
         const float4* row0 = shq + (chunk * P.sh_rows) * SGS_WAVE + lane;
         float r, g, b;
         switch (P.sh_degree) {
