@@ -9,8 +9,10 @@ A "step" is one frame: one pass of the hot path (SH -> projection -> AABB -> bin
 HBM (uploaded once per scene, as the reference loads a stage once — generate_images.py:320-327).
 Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on — a ~3 M-Gaussian
 synthetic InteriorGS-like scene, SH degree 3, 1920x1080 (InteriorGS itself is not available offline).
-N > 1: the frame is sharded by tile row across the ranks and gathered to rank 0 over RCCL/xGMI
-(configs[3]); total work per frame is fixed, so scaling is "strong".
+N > 1 (one process per GPU, scene replicated — 708 MB): the frames of the sweep are independent units, so a step is
+one pose PER GPU with no data-path collective ("weak" scaling: N*K frames in the timed region).  BASELINE configs[3],
+every frame sharded by tile row over the ranks and gathered to rank 0 over RCCL/xGMI ("strong"), is timed right
+afterwards and reported under `also_measured` (`--shard rows` makes it the headline instead).
 
 Prints ONE JSON line on rank 0 with the contract's fields plus `roofline` (dominant kernel, measured
 live with HIP events on the launch stream) and `cpu_baseline` (the oracle's C port on the host cores).
@@ -35,8 +37,13 @@ def parse():
     ap.add_argument("--gaussians", type=int, default=3_000_000, help="scene size (default: BASELINE configs[2])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--shard", choices=("rows", "cameras"), default="rows",
-                    help="N>1: tile-row shards + RCCL gather (default, BASELINE configs[3]) or camera shards")
+    ap.add_argument("--shard", choices=("rows", "cameras"), default="cameras",
+                    help="N>1 headline: camera shards (default: one pose per GPU per step, no data-path collective, weak "
+                         "scaling) or tile-row shards + RCCL gather (BASELINE configs[3], strong scaling); the other "
+                         "mode is timed afterwards and reported under 'also_measured'")
+    ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
+    ap.add_argument("--secondary-timeout", type=float, default=180.0,
+                    help="N>1: seconds after which a stuck second measurement is abandoned and the headline printed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
@@ -107,29 +114,11 @@ def main():
     K, W = args.steps, args.warmup
     timing = not args.no_events
 
-    sharded = ShardedRenderer(r, args.height, args.width) if (world > 1 and args.shard == "rows") else None
-    # frames of the sweep are independent: up to four are in flight, each with its own output buffer
-    pipelined = not args.no_pipeline and sharded is None
+    pipelined = not args.no_pipeline
+    # frames of the sweep are independent: up to four are in flight per GPU, each with its own output buffer
     frames = [torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
     frame = frames[0]
-
-    issued = [0]
-
-    def step(i, timed):
-        cam = cams[i % len(cams)]
-        if sharded is not None:
-            r0, r1 = sharded.g.band
-            if r1 > r0:
-                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=(r0, r1), sync=False, timing=timed)
-                issued[0] += 1
-            sharded.g.gather()
-        elif world > 1:                      # camera shards: rank renders every world-th frame of the sweep
-            if i % world == rank:
-                r.render(cam, gs, out=frames[issued[0] % len(frames)], sync=False, timing=timed, pipelined=pipelined)
-                issued[0] += 1
-        else:
-            r.render(cam, gs, out=frames[issued[0] % len(frames)], sync=False, timing=timed, pipelined=pipelined)
-            issued[0] += 1
+    sharded = ShardedRenderer(r, args.height, args.width) if world > 1 else None
 
     def fence():
         torch.cuda.synchronize(device)
@@ -137,64 +126,80 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    batched_rows = sharded is not None and not args.no_pipeline
+    def cam_of_step(i, rk):
+        """Camera shards: step i is one pose PER RANK (rank rk renders pose i*world + rk of the sweep)."""
+        return cams[(i * world + rk) % len(cams)]
 
-    def run(first, count, timed):
-        """Issue frames first .. first+count-1 and complete them; returns the per-frame average statistics of the
-        frames this rank rendered (every frame of the region is checked for overflow)."""
-        if batched_rows:
-            # tile-row shards of a sweep: the bands of `batch` frames are rendered through the pipelined lanes and
-            # travel in one asynchronous gather, double-buffered against the next batch
-            acc, n_acc, i = None, 0, 0
-            while i < count:
-                nb = min(sharded.batch, count - i)
-                sharded.last_stats = None
-                sharded.render_batch([cams[(first + i + j) % len(cams)] for j in range(nb)], gs, timing=timed)
-                st = sharded.last_stats
-                if st is not None:
-                    if acc is None:
-                        acc = {"ms": {n: 0.0 for n in STAGE_NAMES}, "ms_total": 0.0}
-                    for n in STAGE_NAMES:
-                        acc["ms"][n] += st["ms"][n] * nb
-                    acc["ms_total"] += st["ms_total"] * nb
-                    n_acc += nb
-                i += nb
-            sharded.finish()
-            if acc is not None:
-                for n in STAGE_NAMES:
-                    acc["ms"][n] /= n_acc
-                acc["ms_total"] /= n_acc
-            return acc
-        issued[0] = 0
+    def run_cameras(first, count, timed):
+        """`count` steps, one frame per rank per step, no data-path collective.  Returns this rank's per-frame average
+        statistics; every frame of the region is checked for overflow."""
         for i in range(count):
-            step(first + i, timed)
-        return r.sync() if issued[0] else None            # completes the frames in flight (all lanes)
+            r.render(cam_of_step(first + i, rank), gs, out=frames[i % len(frames)], sync=False, timing=timed, pipelined=pipelined)
+        return r.sync() if count else None                # completes the frames in flight (all lanes)
 
-    run(0, W, False)
-    fence()
-    t0 = time.perf_counter()
-    avg = run(W, K, timing)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def run_rows(first, count, timed):
+        """`count` frames, each sharded by tile row over all ranks and gathered to rank 0 (RCCL): the bands of `batch`
+        frames are rendered through the pipelined lanes and travel in one asynchronous gather, double-buffered."""
+        acc, n_acc, i = None, 0, 0
+        while i < count:
+            nb = min(sharded.batch, count - i) if pipelined else 1
+            batch_cams = [cams[(first + i + j) % len(cams)] for j in range(nb)]
+            sharded.last_stats = None
+            if pipelined:
+                sharded.render_batch(batch_cams, gs, timing=timed)
+                st = sharded.last_stats
+            else:
+                r0, r1 = sharded.g.band
+                st = None
+                if r1 > r0:
+                    r.render(batch_cams[0], gs, out_band=sharded.g.slab, tile_rows=(r0, r1), sync=False, timing=timed)
+                sharded.g.gather()
+                if r1 > r0:
+                    st = r.sync()
+            if st is not None:
+                if acc is None:
+                    acc = {"ms": {n: 0.0 for n in STAGE_NAMES}, "ms_total": 0.0}
+                for n in STAGE_NAMES:
+                    acc["ms"][n] += st["ms"][n] * nb
+                acc["ms_total"] += st["ms_total"] * nb
+                n_acc += nb
+            i += nb
+        sharded.finish()
+        if acc is not None:
+            for n in STAGE_NAMES:
+                acc["ms"][n] /= n_acc
+            acc["ms_total"] /= n_acc
+        return acc
 
-    # ---- per-frame algorithmic bytes of the same K frames (deterministic; outside the timed region) --
+    def measure(runner, n_warm, n_steps, timed):
+        """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks."""
+        runner(0, n_warm, False)
+        fence()
+        t0 = time.perf_counter()
+        st = runner(n_warm, n_steps, timed)
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, st
+
+    rows_primary = world > 1 and args.shard == "rows"
+    elapsed, avg = measure(run_rows if rows_primary else run_cameras, W, K, timing)
+    frames_total = K if rows_primary else K * world       # camera shards: one frame per rank per step (weak scaling)
+
+    # ---- per-frame algorithmic bytes of rank 0's frames (deterministic; outside the timed region) -----
     stage_bytes = {n: 0 for n in STAGE_NAMES}
     iso_ms = {n: 0.0 for n in STAGE_NAMES}                 # the same launches one frame at a time (no overlap)
     counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
     if rank == 0:
-        rows = None if sharded is None else sharded.g.band
+        rows = sharded.g.band if rows_primary else None
         for i in range(K):
-            if world > 1 and args.shard == "cameras" and (W + i) % world != rank:
-                continue
-            cam = cams[(W + i) % len(cams)]
             if rows is None:
-                r.render(cam, gs, out=frame, timing=timing)
+                r.render(cam_of_step(W + i, 0), gs, out=frame, timing=timing)
             else:
-                r.render(cam, gs, out_band=sharded.g.slab, tile_rows=rows, timing=timing)
+                r.render(cams[(W + i) % len(cams)], gs, out_band=sharded.g.slab, tile_rows=rows, timing=timing)
             st = r.last_stats
             for n in STAGE_NAMES:
                 iso_ms[n] += st["ms"][n]
@@ -208,20 +213,20 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        frames_here = K if not (world > 1 and args.shard == "cameras") else len(range(rank, K, world))
+        frames_here = K
         out = {
             "metric": "frames/sec, 3M-Gaussian InteriorGS-like scene @1080p (+ achieved HBM GB/s in roofline)",
-            "value": K / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
-            "scaling": "strong" if (world == 1 or args.shard == "rows") else "weak",
+            "scaling": "strong" if rows_primary else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[2]: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
                                    f"SH deg 3, {args.width}x{args.height}, reference lens (8/20.955), 256-pose yaw sweep",
                        "parallelism": "1 GPU" if world == 1 else
                                       (f"tile-row shard x{world} + RCCL gather to rank 0"
-                                       + (f" (bands of {sharded.batch} frames per collective)" if batched_rows else "")
-                                       if args.shard == "rows"
-                                       else f"camera shard x{world}"),
+                                       + (f" (bands of {sharded.batch} frames per collective)" if pipelined else "")
+                                       if rows_primary
+                                       else f"camera shard x{world}: one pose per GPU per step, scene replicated, no data-path collective"),
                        "per_frame": {k: (v / max(1, frames_here) if k not in ("max_tile_len",) else v) for k, v in counts.items()}},
         }
         if avg is not None and timing and frames_here > 0:
@@ -248,13 +253,46 @@ def main():
                                "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf,
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
                                "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
-                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if (pipelined or batched_rows) else 1),
+                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
                                "note": "the dominant kernel is VALU-issue-bound, not HBM-bound (valu_busy = share of its cycles "
                                        "with the vector ALU executing, from the committed PMC passes); ms = HIP-event duration inside the timed region (frames overlap when "
                                        "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
                                        "with nothing else running"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, cams[W:], args.cpu_seconds)
+    else:
+        out = None
+
+    # ---- N > 1: the OTHER sharding mode, timed the same way, reported beside the headline -------------------
+    if world > 1 and not args.no_secondary:
+        import threading
+        finished = threading.Event()
+
+        def bail():                     # a stuck collective must not cost the headline: print it and leave
+            if not finished.is_set():
+                if rank == 0:
+                    out["also_measured"] = {"error": f"second measurement still running after {args.secondary_timeout:.0f} s; abandoned"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+
+        timer = threading.Timer(args.secondary_timeout, bail)
+        timer.daemon = True
+        timer.start()
+        try:
+            dt2, _ = measure(run_cameras if rows_primary else run_rows, min(W, 8), K, False)
+            n2 = K * world if rows_primary else K
+            second = {"shard": "cameras" if rows_primary else "rows", "value": n2 / dt2, "unit": "frames/s", "steps": K,
+                      "ms_per_step": 1e3 * dt2 / K, "scaling": "weak" if rows_primary else "strong",
+                      "parallelism": (f"camera shard x{world}" if rows_primary else
+                                      f"tile-row shard x{world} + RCCL gather to rank 0"
+                                      + (f" (bands of {sharded.batch} frames per collective)" if pipelined else ""))}
+        except Exception as e:           # noqa: BLE001 - reported, never fatal for the headline
+            second = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finished.set()
+        timer.cancel()
+        if rank == 0:
+            out["also_measured"] = second
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -93,6 +93,7 @@ struct sgs_ctx {
     bool last_timed = false;
     int64_t last_n = 0, last_pixels = 0;
     int last_tiles = 0, last_sh_rows = 0, last_T = 0;
+    int last_t_lo = 0, last_t_hi = 0;         // the band of tiles the last frame rendered (k_tile_scan fills only those)
     int last_retries = 0;
     hipStream_t last_stream = nullptr;
     // frames issued since the last synchronisation (ring slots pending_begin .. +pending_count)
@@ -333,6 +334,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     ctx->last_slot = slot; ctx->last_timed = timed; ctx->last_stream = caller_stream; ctx->last_lane = lane;
     ctx->last_n = scene->n; ctx->last_tiles = (int)ntiles; ctx->last_sh_rows = scene->sh_rows;
     ctx->last_T = gx * gy;
+    ctx->last_t_lo = row_begin * gx; ctx->last_t_hi = row_end * gx;
     ctx->last_scene = scene;
     const int y0 = row_begin * SGS_TILE, y1 = std::min(row_end * SGS_TILE, cam->height);
     ctx->last_pixels = (int64_t)std::max(0, y1 - y0) * cam->width;
@@ -732,7 +734,10 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         if (!tmp) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
         hipError_t e = hipMemcpy(tmp, L.tile_offset, cnt * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { free(tmp); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
-        for (int64_t i = 0; (i + 1) * 4 <= n; ++i) ((unsigned*)host_dst)[i] = tmp[(size_t)i * SGS_XCDS];
+        // k_tile_scan writes the offsets of the band it rendered (and the band's end); outside it they are constant
+        const unsigned total = tmp[(size_t)ctx->last_t_hi * SGS_XCDS];
+        for (int64_t i = 0; (i + 1) * 4 <= n; ++i)
+            ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i * SGS_XCDS];
         free(tmp);
     }
     if (elem) {

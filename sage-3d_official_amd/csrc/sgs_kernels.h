@@ -383,29 +383,30 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
     __shared__ unsigned s_cls[33];                    // tiles per log2(queue length) class, then cursors
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int T = P.gx * P.gy;
     const int t_lo = P.row_begin * P.gx, t_hi = P.row_end * P.gx;      // the tiles this call renders
     if (tid < 33) s_cls[tid] = 0;
     __syncthreads();
     unsigned carry = 0, mx = 0;
     // one tile per thread per round: 32-byte vector loads/stores, the eight sub-counts stay in registers
-    for (int t0 = 0, rnd = 0; t0 < T; t0 += SGS_SCAN_THREADS, ++rnd) {
+    // only the band this call renders: rects are clipped to it in k_preprocess, every other tile's count is zero
+    // (a rank of a tile-row-sharded frame scans 1/N of the tiles)
+    for (int t0 = t_lo, rnd = 0; t0 < t_hi; t0 += SGS_SCAN_THREADS, ++rnd) {
         const int t = t0 + tid;
         uint4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;
-        if (t < T) {
+        if (t < t_hi) {
             uint4* cp = reinterpret_cast<uint4*>(tile_count + (size_t)t * SGS_XCDS);
             c0 = cp[0]; c1 = cp[1];
             cp[0] = uint4{0u, 0u, 0u, 0u}; cp[1] = uint4{0u, 0u, 0u, 0u};
         }
         const unsigned c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
         mx = c > mx ? c : mx;
-        if (t >= t_lo && t < t_hi) atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u);
+        if (t < t_hi) atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u);
         const unsigned incl = wave_incl_scan(c, lane);
         if (lane == 63) s_wsum[rnd & 1][wave] = incl;
         __syncthreads();
         unsigned wbase = 0, total = 0;
         for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) { const unsigned sw = s_wsum[rnd & 1][w]; if (w < wave) wbase += sw; total += sw; }
-        if (t < T) {
+        if (t < t_hi) {
             unsigned run = carry + wbase + incl - c;
             uint4 o0, o1;
             o0.x = run; run += c0.x; o0.y = run; run += c0.y; o0.z = run; run += c0.z; o0.w = run; run += c0.w;
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     __syncthreads();
     for (int t = t_lo + tid; t < t_hi; t += SGS_SCAN_THREADS) {
         const unsigned b = tile_offset[(size_t)t * SGS_XCDS];
-        const unsigned e = (t + 1 < T) ? tile_offset[(size_t)(t + 1) * SGS_XCDS] : carry;
+        const unsigned e = (t + 1 < t_hi) ? tile_offset[(size_t)(t + 1) * SGS_XCDS] : carry;
         const unsigned c = e - b;
         // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
         tile_order[atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u)] = uint4{(unsigned)t, b, c, 0u};
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     if (tid == 0) {
         unsigned tmax = 0;
         for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) tmax = s_wmax[w] > tmax ? s_wmax[w] : tmax;
-        tile_offset[(size_t)T * SGS_XCDS] = carry;
+        tile_offset[(size_t)t_hi * SGS_XCDS] = carry;      // end of the band's last queue (k_bin_emit never reads past it)
         st->d_total = carry;
         st->max_tile_len = tmax;
         st->overflow = (unsigned long long)carry > (unsigned long long)P.rec_capacity ? 1u : 0u;
