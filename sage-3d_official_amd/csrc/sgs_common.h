@@ -9,7 +9,11 @@
 #define SGS_MAX_SH_ROWS 12          // ceil(48 floats / 4) at SH degree 3
 
 // Compaction / binning (S4)
-#define SGS_RANGE 1024              // Gaussians per compaction range: one k_preprocess workgroup, 16 chunks
+#ifndef SGS_RANGE
+#define SGS_RANGE 256               // Gaussians per binning range: a workgroup owns ranges b, b+B, b+2B, ...  Consecutive
+                                    // Gaussians share a surface (hence rect size), so coarse ranges of 1024 left the slowest
+                                    // workgroup at 2-3x the mean; 256 measured best (64: more sweeps than it saves)
+#endif
 #define SGS_RANGE_CHUNKS (SGS_RANGE / SGS_WAVE)
 #define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB)
 #define SGS_BIN_THREADS 512

@@ -1128,7 +1128,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 }
 
 template <bool AUX>
-__global__ __launch_bounds__(256, 6) void k_tile_render(const FrameParams P,
+__global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameParams P,
                                                      const uint4* __restrict__ tile_order,
                                                      const unsigned long long* __restrict__ rec,
                                                      unsigned long long* alt, unsigned long long* part,

@@ -10,11 +10,15 @@ sc = scenes.make_room(3_000_000, seed=2)
 cams = scenes.room_cameras(sc, 1920, 1080, 4, 64, seed=2)
 r = Renderer("cuda:0", record_capacity=96 << 20)
 gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
-for ci in (5, 70, 140):
+slab = torch.zeros((9 * 16, 1920, 3), device="cuda:0")
+for ci, rows in ((5, None), (70, None), (140, None), (20, (27, 36)), (140, (27, 36))):
     for _ in range(3):
-        r.render(cams[ci], gs, timing=True)
+        if rows is None:
+            r.render(cams[ci], gs, timing=True)
+        else:
+            r.render(cams[ci], gs, out_band=slab, tile_rows=rows, timing=True)
     st = r.last_stats
     p = r.debug_buffer(101, np.uint64).reshape(-1, 8).astype(np.float64)
     nlive, find, walk, flush, nlist, nvis, tot, t0 = p.T
-    print(f"cam {ci}: count stage {st['ms']['count']*1e3:.0f} us N_v={st['n_visible']} D={st['d_total']} | per block mean: live chunks {nlive.mean():.0f} touched tiles {nlist.mean():.0f} vis {nvis.mean():.0f} | "
+    print(f"cam {ci} rows {rows}: count stage {st['ms']['count']*1e3:.0f} us N_v={st['n_visible']} D={st['d_total']} | per block mean: live chunks {nlive.mean():.0f} touched tiles {nlist.mean():.0f} vis {nvis.mean():.0f} | "
           f"cycles find {find.mean():.0f} walk {walk.mean():.0f} (max {walk.max():.0f}) flush {flush.mean():.0f} (max {flush.max():.0f}) total {tot.mean():.0f} (max {tot.max():.0f}) | kernel span {(t0+tot).max()-t0.min():.0f} cyc, start spread {t0.max()-t0.min():.0f}")
