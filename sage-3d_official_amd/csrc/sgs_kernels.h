@@ -1200,6 +1200,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     const bool in_lds = n <= SGS_QCAP;
     const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
     if (tid < 2) s_any[tid] = 0;
+    if (tid < 64) reinterpret_cast<unsigned*>(&s_ball[0][0][0])[tid] = 0u;   // both parities: 2 x 4 quadrants x 4 x 64 bits
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
     {
         unsigned long long rq[4];
@@ -1342,7 +1343,6 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
             const float4* const sp = reinterpret_cast<const float4*>(splats + (have ? (unsigned)mine : 0u));
             const float4 nA = sp[0], nB = sp[1];
             const float nC = sp[2].x;
-            if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // 4 quadrants x 4 x 64 bits
             // Rank of my record inside the group.  The resident queue is bucket-contiguous (MSD partition) and the
             // buckets are disjoint depth ranges, so rank = (records of shallower buckets) + (rank inside MY bucket):
             // a lane walks only its own bucket's slice — typically a few dozen records instead of the group's ~256.
@@ -1376,9 +1376,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
                 }
             }
             SGS_PROF_MARK(pt_rank);
-            __syncthreads();             // every lane has read its record: the staging arena may be written
-            SGS_PROF_MARK(pt_bar1);
-                                         // (s_q and the arena are distinct, but s_ball was just cleared)
+            // (no barrier here: ranking reads s_q, staging writes the arena, and this parity's quadrant masks were
+            //  cleared when the batch before last was consumed)
             if (tid == 0) SGS_STAGE_DUMMY()
             if (have) {
                 const float qmax = __log2f(nB.y) + l2_inv_amin;
@@ -1425,6 +1424,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
             tile_done = s_any[par] == 0u;
+            if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;    // consumed: ready for the batch after next
             ++it;
             // a tile that keeps consuming batches is on the kernel's critical path: let its waves win the issue
             // arbitration against the short-lived tiles they share the SIMDs with
@@ -1548,6 +1548,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
+                if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // (the single-batch path ORs into it)
                 if (it == 0) __builtin_amdgcn_s_setprio(1); else if (it == 1) __builtin_amdgcn_s_setprio(2); else if (it == 3) __builtin_amdgcn_s_setprio(3);
 #ifdef SGS_TILE_PROF
                 ++pn_batches;
