@@ -1156,6 +1156,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_used[4];
+#ifdef SGS_EXPERIMENT_LDS_PAD
+    __shared__ unsigned s_pad_experiment[SGS_EXPERIMENT_LDS_PAD / 4];    // occupancy experiment: fewer workgroups per CU
+    if (threadIdx.x == 0 && P.n < 0) s_pad_experiment[0] = 1;
+#endif
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
