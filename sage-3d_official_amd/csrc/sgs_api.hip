@@ -1,8 +1,11 @@
 // sgs_api.hip — host side of libsage_gs.so: the C ABI of include/sage_gs.h over the gfx950 kernels.
 //
-// A frame is seven stream-ordered launches with no host synchronisation in between (grids that
-// depend on device-side counts are fixed-size and grid-stride); the frame's FrameStatus is copied
-// to pinned host memory at the end and inspected when the caller synchronises.
+// A frame is five stream-ordered launches (k_preprocess, k_bin_count, k_tile_scan, k_bin_emit, k_tile_render) with
+// no host synchronisation in between (grids that depend on device-side counts are fixed-size and grid-stride); the
+// frame's FrameStatus is copied to pinned host memory at the end and inspected when the caller synchronises.
+// Ordinary frames run on the caller's stream with lane 0's intermediates; pipelined frames (SGS_FLAG_PIPELINED,
+// sgs_render_batch) rotate over a few lanes, each with its own stream and intermediates, so that independent
+// frames overlap on the chip.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
