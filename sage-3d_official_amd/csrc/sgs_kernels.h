@@ -2,13 +2,13 @@
 //
 // Stage map (BASELINE.json north_star):
 //   k_scene_layout   upload-time re-layout of the scene into wave-chunked float4 rows (A5)
-//   k_preprocess     S1 SH colour, S2 EWA projection (fp64 geometry), S3 AABB -> tile rect,
-//                    wave-ballot compaction of survivors inside 1024-Gaussian ranges
-//   k_tile_scan      S4: exclusive scan of the per-tile counts
+//   k_preprocess     S1 SH colour, S2 EWA projection (fp64 geometry), S3 AABB -> tile rect (+ the tighter rect that is
+//                    binned); slot == Gaussian index, one 64-bit ballot per chunk is the visibility mask
 //   k_bin_count      S4: per-workgroup LDS tile histograms -> one global atomic per touched tile
-//   k_bin_emit       S4: duplication of each splat into the queues of the tiles it touches
-//   k_tile_render    S5+S6 fused: per-tile MSD bucket partition, lazy LDS radix sort of bucket groups
-//                    (ties -> index), front-to-back alpha composite of LDS-staged batches
+//   k_tile_scan      S4: exclusive scan of the per-tile counts, longest-queue-first render order
+//   k_bin_emit       S4: duplication of each splat into the queues of the tiles it can reach
+//   k_tile_render    S5+S6 fused: per-tile MSD bucket partition, lazy rank sort of ~256-record groups (ties -> index),
+//                    front-to-back alpha composite of LDS-staged batches
 //   k_pack_rgba8     fp32 RGB -> uint8 RGBA (get_rgba()-shaped surface)
 //
 // None of these has a counterpart in the reference (it has no rasterizer); the
