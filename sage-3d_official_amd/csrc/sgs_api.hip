@@ -84,6 +84,9 @@ struct sgs_ctx {
     int n_lanes = 3, next_lane = 0;          // SGS_LANES=1..4
     int last_lane = 0;
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
+    int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
+                                             // 64-KB window: binning alone 380 -> 305 us at 3840x2160, but such workgroups overlap worse
+                                             // with the other frames in flight (sweep 1717 -> 1657 frames/s), so it is opt-in
     bool morton = false;                     // Z-order the scene at upload (SGS_MORTON=1): for scenes stored in no spatial order
     const sgs_scene* last_scene = nullptr;
     int64_t rec_cap_wanted = 16ll << 20;
@@ -148,8 +151,8 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     return SGS_OK;
 }
 
-int ensure_blk_list(sgs_ctx* ctx, Lane& L, int n_windows) {
-    const int64_t need = (int64_t)SGS_BIN_BLOCKS * n_windows * SGS_WT;
+int ensure_blk_list(sgs_ctx* ctx, Lane& L, int n_windows, int win_tiles) {
+    const int64_t need = (int64_t)SGS_BIN_BLOCKS * n_windows * win_tiles;
     if (need <= L.blk_list_cap) return SGS_OK;
     int rc;
     if ((rc = grow(ctx, L.blk_list, (size_t)need)) != SGS_OK) return rc;
@@ -221,13 +224,14 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     if (cfg && cfg->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d > 3", cfg->sh_degree);
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
     if (gx > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "width %d exceeds %d tiles per row", cam->width, SGS_WT);
-    const int win_rows = std::max(1, SGS_WT / gx);
+    const int win_tiles = (row_end - row_begin) * gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;
+    const int win_rows = std::max(1, win_tiles / gx);
     if ((row_end - row_begin + win_rows - 1) / win_rows > SGS_MAX_WINDOWS)
         SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d binning windows", row_end - row_begin, gx, SGS_MAX_WINDOWS);
     return SGS_OK;
 }
 
-void fill_params(FrameParams& P, const Lane& L, const sgs_scene* scene, const sgs_camera* cam,
+void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_scene* scene, const sgs_camera* cam,
                  const sgs_config& cfg, int row_begin, int row_end) {
     memset(&P, 0, sizeof P);
     for (int i = 0; i < 12; ++i) P.view[i] = cam->view[i];
@@ -245,7 +249,8 @@ void fill_params(FrameParams& P, const Lane& L, const sgs_scene* scene, const sg
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
     P.n_ranges = (int32_t)((scene->n + SGS_RANGE - 1) / SGS_RANGE);
-    P.win_rows = std::max(1, SGS_WT / P.gx);
+    P.win_tiles = (row_end - row_begin) * P.gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;   // 4K frames: two 64-KB windows, not four
+    P.win_rows = std::max(1, P.win_tiles / P.gx);
     P.n_windows = (row_end - row_begin + P.win_rows - 1) / P.win_rows;
     P.rec_capacity = L.rec_cap;
     P.flags = cfg.flags | SGS_FLAG_STATS;
@@ -270,8 +275,8 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if ((rc = ensure_tiles(ctx, L, gx * gy)) != SGS_OK) return rc;
     if ((rc = ensure_records(ctx, L)) != SGS_OK) return rc;
     FrameParams P;
-    fill_params(P, L, scene, cam, cfg, row_begin, row_end);
-    if ((rc = ensure_blk_list(ctx, L, std::max(1, P.n_windows))) != SGS_OK) return rc;
+    fill_params(P, ctx, L, scene, cam, cfg, row_begin, row_end);
+    if ((rc = ensure_blk_list(ctx, L, std::max(1, P.n_windows), P.win_tiles)) != SGS_OK) return rc;
     if ((P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, L)) != SGS_OK) return rc;
     if (pipelined) {
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
@@ -303,7 +308,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, L.binrec,
+        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_count, L.blk_list, L.blk_len, st,
                            L.bin_prof);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
@@ -311,7 +316,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), 0, stream, P, L.binrec,
+        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_offset, L.blk_list, L.blk_len,
                            L.rec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
@@ -418,6 +423,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
+    if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_RECORD_CAPACITY")) {

@@ -15,7 +15,8 @@
                                     // workgroup at 2-3x the mean; 256 measured best (64: more sweeps than it saves)
 #endif
 #define SGS_RANGE_CHUNKS (SGS_RANGE / SGS_WAVE)
-#define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB)
+#define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB) ...
+#define SGS_WT_BIG 16384            // ... or 64 KB (SGS_WINDOW_TILES=16384, bands of more than SGS_WT tiles: 4K in two windows, not four)
 #define SGS_BIN_THREADS 512
 #define SGS_BIN_BLOCKS 512          // binning workgroups (2 per CU); each owns ranges b, b+B, b+2B, ...
 #define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)
@@ -49,7 +50,7 @@ struct FrameParams {
     int32_t n_ranges;               // ceil(n / SGS_RANGE)
     int32_t win_rows;               // tile rows per binning window = max(1, SGS_WT / gx)
     int32_t n_windows;              // ceil((row_end - row_begin) / win_rows)
-    int32_t pad0_;
+    int32_t win_tiles;              // SGS_WT or SGS_WT_BIG: counters a binning workgroup keeps in (dynamic) LDS
     int64_t rec_capacity;           // records the queues can hold
     uint32_t flags;
     uint32_t pad_;

@@ -614,12 +614,16 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 #else
 #define SGS_BPROF(acc) do { } while (0)
 #endif
-    __shared__ unsigned s_cnt[SGS_WT];
+#ifdef SGS_HIPEMU
+    unsigned* const s_cnt = static_cast<unsigned*>(hipemu::dyn_shared());
+#else
+    extern __shared__ unsigned s_cnt[];              // P.win_tiles counters (dynamic LDS)
+#endif
     __shared__ unsigned s_nlist;
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
     const unsigned xcd = xcc_id();
-    for (int i = tid; i < SGS_WT; i += SGS_BIN_THREADS) s_cnt[i] = 0;
+    for (int i = tid; i < P.win_tiles; i += SGS_BIN_THREADS) s_cnt[i] = 0;
     const int n_sweeps = bin_sweeps(P);
     unsigned n_vis = 0;
     for (int w = 0; w < P.n_windows; ++w) {
@@ -641,10 +645,10 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         // Every wave sweeps a 1/8 of the window's counters 64 at a time; the touched ones are compacted with a
         // ballot straight into the workgroup's (tile, base) list (no LDS list of touched tiles: LDS is what limits
         // how many composite workgroups share the CU with this kernel).
-        uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
+        uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * P.win_tiles;
         {
             const int lane = tid & 63, wave = tid >> 6;
-            constexpr int kPerWave = SGS_WT / (SGS_BIN_THREADS / 64);
+            const int kPerWave = P.win_tiles / (SGS_BIN_THREADS / 64);
             for (int i0 = 0; i0 < kPerWave; i0 += 128) {           // two rounds per trip: two atomics in flight per lane
                 unsigned tl[2], c[2], pre[2], base[2];
                 unsigned long long m[2];
@@ -702,7 +706,11 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
                                                               const unsigned* __restrict__ blk_len,
                                                               unsigned long long* __restrict__ rec,
                                                               const FrameStatus* __restrict__ st) {
-    __shared__ unsigned s_next[SGS_WT];
+#ifdef SGS_HIPEMU
+    unsigned* const s_next = static_cast<unsigned*>(hipemu::dyn_shared());
+#else
+    extern __shared__ unsigned s_next[];             // P.win_tiles write cursors (dynamic LDS)
+#endif
     __shared__ LiveChunks lc;
     if (st->overflow) return;
     const int tid = threadIdx.x;
@@ -711,7 +719,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
     for (int w = 0; w < P.n_windows; ++w) {
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
         const unsigned nl = blk_len[blockIdx.x * SGS_MAX_WINDOWS + w];
-        const uint2* in = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * SGS_WT;
+        const uint2* in = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * P.win_tiles;
         for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
             const uint2 e = in[i];
             s_next[e.x] = tile_offset[((size_t)wr0 * P.gx + e.x) * SGS_XCDS + xcd] + e.y;

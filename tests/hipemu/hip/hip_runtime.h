@@ -279,5 +279,14 @@ static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { retu
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 
+// dynamic LDS: a buffer per OS thread (= per workgroup in flight), sized by the launch that is running
+namespace hipemu {
+inline size_t& dyn_bytes() { static size_t b = 0; return b; }
+inline void* dyn_shared() {
+    static thread_local std::vector<char> buf;
+    if (buf.size() < dyn_bytes()) buf.resize(dyn_bytes());
+    return buf.data();
+}
+}  // namespace hipemu
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+    (hipemu::dyn_bytes() = (size_t)(shmem), hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))

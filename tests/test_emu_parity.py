@@ -56,9 +56,16 @@ def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(640, 368))
 
 
-def test_two_binning_windows(drv):
-    # 129 x 65 = 8385 tiles > SGS_WT (8192): the binning kernels walk two LDS windows
+def test_two_binning_windows(drv, monkeypatch):
+    # 129 x 65 = 8385 tiles > SGS_WT (8192): the binning kernels walk two LDS windows ...
     pc.case_full_grid_splat(drv, res=(2064, 1040))
+    # ... or one 16 k-tile window (dynamic LDS) when the big window is enabled
+    monkeypatch.setenv("SGS_WINDOW_TILES", "16384")
+    d = emu_harness.EmuRenderer()
+    try:
+        pc.case_full_grid_splat(d, res=(2064, 1040))
+    finally:
+        d.close()
 
 
 def test_depth_and_coverage_outputs(drv):
