@@ -15,6 +15,10 @@
                                     // workgroup at 2-3x the mean; 256 measured best (64: more sweeps than it saves)
 #endif
 #define SGS_RANGE_CHUNKS (SGS_RANGE / SGS_WAVE)
+// the launch-sized part of a workgroup's LDS (a CPU test harness may supply its own definition)
+#ifndef SGS_DYNAMIC_LDS
+#define SGS_DYNAMIC_LDS(T, name) extern __shared__ T name[]
+#endif
 #define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB) ...
 #define SGS_WT_BIG 16384            // ... or 64 KB (SGS_WINDOW_TILES=16384, bands of more than SGS_WT tiles: 4K in two windows, not four)
 #define SGS_BIN_THREADS 512

@@ -614,11 +614,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 #else
 #define SGS_BPROF(acc) do { } while (0)
 #endif
-#ifdef SGS_HIPEMU
-    unsigned* const s_cnt = static_cast<unsigned*>(hipemu::dyn_shared());
-#else
-    extern __shared__ unsigned s_cnt[];              // P.win_tiles counters (dynamic LDS)
-#endif
+    SGS_DYNAMIC_LDS(unsigned, s_cnt);                // P.win_tiles counters
     __shared__ unsigned s_nlist;
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
@@ -706,11 +702,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
                                                               const unsigned* __restrict__ blk_len,
                                                               unsigned long long* __restrict__ rec,
                                                               const FrameStatus* __restrict__ st) {
-#ifdef SGS_HIPEMU
-    unsigned* const s_next = static_cast<unsigned*>(hipemu::dyn_shared());
-#else
-    extern __shared__ unsigned s_next[];             // P.win_tiles write cursors (dynamic LDS)
-#endif
+    SGS_DYNAMIC_LDS(unsigned, s_next);               // P.win_tiles write cursors
     __shared__ LiveChunks lc;
     if (st->overflow) return;
     const int tid = threadIdx.x;

@@ -288,5 +288,6 @@ inline void* dyn_shared() {
     return buf.data();
 }
 }  // namespace hipemu
+#define SGS_DYNAMIC_LDS(T, name) T* const name = static_cast<T*>(hipemu::dyn_shared())
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     (hipemu::dyn_bytes() = (size_t)(shmem), hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))
