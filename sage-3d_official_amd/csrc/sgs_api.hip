@@ -145,7 +145,7 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     if ((rc = grow(ctx, L.bigmask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.binrec, (size_t)cap)) != SGS_OK) return rc;
     if (!L.big_list && (rc = grow(ctx, L.big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * (SGS_MAX_WINDOWS + 1))) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS * 2)) != SGS_OK) return rc;    // list lengths | XCD ids
     if ((rc = grow(ctx, L.bin_prof, (size_t)SGS_BIN_BLOCKS * 8)) != SGS_OK) return rc;
     L.splat_cap = cap;
     return SGS_OK;
@@ -308,7 +308,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
+        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_count, L.blk_list, L.blk_len, st,
                            L.bin_prof);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
@@ -316,7 +316,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
+        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_offset, L.blk_list, L.blk_len,
                            L.rec, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));

@@ -467,10 +467,16 @@ struct LiveChunks {
 };
 // One sweep covers SGS_BIN_THREADS / 16 of the workgroup's ranges; a pass does at most
 // SGS_MAX_LIVE / SGS_BIN_THREADS sweeps, so the list cannot overflow however large the scene is.
+// The binning grid is (workgroups per window) x (windows): workgroup (b, w) bins the ranges b, b+B, b+2B, ... into
+// window w.  A frame of more than SGS_WT tiles (4K) thus runs its windows side by side instead of as sequential
+// passes of every workgroup — these kernels leave the chip mostly idle (~1 wave per SIMD), so the passes overlap.
+__device__ __forceinline__ unsigned bin_B(const FrameParams& P) { return gridDim.x / (unsigned)max(1, P.n_windows); }
+__device__ __forceinline__ unsigned bin_b(const FrameParams& P) { return blockIdx.x % bin_B(P); }
+__device__ __forceinline__ int bin_w(const FrameParams& P) { return (int)(blockIdx.x / bin_B(P)); }
 #define SGS_RANGES_PER_SWEEP (SGS_BIN_THREADS / SGS_RANGE_CHUNKS)
 #define SGS_SWEEPS_PER_PASS (SGS_MAX_LIVE / SGS_BIN_THREADS)
 __device__ __forceinline__ int bin_sweeps(const FrameParams& P) {
-    const int mine = (P.n_ranges - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // ranges b, b+B, ...
+    const int mine = (P.n_ranges - (int)bin_b(P) + (int)bin_B(P) - 1) / (int)bin_B(P);   // ranges b, b+B, ...
     return (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP;
 }
 __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const unsigned long long* __restrict__ vismask,
@@ -481,7 +487,7 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     unsigned vis = 0;
     for (int sw = sweep0; sw < sweep1; ++sw) {
         const int j = sw * SGS_RANGES_PER_SWEEP + (int)(threadIdx.x / SGS_RANGE_CHUNKS);     // j-th range of this workgroup
-        const long long r = (long long)blockIdx.x + (long long)j * gridDim.x;
+        const long long r = (long long)bin_b(P) + (long long)j * bin_B(P);
         const long long chunk = r * SGS_RANGE_CHUNKS + (threadIdx.x % SGS_RANGE_CHUNKS);
         if (r < P.n_ranges && chunk < P.n_chunks) {
             const unsigned long long vm = vismask[chunk];
@@ -580,7 +586,7 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
                                              const unsigned* __restrict__ big_list, unsigned n_big,
                                              int wr0, int wr1, F&& f) {
     n_big = min(n_big, (unsigned)SGS_BIG_CAP);
-    for (unsigned i = blockIdx.x; i < n_big; i += gridDim.x) {
+    for (unsigned i = bin_b(P); i < n_big; i += bin_B(P)) {
         const uint4 br = binrec[big_list[i]];
         const unsigned key = br.x, r01 = br.y, r23 = br.z, slot = br.w;
         const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
@@ -622,7 +628,9 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
     for (int i = tid; i < P.win_tiles; i += SGS_BIN_THREADS) s_cnt[i] = 0;
     const int n_sweeps = bin_sweeps(P);
     unsigned n_vis = 0;
-    for (int w = 0; w < P.n_windows; ++w) {
+    const unsigned b = bin_b(P);
+    {
+        const int w = bin_w(P);
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
         if (tid == 0) s_nlist = 0;
         __syncthreads();
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         // Every wave sweeps a 1/8 of the window's counters 64 at a time; the touched ones are compacted with a
         // ballot straight into the workgroup's (tile, base) list (no LDS list of touched tiles: LDS is what limits
         // how many composite workgroups share the CU with this kernel).
-        uint2* out = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * P.win_tiles;
+        uint2* out = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
         {
             const int lane = tid & 63, wave = tid >> 6;
             const int kPerWave = P.win_tiles / (SGS_BIN_THREADS / 64);
@@ -677,16 +685,16 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         __syncthreads();
         const unsigned nl = s_nlist;
         if (tid == 0) {
-            blk_len[blockIdx.x * SGS_MAX_WINDOWS + w] = nl;
-            if (w == 0) blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + blockIdx.x] = xcd;   // k_bin_emit must use the same sub-queue
+            blk_len[b * SGS_MAX_WINDOWS + w] = nl;
+            blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + b * SGS_MAX_WINDOWS + w] = xcd;   // k_bin_emit must use the same sub-queue
             if (w == 0 && n_vis) atomicAdd(&st->n_visible, n_vis);    // one per workgroup
         }
         __syncthreads();
         SGS_BPROF(bt_flush);
     }
 #ifdef SGS_TILE_PROF
-    if (tid == 0 && prof) {
-        unsigned long long* o = prof + (size_t)blockIdx.x * 8;
+    if (tid == 0 && prof && bin_w(P) == 0) {
+        unsigned long long* o = prof + (size_t)b * 8;
         o[0] = lc.n; o[1] = bt_find; o[2] = bt_walk; o[3] = bt_flush; o[4] = s_nlist; o[5] = n_vis; o[6] = clock64() - bt0; o[7] = bt0;
     }
 #endif
@@ -706,12 +714,14 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
     __shared__ LiveChunks lc;
     if (st->overflow) return;
     const int tid = threadIdx.x;
-    const unsigned xcd = blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + blockIdx.x];   // the XCD k_bin_count ran this workgroup's share on
+    const unsigned b = bin_b(P);
     const int n_sweeps = bin_sweeps(P);
-    for (int w = 0; w < P.n_windows; ++w) {
+    {
+        const int w = bin_w(P);
+        const unsigned xcd = blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + b * SGS_MAX_WINDOWS + w];   // the XCD k_bin_count ran (b, w) on
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
-        const unsigned nl = blk_len[blockIdx.x * SGS_MAX_WINDOWS + w];
-        const uint2* in = blk_list + ((size_t)blockIdx.x * P.n_windows + w) * P.win_tiles;
+        const unsigned nl = blk_len[b * SGS_MAX_WINDOWS + w];
+        const uint2* in = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
         for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
             const uint2 e = in[i];
             s_next[e.x] = tile_offset[((size_t)wr0 * P.gx + e.x) * SGS_XCDS + xcd] + e.y;
