@@ -1116,7 +1116,9 @@ template <> struct ColOf<true> { typedef float4 type; };
 #ifndef SGS_GROUP
 #define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
 #endif
+#ifndef SGS_QCAP
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
+#endif
 #define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
 
 // orders a wave's own LDS writes before its later LDS reads by OTHER lanes of the same wave
@@ -1157,7 +1159,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     float4* const s_b = s_arena + (SGS_BATCH + 1);
     ColT* const s_c = reinterpret_cast<ColT*>(s_arena + 2 * (SGS_BATCH + 1));
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
-    __shared__ __attribute__((aligned(16))) unsigned s_sorted[SGS_QCAP + 16];   // the group's slots in (depth, index) order; single-batch
+    __shared__ __attribute__((aligned(16))) unsigned s_sorted[(SGS_QCAP + 16) > 4 * (SGS_BATCH + 4) ? (SGS_QCAP + 16) : 4 * (SGS_BATCH + 4)];   // the group's slots in (depth, index) order; single-batch
                                                                               // groups: the four waves' splat lists
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
