@@ -146,3 +146,9 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
     lib.check(lib.sgs_render_batch(ctx, drv.scene, arr, len(cams), C.byref(cfg2), 0, -1, batch.ctypes.data, stats, None), ctx)
     for i in range(len(cams)):
         assert (batch[i] == seq[i]).all() and stats[i].d_total > 0
+
+
+@pytest.mark.parametrize("case", __import__("known_answer_cases").ALL, ids=lambda f: f.__name__)
+def test_kernels_against_closed_form_answers(drv, case):
+    """The analytic cases that pin the oracle, run straight against the kernels (emulator) — no oracle involved."""
+    case(drv)

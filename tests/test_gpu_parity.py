@@ -295,6 +295,12 @@ def test_culling_never_changes_a_pixel_stress(drv):
     scene.free()
 
 
+@pytest.mark.parametrize("case", __import__("known_answer_cases").ALL, ids=lambda f: f.__name__)
+def test_kernels_against_closed_form_answers(drv, case):
+    """The analytic cases that pin the oracle, run straight against the HIP path — no oracle involved."""
+    case(drv)
+
+
 def test_against_committed_golden_fixture(drv):
     """The HIP path against tests/golden/config1_golden.npz — no oracle run involved."""
     import os
