@@ -189,6 +189,16 @@ def test_3m_scene_properties(drv, big_scene):
         # (4) idempotence / determinism
         again, _ = drv.render(ocam)
         assert (again == full).all()
+        # (6) background linearity: frame(bg) = frame(black) + (1 - coverage) * bg, coverage from the depth/coverage output
+        if cam is cams[0]:
+            from sage_gs import Camera, RenderConfig
+            c = Camera(ocam.width, ocam.height, ocam.fx, ocam.fy, ocam.cx, ocam.cy, np.asarray(ocam.view, np.float64))
+            bg = (0.25, 0.5, 0.75)
+            over = drv.r.render(c, drv.scene, config=RenderConfig(background=bg)).cpu().numpy()
+            _, aux = drv.r.render(c, drv.scene, return_aux=True)
+            t_final = 1.0 - aux.cpu().numpy()[..., 1:2]
+            assert np.abs(over - (full + t_final * np.asarray(bg, np.float32))).max() < 2e-6
+            assert (t_final >= 0).all() and (t_final <= 1).all()
         # (5) lazy sort under reference binning consumes exactly as many records as the full sort did
         loose, st_loose = drv.render(ocam, loose_cull=True)
         assert (loose == full).all() and st_loose["d_fetched"] == st["d_fetched"]
