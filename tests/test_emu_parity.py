@@ -152,3 +152,40 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
 def test_kernels_against_closed_form_answers(drv, case):
     """The analytic cases that pin the oracle, run straight against the kernels (emulator) — no oracle involved."""
     case(drv)
+
+
+def test_argument_errors_are_reported_not_swallowed(drv):
+    """The reference swallows render failures into `None` / black frames (simple_env.py:1390-1393); this ABI returns a
+    negative status and a message for every bad argument, and leaves the context usable."""
+    import ctypes as C
+    from sage_gs import _capi
+    scene, _ = onp.config1_scene(n=200, seed=1)
+    drv.upload(*scene)
+    lib, ctx = drv.lib, drv.ctx
+    out = np.zeros((32, 32, 3), np.float32)
+    good = _capi.make_camera(32, 32, 30.0, 30.0, 16.0, 16.0, np.eye(4, dtype=np.float32).tolist())
+
+    def call(cam=good, cfg=None, r0=0, r1=-1, dst=out.ctypes.data, sc=None):
+        return lib.sgs_render(ctx, drv.scene if sc is None else sc, C.byref(cam) if cam is not None else None,
+                              C.byref(cfg) if cfg is not None else None, r0, r1, dst, None, None)
+
+    def expect_invalid(rc, word):
+        assert rc == -1, rc                                    # SGS_ERR_INVALID
+        msg = lib.sgs_last_error(ctx).decode()
+        assert word in msg, msg
+
+    expect_invalid(call(dst=None), "null")
+    expect_invalid(call(cam=None), "null")
+    expect_invalid(call(cam=_capi.make_camera(0, 32, 30.0, 30.0, 16.0, 16.0, np.eye(4).tolist())), "resolution")
+    expect_invalid(call(cam=_capi.make_camera(32, 32, 0.0, 30.0, 16.0, 16.0, np.eye(4).tolist())), "focal")
+    expect_invalid(call(r0=2, r1=1), "tile_row_begin")
+    bad = lib.default_config(); bad.sh_degree = 4
+    expect_invalid(call(cfg=bad), "sh_degree")
+    assert lib.sgs_set_record_capacity(ctx, 0) == -1
+    assert lib.sgs_debug_read(ctx, 999, None, 0) == -1
+    # an unknown backend is refused at creation, with a message that needs no context
+    h = C.c_void_p()
+    assert lib.sgs_create(0, 7, C.byref(h)) == -5 and b"SGS_BACKEND_HIP" in lib.sgs_last_error(None)
+    # the context still renders after all of that
+    img, st = drv.render(onp.Camera(32, 32, 30.0, 30.0, 16.0, 16.0, np.eye(4, dtype=np.float32)))
+    assert np.isfinite(img).all() and st["n_gaussians"] == 200
