@@ -625,13 +625,16 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
     const unsigned xcd = xcc_id();
-    for (int i = tid; i < P.win_tiles; i += SGS_BIN_THREADS) s_cnt[i] = 0;
     const int n_sweeps = bin_sweeps(P);
     unsigned n_vis = 0;
     const unsigned b = bin_b(P);
     {
         const int w = bin_w(P);
         const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
+        // the counters this window can touch, rounded up to whole flush rounds (a band or a small frame spans far
+        // fewer than the window's capacity)
+        const int used = min(P.win_tiles, (((wr1 - wr0) * P.gx + 127) / 128) * 128);
+        for (int i = tid; i < used; i += SGS_BIN_THREADS) s_cnt[i] = 0;
         if (tid == 0) s_nlist = 0;
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
@@ -652,14 +655,14 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         uint2* out = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
         {
             const int lane = tid & 63, wave = tid >> 6;
-            const int kPerWave = P.win_tiles / (SGS_BIN_THREADS / 64);
-            for (int i0 = 0; i0 < kPerWave; i0 += 128) {           // two rounds per trip: two atomics in flight per lane
+            // waves interleave 128-tile slabs of the used counters; two rounds per trip: two atomics in flight per lane
+            for (int i0 = wave * 128; i0 < used; i0 += (SGS_BIN_THREADS / 64) * 128) {
                 unsigned tl[2], c[2], pre[2], base[2];
                 unsigned long long m[2];
                 unsigned tot = 0;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    tl[u] = (unsigned)(wave * kPerWave + i0 + u * 64 + lane);
+                    tl[u] = (unsigned)(i0 + u * 64 + lane);
                     c[u] = s_cnt[tl[u]];
                     m[u] = __ballot(c[u] != 0u);
                     pre[u] = tot + (unsigned)__popcll(m[u] & lanemask_lt(lane));
