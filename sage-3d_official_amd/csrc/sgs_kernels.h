@@ -1085,34 +1085,25 @@ template <bool AUX> struct ColOf { typedef float2 type; };
 template <> struct ColOf<true> { typedef float4 type; };
 
 // ------------------------------------------------------------------------------------------------
-// S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.
+// S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.  One workgroup per 16x16 tile,
+// one lane per pixel, each of the four waves owns an 8x8 quadrant.
 //
-// Measured on the 3 M-Gaussian scene: a tile's queue holds ~900 records on average (up to 20 k), but
-// its pixels saturate after ~200 (p99 ~1000) — 80 % of a fully sorted queue is never read.  So the
-// workgroup of a tile
+// Measured on the 3 M-Gaussian scene: a tile's queue holds ~500 records on average (up to 15 k), but its pixels
+// saturate after ~140 — most of a fully sorted queue would never be read.  So the workgroup of a tile
 //   1. partitions its queue into SGS_NB depth buckets with one MSD pass on the fp32 depth bits
-//      (bucket = (bits >> 18) - (bits(near) >> 18): 32 buckets per binade of view depth, so buckets are
-//      fine near the camera where it matters); counters in LDS; queues of <= SGS_QCAP records are
-//      read from HBM once and partitioned inside LDS, longer ones go through the alt buffers (queues
-//      of <= SGS_GROUP records skip the partition and form a single group);
-//   2. walks the buckets front to back in groups of about SGS_GROUP records: loads a group into LDS as
-//      (depth << 32 | slot) words, orders it with the rank sort above and blends it;
+//      (bucket = (bits >> 18) - (bits(near) >> 18): 32 buckets per binade of view depth, so buckets are fine near
+//      the camera where it matters); counters in LDS.  Queues of <= SGS_QCAP records are read from HBM once and
+//      live in LDS from then on, bucket-contiguous; longer ones stay in HBM and a WINDOW of whole buckets is
+//      filled by one coalesced re-scan and serves several groups (queues of <= SGS_GROUP records skip the partition);
+//   2. takes the buckets front to back in groups of about SGS_GROUP records.  A group of <= SGS_BATCH records (the
+//      common case) is handled in one go: every lane owns a record, issues the gather of its 48-B splat, ranks the
+//      record inside its own bucket while the loads are in flight, and stores the splat at staging[rank] together
+//      with the quadrants it can reach (axis-aligned extent, then the exact ellipse/rectangle test); each wave
+//      compacts its quadrant's splats into a private list and blends them four per trip.  Larger groups (one
+//      oversized bucket) are rank-sorted with 2-4 records per lane and streamed through the staging area in
+//      batches; a bucket beyond SGS_QCAP (thousands of splats within 2 % of one depth) is radix-sorted through HBM;
 //   3. stops as soon as every pixel of the tile has terminated.
-// A single bucket may hold up to SGS_QCAP records (rank sort with 2-4 records per lane); one longer
-// than that (thousands of splats within 2 % of one depth) is radix-sorted through HBM, ping-ponging
-// between the two record buffers.
-//
-// Blend stage: one lane per pixel, each wave owns an 8x8 quadrant.  A group is streamed through LDS
-// in batches of 256 splats:
-//   * every lane gathers one 48-B splat of the NEXT batch into registers while the current batch is
-//     being blended (global latency hidden behind the VALU work);
-//   * when staging a batch, the gathering lane tests its splat against the four quadrants (the
-//     axis-aligned extent of the alpha >= 1/255 ellipse, padded) and the four ballots are stored in LDS,
-//     so each wave walks only the splats that can touch ITS 64 pixels, with scalar bit scans;
-//   * the per-pixel body is branch-free (predicated), and the LDS reads of splat k+1 are issued
-//     before the arithmetic of splat k.
-// Block b is mapped so that consecutive blocks on one XCD (b % 8) render neighbouring tiles, which
-// share most of their splats -> the gathers hit that XCD's L2.
+// Workgroup b renders position b of k_tile_scan's longest-queue-first order.
 #define SGS_BATCH 256
 #define SGS_NB 256
 #define SGS_BUCKET_SHIFT 18
