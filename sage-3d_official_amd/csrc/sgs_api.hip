@@ -271,12 +271,19 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
         stream = L.stream;
     }
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE, gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
-    if ((rc = ensure_splats(ctx, L, scene->n)) != SGS_OK) return rc;
-    if ((rc = ensure_tiles(ctx, L, gx * gy)) != SGS_OK) return rc;
-    if ((rc = ensure_records(ctx, L)) != SGS_OK) return rc;
     FrameParams P;
+    // a pipelined frame sizes the intermediates of ALL lanes (once: the ensure_* are no-ops afterwards), so that no
+    // later frame of the sweep stops to allocate
+    for (int l = pipelined ? 0 : lane; l < (pipelined ? ctx->n_lanes : lane + 1); ++l) {
+        Lane& A = ctx->lanes[l];
+        if ((rc = ensure_splats(ctx, A, scene->n)) != SGS_OK) return rc;
+        if ((rc = ensure_tiles(ctx, A, gx * gy)) != SGS_OK) return rc;
+        if ((rc = ensure_records(ctx, A)) != SGS_OK) return rc;
+        fill_params(P, ctx, A, scene, cam, cfg, row_begin, row_end);
+        if ((rc = ensure_blk_list(ctx, A, std::max(1, P.n_windows), P.win_tiles)) != SGS_OK) return rc;
+        if (pipelined && (rc = ensure_lane_stream(ctx, A)) != SGS_OK) return rc;
+    }
     fill_params(P, ctx, L, scene, cam, cfg, row_begin, row_end);
-    if ((rc = ensure_blk_list(ctx, L, std::max(1, P.n_windows), P.win_tiles)) != SGS_OK) return rc;
     if ((P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, L)) != SGS_OK) return rc;
     if (pipelined) {
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
