@@ -192,6 +192,7 @@ def main():
     # ---- per-frame algorithmic bytes of rank 0's frames (deterministic; outside the timed region) -----
     stage_bytes = {n: 0 for n in STAGE_NAMES}
     iso_ms = {n: 0.0 for n in STAGE_NAMES}                 # the same launches one frame at a time (no overlap)
+    frame_ms = []                                          # GPU time of each of those frames, first launch -> last
     counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
     if rank == 0:
         rows = sharded.g.band if rows_primary else None
@@ -201,6 +202,7 @@ def main():
             else:
                 r.render(cams[(W + i) % len(cams)], gs, out_band=sharded.g.slab, tile_rows=rows, timing=timing)
             st = r.last_stats
+            frame_ms.append(st["ms_total"])
             for n in STAGE_NAMES:
                 iso_ms[n] += st["ms"][n]
             for n in STAGE_NAMES:
@@ -253,6 +255,9 @@ def main():
                                "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf,
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
                                "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
+                               "frame_ms_alone": ({"p10": float(np.percentile(frame_ms, 10)), "p50": float(np.percentile(frame_ms, 50)),
+                                                   "p90": float(np.percentile(frame_ms, 90)), "mean": float(np.mean(frame_ms))}
+                                                  if frame_ms and timing else None),
                                "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
                                "note": "the dominant kernel is VALU-issue-bound, not HBM-bound (valu_busy = share of its cycles "
                                        "with the vector ALU executing, from the committed PMC passes); ms = HIP-event duration inside the timed region (frames overlap when "
