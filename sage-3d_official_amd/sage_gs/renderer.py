@@ -256,8 +256,16 @@ class Renderer:
             return out, [s.as_dict() for s in stats]
         return out
 
-    def pack_rgba8(self, rgb: torch.Tensor) -> torch.Tensor:
-        """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns."""
+    def pack_rgba8(self, rgb: torch.Tensor, tonemap: Optional[str] = None) -> torch.Tensor:
+        """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns.
+
+        tonemap="reinhard" applies x / (1 + x) first — the operator the reference's stage selects
+        (Data/template.usda:102,196).  An optional host-side op, off by default and outside the
+        parity contract: the simulator's exposure/white-point settings are not reproduced, frames stay linear otherwise."""
+        if tonemap is not None:
+            if tonemap != "reinhard":
+                raise ValueError("tonemap must be None or 'reinhard'")
+            rgb = rgb / (1.0 + rgb.clamp_min(0.0))
         h, w = int(rgb.shape[0]), int(rgb.shape[1])
         out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
         self._lib.check(self._lib.sgs_pack_rgba8(self._ctx, rgb.contiguous().data_ptr(), out.data_ptr(), w, h,

@@ -376,6 +376,11 @@ def test_pack_rgba8(drv):
     out = drv.r.pack_rgba8(rgb).cpu().numpy()
     exp = (np.clip(rgb.cpu().numpy(), 0, 1) * 255.0 + 0.5).astype(np.uint8)
     assert (out[..., :3] == exp).all() and (out[..., 3] == 255).all()
+    # the optional Reinhard operator of the reference's stage (template.usda:102,196): x / (1 + x) before quantisation
+    tm = drv.r.pack_rgba8(rgb, tonemap="reinhard").cpu().numpy()
+    x = np.maximum(rgb.cpu().numpy(), 0.0)
+    exp_tm = (np.clip(rgb.cpu().numpy() / (1.0 + x), 0, 1) * 255.0 + 0.5).astype(np.uint8)
+    assert np.abs(tm[..., :3].astype(int) - exp_tm.astype(int)).max() <= 1 and (tm[..., 3] == 255).all()
 
 
 def test_render_function_surface():
