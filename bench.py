@@ -47,6 +47,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
+    ap.add_argument("--event-stride", type=int, default=4,
+                    help="bracket the stages of every n-th frame of the timed region with HIP events (recording them on "
+                         "every frame costs ~4 %% of the sweep's throughput; the per-stage times are averages over the "
+                         "sampled frames)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
                          "independent frames in flight on the library's internal streams)")
@@ -134,7 +138,8 @@ def main():
         """`count` steps, one frame per rank per step, no data-path collective.  Returns this rank's per-frame average
         statistics; every frame of the region is checked for overflow."""
         for i in range(count):
-            r.render(cam_of_step(first + i, rank), gs, out=frames[i % len(frames)], sync=False, timing=timed, pipelined=pipelined)
+            r.render(cam_of_step(first + i, rank), gs, out=frames[i % len(frames)], sync=False,
+                     timing=timed and i % max(1, args.event_stride) == 0, pipelined=pipelined)
         return r.sync() if count else None                # completes the frames in flight (all lanes)
 
     def run_rows(first, count, timed):
@@ -259,6 +264,7 @@ def main():
                                                    "p90": float(np.percentile(frame_ms, 90)), "mean": float(np.mean(frame_ms))}
                                                   if frame_ms and timing else None),
                                "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
+                               "events_on_every_nth_frame": max(1, args.event_stride),
                                "note": "the dominant kernel is VALU-issue-bound, not HBM-bound (valu_busy = share of its cycles "
                                        "with the vector ALU executing, from the committed PMC passes); ms = HIP-event duration inside the timed region (frames overlap when "
                                        "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
