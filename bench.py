@@ -245,7 +245,7 @@ def main():
                              "ms_alone": iso_ms[n] / frames_here}
             dom = max(STAGE_NAMES, key=lambda n: ms[n])
             ach = stages[dom]["GBps"] or 0.0
-            traffic = valu_busy = lds_conf = None
+            traffic = valu_busy = lds_conf = valu_insts = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tpath):
                 try:                         # PMC passes of the same frames (scripts/gpu_round_profile.sh), committed
@@ -253,11 +253,21 @@ def main():
                     traffic = tj.get(dom)
                     valu_busy = tj.get("_valu_busy", {}).get(dom)
                     lds_conf = tj.get("_lds_bank_conflict_share", {}).get(dom)
+                    valu_insts = tj.get("_valu_insts", {}).get(dom)
                 except Exception:
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                                "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf,
+                               # fp32-VALU fraction of the composite.  Lane operations (wave instructions x 64,
+                               # an FMA counted once) per second of the launch alone, against 256 CUs x 4 SIMDs x 32 lanes
+                               # x 2.4 GHz = 78.6 T lane-ops/s (the 157 TFLOP/s fp32 peak counts an FMA twice)
+                               "valu": ({"inst_per_launch": valu_insts,
+                                         "lane_ops_per_s": valu_insts * 64.0 / (iso_ms[dom] / frames_here * 1e-3),
+                                         "peak_lane_ops_per_s": 78.6e12,
+                                         "frac": valu_insts * 64.0 / (iso_ms[dom] / frames_here * 1e-3) / 78.6e12,
+                                         "basis": "SQ_INSTS_VALU of the committed PMC passes / ms_alone"}
+                                        if valu_insts and iso_ms[dom] > 0 else None),
                                "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
                                "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
                                "frame_ms_alone": ({"p10": float(np.percentile(frame_ms, 10)), "p50": float(np.percentile(frame_ms, 50)),

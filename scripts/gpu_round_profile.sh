@@ -48,6 +48,7 @@ out["_valu_busy"] = {s: max((d[k]["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0) / (d[k]
                      for s, ks in stage.items()}
 out["_lds_bank_conflict_share"] = {s: max(d[k]["SQ_LDS_BANK_CONFLICT"] / max(1.0, d[k]["SQ_LDS_IDX_ACTIVE"]) for k in ks if k in d)
                                    for s, ks in stage.items()}
+out["_valu_insts"] = {s: sum(d[k]["SQ_INSTS_VALU"] for k in ks if k in d) for s, ks in stage.items()}   # wave instructions per launch
 out["_note"] = ("HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc (separate passes, --kernel-trace only), "
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM and this repo's own calibration (profiles/r01_hbm_calib_*.csv: "
                 "2 GiB streamed reads report 1 GiB at 16 and at 4 B/lane; streamed writes are exact); averaged over the launches of "
