@@ -96,6 +96,13 @@ typedef struct sgs_config {
     float bg[3];           /* background, linear RGB (Data/template.usda tonemap is NOT applied) */
     int32_t sh_degree;     /* -1 = the scene's degree                                   */
     uint32_t flags;        /* SGS_FLAG_*                                                */
+    /* Interleaved tile rows (multi-GPU sharding of one frame): with stride S > 1 the call owns
+     * the tile rows phase, phase + S, phase + 2S, ... of the frame — every rank gets the same mix of cheap and
+     * expensive rows, whatever the camera looks at.  tile_row_begin/_end then index the OWNED rows (0 .. their
+     * count; end < 0 = all of them) and out_rgb is a COMPACT image: owned row k occupies pixel rows
+     * [16k, 16k+16) of it.  0 or 1 = the contiguous band [tile_row_begin, tile_row_end) of the frame itself. */
+    int32_t tile_row_stride;
+    int32_t tile_row_phase;
 } sgs_config;
 
 typedef struct sgs_stats {

@@ -217,7 +217,10 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     if (cam->width <= 0 || cam->height <= 0 || cam->width > 65535 * SGS_TILE || cam->height > 65535 * SGS_TILE)
         SGS_FAIL(ctx, SGS_ERR_INVALID, "bad resolution %dx%d", cam->width, cam->height);
     if (!(cam->fx > 0.f) || !(cam->fy > 0.f)) SGS_FAIL(ctx, SGS_ERR_INVALID, "focal lengths must be positive");
-    const int gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    const int stride = cfg && cfg->tile_row_stride > 1 ? cfg->tile_row_stride : 1, phase = cfg && stride > 1 ? cfg->tile_row_phase : 0;
+    if (phase < 0 || phase >= stride) SGS_FAIL(ctx, SGS_ERR_INVALID, "tile_row_phase %d outside [0, stride %d)", phase, stride);
+    const int gy_frame = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    const int gy = gy_frame > phase ? (gy_frame - phase + stride - 1) / stride : 0;      // rows this call owns
     if (row_end < 0 || row_end > gy) row_end = gy;
     if (row_begin < 0) row_begin = 0;
     if (row_begin > row_end) SGS_FAIL(ctx, SGS_ERR_INVALID, "tile_row_begin %d > tile_row_end %d", row_begin, row_end);
@@ -245,6 +248,11 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.width = cam->width; P.height = cam->height;
     P.gx = (cam->width + SGS_TILE - 1) / SGS_TILE; P.gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
     P.row_begin = row_begin; P.row_end = row_end;
+    P.row_stride = cfg.tile_row_stride > 1 ? cfg.tile_row_stride : 1;
+    P.row_phase = P.row_stride > 1 ? cfg.tile_row_phase : 0;
+    // a contiguous band ignores what projects outside its pixel rows; interleaved rows span the frame
+    P.cull_y0 = P.row_stride > 1 ? 0 : SGS_TILE * row_begin;
+    P.cull_y1 = P.row_stride > 1 ? SGS_TILE * P.gy : SGS_TILE * row_end;
     P.sh_degree = cfg.sh_degree < 0 ? scene->sh_degree : std::min(cfg.sh_degree, scene->sh_degree);
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
@@ -351,8 +359,12 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     ctx->last_T = gx * gy;
     ctx->last_t_lo = row_begin * gx; ctx->last_t_hi = row_end * gx;
     ctx->last_scene = scene;
-    const int y0 = row_begin * SGS_TILE, y1 = std::min(row_end * SGS_TILE, cam->height);
-    ctx->last_pixels = (int64_t)std::max(0, y1 - y0) * cam->width;
+    int64_t pixel_rows = 0;                       // pixel rows of the frame this call wrote
+    for (int k = row_begin; k < row_end; ++k) {
+        const int y0 = (k * P.row_stride + P.row_phase) * SGS_TILE;
+        pixel_rows += std::max(0, std::min(y0 + SGS_TILE, cam->height) - y0);
+    }
+    ctx->last_pixels = pixel_rows * cam->width;
     return SGS_OK;
 }
 
@@ -400,6 +412,7 @@ void sgs_config_default(sgs_config* cfg) {
     cfg->alpha_min = 1.0f / 255.0f; cfg->alpha_max = 0.99f; cfg->t_min = 1.0e-4f;
     cfg->bg[0] = cfg->bg[1] = cfg->bg[2] = 0.f;
     cfg->sh_degree = -1; cfg->flags = 0;
+    cfg->tile_row_stride = 1; cfg->tile_row_phase = 0;
 }
 
 const char* sgs_last_error(const sgs_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }

@@ -57,6 +57,8 @@ struct FrameParams {
     int32_t win_tiles;              // SGS_WT or SGS_WT_BIG: counters a binning workgroup keeps in (dynamic) LDS
     int64_t rec_capacity;           // records the queues can hold
     uint32_t flags;
+    int32_t row_stride, row_phase;  // interleaved tile rows: local row k of this call is frame row k * row_stride + row_phase
+    int32_t cull_y0, cull_y1;       // pixel rows outside [cull_y0, cull_y1) cannot matter to this call (conservative)
     uint32_t pad_;
 };
 

@@ -177,6 +177,14 @@ __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
     return (int)f;
 }
 
+// The first row this call owns that is not above frame tile row f (clamped to [row_begin, row_end]): frame rows [a, b)
+// are the owned rows [owned_row(a), owned_row(b)).  Owned row k is frame row k * row_stride + row_phase.
+__device__ __forceinline__ int owned_row(const FrameParams& P, int f) {
+    int k = f;
+    if (P.row_stride > 1) k = f > P.row_phase ? (f - P.row_phase + P.row_stride - 1) / P.row_stride : 0;
+    return min(max(k, P.row_begin), P.row_end);
+}
+
 // One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
 __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const float4* __restrict__ geom,
                                                  const float4* __restrict__ shq, Splat* __restrict__ splats,
@@ -217,7 +225,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float pxf = P.fx * (float)tx * inv + P.cx - 0.5f, pyf = P.fy * (float)ty * inv + P.cy - 0.5f;
         const float ex = 1.0e-5f * fabsf(pxf) + 0.01f, ey = 1.0e-5f * fabsf(pyf) + 0.01f;
         const bool out_x = pxf + rb + ex < 1.0f || pxf - rb - ex >= (float)(SGS_TILE_PX * P.gx);
-        const bool out_y = pyf + rb + ey < (float)(SGS_TILE_PX * P.row_begin) + 1.0f || pyf - rb - ey >= (float)(SGS_TILE_PX * P.row_end);
+        const bool out_y = pyf + rb + ey < (float)P.cull_y0 + 1.0f || pyf - rb - ey >= (float)P.cull_y1;
         maybe = !(out_x || out_y);                   // (NaN anywhere keeps the Gaussian)
     }
     if (maybe) {
@@ -273,8 +281,11 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const double py = fy * yz + (double)P.cy - 0.5;
             const int x0 = tile_clamp((px - radius) / SGS_TILE_PX, 0, P.gx);
             const int x1 = tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gx);
-            const int y0 = tile_clamp((py - radius) / SGS_TILE_PX, P.row_begin, P.row_end);
-            const int y1 = tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, P.row_begin, P.row_end);
+            // frame rows [fy0, fy1) -> the rows this call owns: the contiguous band, or every row_stride-th row from
+            // row_phase (then a rect's rows are again a contiguous range of OWNED rows, so binning never knows)
+            const int fy0 = tile_clamp((py - radius) / SGS_TILE_PX, 0, P.gy);
+            const int fy1 = tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gy);
+            const int y0 = owned_row(P, fy0), y1 = owned_row(P, fy1);
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
                 vis = true;
@@ -296,7 +307,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                         const float lo_x = ceilf((fpx - hx - epx - 15.0f) * (1.0f / SGS_TILE_PX)), hi_x = floorf((fpx + hx + epx) * (1.0f / SGS_TILE_PX)) + 1.0f;
                         const float lo_y = ceilf((fpy - hy - epy - 15.0f) * (1.0f / SGS_TILE_PX)), hi_y = floorf((fpy + hy + epy) * (1.0f / SGS_TILE_PX)) + 1.0f;
                         const int bx0 = max(x0, (int)fmaxf(lo_x, -1.0e6f)), bx1 = min(x1, (int)fminf(hi_x, 1.0e6f));
-                        const int by0 = max(y0, (int)fmaxf(lo_y, -1.0e6f)), by1 = min(y1, (int)fminf(hi_y, 1.0e6f));
+                        const int by0 = owned_row(P, max(fy0, (int)fmaxf(lo_y, -1.0e6f))), by1 = owned_row(P, min(fy1, (int)fminf(hi_y, 1.0e6f)));
                         if (bx1 > bx0 && by1 > by0) {
                             brect01 = (unsigned)bx0 | ((unsigned)by0 << 16); brect23 = (unsigned)bx1 | ((unsigned)by1 << 16);
                             bnt = (bx1 - bx0) * (by1 - by0);
@@ -1187,10 +1198,14 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     const unsigned tile = job.x;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
-    const unsigned py = tile_y * 16u + (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
+    // tile_y counts the rows this call owns; the pixels it covers are those of frame row tile_y * stride + phase,
+    // and it is stored at row tile_y of the (compact, when stride > 1) output image
+    const unsigned frame_y = tile_y * (unsigned)P.row_stride + (unsigned)P.row_phase;
+    const unsigned in_y = (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
+    const unsigned py = frame_y * 16u + in_y, out_py = tile_y * 16u + in_y;
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     const float fpx = (float)px, fpy = (float)py;
-    const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(tile_y * 16u);
+    const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
     const float amin = P.alpha_min, amax = P.alpha_max, tmin = P.t_min;
     const int tmin_bits = (int)__float_as_uint(tmin);
     const float l2_inv_amin = -__log2f(amin);          // alpha >= amin  <=>  q2 <= log2(o) + l2_inv_amin
@@ -1579,11 +1594,11 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     }
 #endif
     if (inside) {
-        float* o = out_rgb + ((size_t)py * P.width + px) * 3;
+        float* o = out_rgb + ((size_t)out_py * P.width + px) * 3;
         const float Tf = __builtin_fabsf(T);            // a finished pixel holds its final transmittance negated
         o[0] = C0 + Tf * P.bg[0]; o[1] = C1 + Tf * P.bg[1]; o[2] = C2 + Tf * P.bg[2];
         if (AUX) {                        // expected depth sum(T alpha z) and coverage 1 - T_final
-            float* a = out_aux + ((size_t)py * P.width + px) * 2;
+            float* a = out_aux + ((size_t)out_py * P.width + px) * 2;
             a[0] = Dz; a[1] = 1.0f - Tf;
         }
     }

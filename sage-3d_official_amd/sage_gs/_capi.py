@@ -43,7 +43,7 @@ class SgsConfig(C.Structure):
     _fields_ = [("near_z", C.c_float), ("far_z", C.c_float), ("dilation", C.c_float),
                 ("clamp", C.c_float), ("alpha_min", C.c_float), ("alpha_max", C.c_float),
                 ("t_min", C.c_float), ("bg", C.c_float * 3), ("sh_degree", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("tile_row_stride", C.c_int32), ("tile_row_phase", C.c_int32)]
 
 
 class SgsStats(C.Structure):

@@ -6,6 +6,17 @@ generate_images.py:136-139); this is BASELINE.json's design: every rank holds th
 rows, and the bands are gathered to rank 0 over xGMI.  Tiles are independent after binning, so the
 gathered frame is bit-identical to a single-GPU frame (tests: tile-row union == full frame).
 
+Which rows a rank owns: a contiguous band of equal height by default, or (`interleave=True`) every R-th row — rank r of R
+owns frame tile rows r, r+R, r+2R, ...  An indoor view puts most of its depth complexity into a few rows around the
+horizon, so equal bands are uneven (the slowest of 8 ranks carries 1.5x the mean of the 256-pose sweep) while every R-th
+row gives each rank the same mix whatever the camera looks at.  Interleaved rows are stored compactly
+(`Renderer.render(interleave=(R, r))`), so slabs stay equal-size and the collective is unchanged; rank 0 re-interleaves
+the rows when it hands out a frame (one device copy).  It is opt-in because it does not pay on the indoor sweep
+(measured per rank on one MI355X, frames pipelined, ms per frame of the slowest rank, contiguous -> interleaved:
+R=2 0.168 -> 0.171, R=4 0.136 -> 0.134, R=8 0.112 -> 0.101): a splat covers 2-3 tile rows, so every rank then projects,
+shades and bins ~1.7x the splats a contiguous band sees, and the copy on rank 0 eats what is left.  Bands balanced by
+queue length did better in the same experiment (R=8 0.087, R=4 0.116) but need a calibration pass and unequal slabs.
+
 The one exchange step is a gather of equal-size slabs (`torch.distributed.gather`; backend "nccl" is
 RCCL on ROCm, "gloo" in the CPU tests).  Rank 0 receives straight into views of its frame buffer,
 so there is no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.3 MB per rank at 8 ranks): seven
@@ -50,8 +61,10 @@ class FrameGather:
     (a sweep's frames are independent, so their bands can travel together: one collective per B frames)."""
 
     def __init__(self, height: int, width: int, device, rank: Optional[int] = None, world: Optional[int] = None,
-                 group=None, dst: int = 0, channels: int = 3, dtype=torch.float32, batch: Optional[int] = None):
+                 group=None, dst: int = 0, channels: int = 3, dtype=torch.float32, batch: Optional[int] = None,
+                 interleave: bool = False):
         self.group = group
+        self.interleave = bool(interleave)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
         self.dst, self.h, self.w = dst, height, width
@@ -60,6 +73,9 @@ class FrameGather:
         self.bands = row_partition(self.n_tile_rows, self.world)
         self.slab_rows = ((self.n_tile_rows + self.world - 1) // self.world) * TILE      # pixel rows per slab
         self.band = self.bands[self.rank]
+        if self.interleave:          # rank r owns frame rows r, r+world, ...; `band` then counts OWNED rows
+            self.bands = [(0, len(range(r, self.n_tile_rows, self.world))) for r in range(self.world)]
+            self.band = self.bands[self.rank]
         lead = () if batch is None else (int(batch),)
         # every rank's slab has the same shape; rank dst owns the padded buffer the slabs land in
         if self.rank == dst:
@@ -73,7 +89,24 @@ class FrameGather:
 
     @property
     def band_pixel_rows(self) -> Tuple[int, int]:
+        if self.interleave:
+            raise ValueError("interleaved rows are not one range of pixel rows")
         return self.band[0] * TILE, min(self.band[1] * TILE, self.h)
+
+    @property
+    def render_rows(self) -> dict:
+        """Keyword arguments for Renderer.render that select this rank's rows (out_band = a slab of this object)."""
+        if self.interleave:
+            return {"interleave": (self.world, self.rank)} if self.world > 1 else {"tile_rows": self.band}
+        return {"tile_rows": self.band}
+
+    def _assemble(self, padded: torch.Tensor) -> torch.Tensor:
+        """[world, slab_rows, W, C] -> [H, W, C]: a view for contiguous bands, one copy for interleaved rows."""
+        if self.interleave and self.world > 1:
+            k = self.slab_rows // TILE
+            v = padded.view(self.world, k, TILE, self.w, -1).permute(1, 0, 2, 3, 4)       # [k, world, 16, W, C]
+            return v.reshape(k * self.world * TILE, self.w, -1)[: self.h]
+        return padded.reshape(self.world * self.slab_rows, self.w, -1)[: self.h]
 
     def _collective(self, n: Optional[int], async_op: bool):
         src = self.slab if n is None else self.slab[:n]
@@ -92,14 +125,15 @@ class FrameGather:
         return dist.gather(src, outs, dst=self.dst, group=self.group, async_op=async_op)
 
     def gather(self) -> Optional[torch.Tensor]:
-        """Collective (single-frame buffers).  Returns the assembled [H,W,C] frame on rank dst (a view, no copy)."""
+        """Collective (single-frame buffers).  Returns the assembled [H,W,C] frame on rank dst (contiguous bands: a view
+        of the receive buffer, no copy)."""
         if self.batch is not None:
             raise ValueError("gather() is for single-frame buffers; use gather_batch()")
         if self.world > 1:
             self._collective(None, False)
         if self.rank != self.dst:
             return None
-        return self.padded.view(self.world * self.slab_rows, self.w, -1)[: self.h]
+        return self._assemble(self.padded)
 
     def gather_batch(self, n: Optional[int] = None, async_op: bool = False):
         """Collective over the first n frames of a batched buffer.  Returns the work handle (None when complete)."""
@@ -110,7 +144,8 @@ class FrameGather:
         return None
 
     def frames(self, n: Optional[int] = None) -> Optional[torch.Tensor]:
-        """Rank dst: the gathered batch as a [n, world, slab_rows, W, C] view (frame b = rows of [b] stacked, cut at H)."""
+        """Rank dst: the gathered batch as a [n, world, slab_rows, W, C] view (contiguous bands: frame b = rows of [b]
+        stacked, cut at H; interleaved: use frame(b))."""
         if self.rank != self.dst:
             return None
         v = self.padded.permute(1, 0, 2, 3, 4)
@@ -120,17 +155,18 @@ class FrameGather:
         """Rank dst: frame b of the gathered batch, assembled to [H,W,C] (one copy)."""
         if self.rank != self.dst:
             return None
-        return self.padded[:, b].reshape(self.world * self.slab_rows, self.w, -1)[: self.h]
+        return self._assemble(self.padded[:, b])
 
 
 class ShardedRenderer:
     """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows,
     the bands are gathered to rank `dst`."""
 
-    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8):
+    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8, interleave: bool = False):
         self.r = renderer
         self.h, self.w, self.group, self.dst = height, width, group, dst
-        self.g = FrameGather(height, width, renderer.device, group=group, dst=dst)
+        self.interleave = bool(interleave)
+        self.g = FrameGather(height, width, renderer.device, group=group, dst=dst, interleave=self.interleave)
         self.batch = int(batch)
         self._ring = None            # two batched buffers: one travels while the other is rendered into
         self._pending = [None, None]
@@ -141,7 +177,7 @@ class ShardedRenderer:
         """One frame: every rank renders its band into its slab and joins the gather; rank dst gets the frame."""
         r0, r1 = self.g.band
         if r1 > r0:
-            self.r.render(camera, scene, config=config, out_band=self.g.slab, tile_rows=(r0, r1), sync=sync)
+            self.r.render(camera, scene, config=config, out_band=self.g.slab, sync=sync, **self.g.render_rows)
         return self.g.gather()
 
     def render_batch(self, cameras, scene, *, config=None, timing=False):
@@ -153,8 +189,8 @@ class ShardedRenderer:
         if n == 0 or n > self.batch:
             raise ValueError(f"1..{self.batch} cameras per batch")
         if self._ring is None:
-            self._ring = [FrameGather(self.h, self.w, self.r.device, group=self.group, dst=self.dst, batch=self.batch)
-                          for _ in range(2)]
+            self._ring = [FrameGather(self.h, self.w, self.r.device, group=self.group, dst=self.dst, batch=self.batch,
+                                      interleave=self.interleave) for _ in range(2)]
         k = self._turn
         self._turn ^= 1
         if self._pending[k] is not None:           # the collective that last read this buffer
@@ -164,8 +200,8 @@ class ShardedRenderer:
         r0, r1 = g.band
         if r1 > r0:
             for b, cam in enumerate(cameras):
-                self.r.render(cam, scene, config=config, out_band=g.slab[b], tile_rows=(r0, r1), sync=False, pipelined=True,
-                              timing=timing)
+                self.r.render(cam, scene, config=config, out_band=g.slab[b], sync=False, pipelined=True, timing=timing,
+                              **g.render_rows)
             self.last_stats = self.r.sync()        # bands complete (all lanes) before the collective reads them
         self._pending[k] = g.gather_batch(n, async_op=True)
         return g

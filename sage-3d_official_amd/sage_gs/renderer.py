@@ -179,7 +179,7 @@ class Renderer:
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
-               return_aux=False, pipelined=False, loose_cull=False):
+               return_aux=False, pipelined=False, loose_cull=False, interleave=None):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
@@ -187,10 +187,26 @@ class Renderer:
         stored, at the top of the slab, and the slab is returned.  sync=False enqueues on the current
         stream without waiting (collect with .sync()).  pipelined=True (with sync=False) lets the frame overlap
         with other pipelined frames on the library's internal streams: for sweeps of independent frames; the
-        output is complete only after .sync()."""
+        output is complete only after .sync().
+
+        interleave=(stride, phase) renders the tile rows phase, phase+stride, ... of the frame (the balanced way to
+        shard one frame over `stride` GPUs) into `out_band`, a COMPACT [>= 16 * owned rows, W, 3] image: owned row k
+        (frame tile row k*stride + phase) is stored at pixel rows [16k, 16k+16).  tile_rows then indexes owned rows."""
         scene = self._scene_of(gaussians)
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
-        if out_band is not None:
+        stride, phase = (1, 0) if interleave is None else (int(interleave[0]), int(interleave[1]))
+        if stride > 1:
+            if out_band is None or out is not None or return_aux or out_aux is not None:
+                raise ValueError("interleave renders into out_band (a compact image of the owned rows) only")
+            if not 0 <= phase < stride:
+                raise ValueError(f"interleave phase {phase} outside [0, {stride})")
+            owned = len(range(phase, camera.tile_rows, stride))
+            need = 16 * (owned if r1 < 0 else min(r1, owned))
+            if (out_band.device != self.device or out_band.dtype != torch.float32 or not out_band.is_contiguous()
+                    or out_band.dim() != 3 or out_band.shape[0] < need or tuple(out_band.shape[1:]) != (camera.width, 3)):
+                raise ValueError("out_band must be a contiguous float32 [>= 16 * owned rows, W, 3] tensor on the device")
+            ptr, ret = out_band.data_ptr(), out_band
+        elif out_band is not None:
             if tile_rows is None:
                 raise ValueError("out_band needs tile_rows")
             y0, y1 = r0 * 16, min(r1 * 16, camera.height)
@@ -212,6 +228,7 @@ class Renderer:
                 (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
+        cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
         if return_aux or out_aux is not None:
             # f-4: [H,W,2] = expected view depth sum(T alpha z), coverage 1 - T_final (full-frame buffers only)
             if out_band is not None:

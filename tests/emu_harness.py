@@ -67,7 +67,7 @@ class EmuRenderer:
         self.scene = sc
         self.n = arrs[0].shape[0]
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None):
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
         flags |= _capi.FLAG_LOOSE_CULL if loose_cull else 0
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
@@ -80,6 +80,10 @@ class EmuRenderer:
                 k.bg[i] = cfg.background[i]
             k.sh_degree = cfg.sh_degree
         k.flags = flags
+        if interleave is not None:         # (stride, phase): compact image of the owned tile rows
+            k.tile_row_stride, k.tile_row_phase = interleave
+            owned = len(range(interleave[1], (cam.height + 15) // 16, interleave[0]))
+            out = np.full((16 * owned, cam.width, 3), -1.0, np.float32)
         if out is None:
             out = np.zeros((cam.height, cam.width, 3), np.float32)
         st = _capi.SgsStats()

@@ -135,6 +135,39 @@ def case_empty(drv):
     assert st["n_visible"] == 0 and st["d_total"] == 0 and (img == 0).all()
 
 
+def case_interleaved_rows(drv, stride, n=2500, res=(208, 150)):
+    """Interleaved tile-row shards (rank p of `stride` owns frame rows p, p+stride, ...): every shard's compact image
+    holds exactly those rows of the full frame, bit for bit, and the shards' queues add up to the frame's."""
+    scene = random_scene(n, 7, 2, scale=(0.03, 0.3))
+    w, h = res
+    cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    full, st_full = drv.render(cam)
+    _, st_full_ref = drv.render(cam, loose_cull=True)
+    gy = (h + 15) // 16
+    d_sum = d_ref_sum = pix = 0
+    seen = np.zeros(gy, bool)
+    for phase in range(stride):
+        img, st = drv.render(cam, interleave=(stride, phase))
+        _, st_ref = drv.render(cam, interleave=(stride, phase), loose_cull=True)
+        owned = list(range(phase, gy, stride))
+        assert img.shape[0] == 16 * len(owned) and st["n_tiles"] == len(owned) * ((w + 15) // 16)
+        for k, row in enumerate(owned):
+            y0, y1 = 16 * row, min(16 * row + 16, h)
+            assert (img[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"stride {stride} phase {phase}: frame row {row}"
+            assert (img[16 * k + (y1 - y0): 16 * k + 16] == -1).all(), "pixels below the frame must stay untouched"
+            seen[row] = True
+            pix += (y1 - y0) * w
+        d_sum += st["d_total"]; d_ref_sum += st_ref["d_total"]
+        # a sub-range of the owned rows: only those are written
+        if len(owned) >= 2:
+            part, st_p = drv.render(cam, rows=(1, 2), interleave=(stride, phase))
+            y0, y1 = 16 * owned[1], min(16 * owned[1] + 16, h)
+            assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
+    assert seen.all() and pix == w * h
+    assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
+
+
 def case_tile_rows(drv, n=2500, res=(208, 150)):
     """Tile-row shards: each band equals the oracle's band; their union equals the full frame bit-exactly."""
     scene = random_scene(n, 7, 2, scale=(0.03, 0.3))

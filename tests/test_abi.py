@@ -37,7 +37,7 @@ def test_version_and_default_config(lib):
 def test_struct_layouts_match_the_header(lib):
     from sage_gs import _capi
     assert C.sizeof(_capi.SgsCamera) == 2 * 4 + 4 * 4 + 16 * 4
-    assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4
+    assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4 + 2 * 4      # + tile_row_stride, tile_row_phase
     assert C.sizeof(_capi.SgsStats) == 112      # 5 i64, 4 i32, float[4], float, (pad), i64[4]
 
 

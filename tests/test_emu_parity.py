@@ -40,6 +40,11 @@ def test_tile_row_bands(drv):
     pc.case_tile_rows(drv, n=1200, res=(112, 100))
 
 
+@pytest.mark.parametrize("stride", [2, 3])
+def test_interleaved_tile_rows(drv, stride):
+    pc.case_interleaved_rows(drv, stride, n=1200, res=(112, 100))
+
+
 def test_depth_ties(drv):
     pc.case_depth_ties(drv)
 
@@ -181,6 +186,10 @@ def test_argument_errors_are_reported_not_swallowed(drv):
     expect_invalid(call(r0=2, r1=1), "tile_row_begin")
     bad = lib.default_config(); bad.sh_degree = 4
     expect_invalid(call(cfg=bad), "sh_degree")
+    bad = lib.default_config(); bad.tile_row_stride, bad.tile_row_phase = 2, 2
+    expect_invalid(call(cfg=bad), "tile_row_phase")
+    bad.tile_row_phase = -1
+    expect_invalid(call(cfg=bad), "tile_row_phase")
     assert lib.sgs_set_record_capacity(ctx, 0) == -1
     assert lib.sgs_debug_read(ctx, 999, None, 0) == -1
     # an unknown backend is refused at creation, with a message that needs no context

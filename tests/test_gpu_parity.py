@@ -30,11 +30,17 @@ class GpuDriver:
             self.scene.free()
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False, interleave=None):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
                                                   cfg.alpha_max, cfg.t_min, cfg.background, cfg.sh_degree)
+        if interleave is not None:         # (stride, phase): compact image of the owned tile rows
+            owned = len(range(interleave[1], (cam.height + 15) // 16, interleave[0]))
+            band = self.torch.full((16 * owned, cam.width, 3), -1.0, dtype=self.torch.float32, device="cuda:0")
+            img = self.r.render(c, self.scene, config=k, out_band=band, tile_rows=None if rows == (0, -1) else rows,
+                                full_sort=full_sort, loose_cull=loose_cull, interleave=interleave)
+            return img.cpu().numpy(), self.r.last_stats
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
         img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
                             full_sort=full_sort, loose_cull=loose_cull)
@@ -95,6 +101,11 @@ def test_empty_and_all_culled(drv):
 
 def test_tile_row_bands(drv):
     pc.case_tile_rows(drv, n=6000, res=(400, 300))
+
+
+@pytest.mark.parametrize("stride", [2, 3, 8])
+def test_interleaved_tile_rows(drv, stride):
+    pc.case_interleaved_rows(drv, stride)
 
 
 def test_depth_ties(drv):
