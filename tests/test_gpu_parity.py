@@ -197,6 +197,15 @@ def test_3m_scene_properties(drv, big_scene):
             band, _ = drv.render(ocam, None, (r0, r1))
             union[r0 * 16:min(r1 * 16, 1080)] = band[r0 * 16:min(r1 * 16, 1080)]
         assert (union == full).all()
+        # (3b) so do interleaved rows (rank p of 8 owns rows p, p+8, ...), and their queues add up to the frame's
+        union = np.zeros_like(full); d_sum = 0
+        for phase in range(8):
+            comp_img, st_p = drv.render(ocam, interleave=(8, phase))
+            for k, row in enumerate(range(phase, 68, 8)):
+                y0, y1 = 16 * row, min(16 * row + 16, 1080)
+                union[y0:y1] = comp_img[16 * k: 16 * k + (y1 - y0)]
+            d_sum += st_p["d_total"]
+        assert (union == full).all() and d_sum == st_prod["d_total"]
         # (4) idempotence / determinism
         again, _ = drv.render(ocam)
         assert (again == full).all()
