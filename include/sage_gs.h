@@ -159,7 +159,8 @@ int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
                     sgs_stats* stats, void* hip_stream);
 
 /* B frames of one scene, back to back, one synchronisation at the end — the frame loop of
- * generate_images.py:408-436.  out_rgb holds B consecutive frames; stats (nullable) B entries. */
+ * generate_images.py:408-436.  out_rgb holds B consecutive frames; stats (nullable) B entries.  (With
+ * cfg->tile_row_stride > 1 every frame still has a height*width*3 slot; its compact image starts at the slot.) */
 int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
                      const sgs_config* cfg, int tile_row_begin, int tile_row_end, float* out_rgb,
                      sgs_stats* stats, void* hip_stream);
