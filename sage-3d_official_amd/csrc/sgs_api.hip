@@ -167,7 +167,7 @@ int ensure_tiles(sgs_ctx* ctx, Lane& L, int tiles) {
     if ((rc = grow(ctx, L.tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_prof, (size_t)tiles * SGS_PROF_WORDS)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_order, (size_t)tiles)) != SGS_OK) return rc;
-    // k_tile_scan leaves every count it has consumed at zero, so one memset at allocation suffices
+    // k_bin_emit zeroes every count k_tile_scan has consumed, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
     L.tile_cap = tiles;
     return SGS_OK;
@@ -326,14 +326,16 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
         hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_count, L.blk_list, L.blk_len, st,
                            L.bin_prof);
-    hipLaunchKernelGGL(sgs::k_tile_scan, dim3(1), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
+    // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
+    const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
+    hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
                        L.tile_offset, L.tile_order, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
         hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
                            L.vismask, L.bigmask, L.big_list, L.tile_offset, L.blk_list, L.blk_len,
-                           L.rec, st);
+                           L.rec, L.tile_count, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);

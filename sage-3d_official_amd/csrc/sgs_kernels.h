@@ -380,77 +380,128 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4: exclusive scan of the tile counts (single workgroup), D and the longest queue.  A tile has
-// SGS_XCDS sub-counters — one per XCD the binning workgroups run on — so that the records an XCD
-// writes into a queue are contiguous and its L2 can write-combine them; the queue of tile t is
-// [offset[8t], offset[8t+8]).  Every count is cleared once consumed: no per-frame memset.
+// S4: exclusive scan of the tile counts, D, the longest queue and the render order.  A tile has SGS_XCDS
+// sub-counters — one per XCD the binning workgroups run on — so that the records an XCD writes into a queue are
+// contiguous and its L2 can write-combine them; the queue of tile t is [offset[8t], offset[8t+8]).
+//
+// One workgroup per 1024 tiles of the band, and NO communication between them: every workgroup reads ALL the band's
+// counters (256 KB at 1080p, L2-resident, every load coalesced and in flight together) and derives what it needs about the
+// other workgroups' tiles itself — the records queued before its own tiles, and the tiles per length class before them
+// and overall — then writes the offsets and render-order entries of its own 1024 tiles (one per thread).  A single
+// workgroup doing all of it was bound by ONE CU's memory pipeline (24 us at 1080p, 90 us at 3840x2160; batching its
+// loads or aggregating its LDS atomics changed nothing); reading 8x what is needed on 8 CUs is the cheaper trade.
+// The counters are cleared by k_bin_emit (the next launch), not here: other workgroups may still be reading them.
 #define SGS_SCAN_THREADS 1024
+#define SGS_SCAN_SLABS 8
+// Per (wave, class) ONE LDS atomic instead of 64 serialised ones on the same address: neighbouring tiles have queues
+// of similar length, so a wave holds two or three classes.  Returns the lane's position (old cursor + rank in its class).
+__device__ __forceinline__ unsigned class_take(unsigned* s_cls, unsigned cls, bool valid, int lane) {
+    unsigned pos = 0;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned lc = (unsigned)__shfl((int)cls, leader);
+        const bool mine = valid && cls == lc;
+        const unsigned long long m = __ballot(mine);
+        unsigned base = 0;
+        if (lane == leader) base = atomicAdd(&s_cls[lc], (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, leader);
+        if (mine) pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        todo &= ~m;
+    }
+    return pos;
+}
+__device__ __forceinline__ unsigned queue_class(unsigned c) { return c ? 32u - (unsigned)__clz((int)c) : 0u; }
+
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
-                                                                unsigned* __restrict__ tile_count,
+                                                                const unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
                                                                 uint4* __restrict__ tile_order,
                                                                 FrameStatus* __restrict__ st) {
-    __shared__ unsigned s_wsum[2][SGS_SCAN_THREADS / SGS_WAVE];
-    __shared__ unsigned s_wmax[SGS_SCAN_THREADS / SGS_WAVE];
-    __shared__ unsigned s_cls[33];                    // tiles per log2(queue length) class, then cursors
+    constexpr int NW = SGS_SCAN_THREADS / SGS_WAVE;
+    __shared__ unsigned s_all[33], s_before[33];      // tiles per log2(queue length) class: whole band / before my tiles
+    __shared__ unsigned s_cur[33];                    // my tiles' cursors: first render position of each class for them
+    __shared__ unsigned s_wa[NW], s_wb[NW], s_wm[NW], s_wi[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t_lo = P.row_begin * P.gx, t_hi = P.row_end * P.gx;      // the tiles this call renders
-    if (tid < 33) s_cls[tid] = 0;
+    const int t_lo = P.row_begin * P.gx, t_hi = P.row_end * P.gx;      // the tiles this call renders: rects are clipped
+    const int g = (int)blockIdx.x;                                     // to them in k_preprocess (a rank scans 1/N)
+    if (tid < 33) { s_all[tid] = 0; s_before[tid] = 0; }
     __syncthreads();
-    unsigned carry = 0, mx = 0;
-    // one tile per thread per round: 32-byte vector loads/stores, the eight sub-counts stay in registers
-    // only the band this call renders: rects are clipped to it in k_preprocess, every other tile's count is zero
-    // (a rank of a tile-row-sharded frame scans 1/N of the tiles)
-    for (int t0 = t_lo, rnd = 0; t0 < t_hi; t0 += SGS_SCAN_THREADS, ++rnd) {
-        const int t = t0 + tid;
-        uint4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;
-        if (t < t_hi) {
-            uint4* cp = reinterpret_cast<uint4*>(tile_count + (size_t)t * SGS_XCDS);
-            c0 = cp[0]; c1 = cp[1];
-            cp[0] = uint4{0u, 0u, 0u, 0u}; cp[1] = uint4{0u, 0u, 0u, 0u};
+    unsigned sum_all = 0, sum_before = 0, mx = 0;
+    uint4 m0 = {0u, 0u, 0u, 0u}, m1 = m0;            // my tile's eight sub-counts
+    for (int t0 = t_lo, slab0 = 0; t0 < t_hi; t0 += SGS_SCAN_THREADS * SGS_SCAN_SLABS, slab0 += SGS_SCAN_SLABS) {
+        uint4 c0[SGS_SCAN_SLABS], c1[SGS_SCAN_SLABS];
+#pragma unroll
+        for (int j = 0; j < SGS_SCAN_SLABS; ++j) {
+            const int t = t0 + j * SGS_SCAN_THREADS + tid;
+            c0[j] = uint4{0u, 0u, 0u, 0u}; c1[j] = c0[j];
+            if (t < t_hi) {
+                const uint4* cp = reinterpret_cast<const uint4*>(tile_count + (size_t)t * SGS_XCDS);
+                c0[j] = cp[0]; c1[j] = cp[1];
+            }
         }
-        const unsigned c = c0.x + c0.y + c0.z + c0.w + c1.x + c1.y + c1.z + c1.w;
-        mx = c > mx ? c : mx;
-        if (t < t_hi) atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u);
-        const unsigned incl = wave_incl_scan(c, lane);
-        if (lane == 63) s_wsum[rnd & 1][wave] = incl;
-        __syncthreads();
-        unsigned wbase = 0, total = 0;
-        for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) { const unsigned sw = s_wsum[rnd & 1][w]; if (w < wave) wbase += sw; total += sw; }
-        if (t < t_hi) {
-            unsigned run = carry + wbase + incl - c;
-            uint4 o0, o1;
-            o0.x = run; run += c0.x; o0.y = run; run += c0.y; o0.z = run; run += c0.z; o0.w = run; run += c0.w;
-            o1.x = run; run += c1.x; o1.y = run; run += c1.y; o1.z = run; run += c1.z; o1.w = run;
-            uint4* op = reinterpret_cast<uint4*>(tile_offset + (size_t)t * SGS_XCDS);
-            op[0] = o0; op[1] = o1;
+#pragma unroll
+        for (int j = 0; j < SGS_SCAN_SLABS; ++j) {
+            const int t = t0 + j * SGS_SCAN_THREADS + tid;
+            const unsigned c = c0[j].x + c0[j].y + c0[j].z + c0[j].w + c1[j].x + c1[j].y + c1[j].z + c1[j].w;
+            const bool before = slab0 + j < g;                         // slab k = the 1024 tiles of workgroup k (uniform)
+            sum_all += c; sum_before += before ? c : 0u;
+            mx = c > mx ? c : mx;
+            // tiles per class, counted per (wave, class)
+            unsigned long long todo = __ballot(t < t_hi);
+            const unsigned cls = queue_class(c);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const unsigned lc = (unsigned)__shfl((int)cls, leader);
+                const unsigned long long m = __ballot(t < t_hi && cls == lc);
+                if (lane == leader) { atomicAdd(&s_all[lc], (unsigned)__popcll(m)); if (before) atomicAdd(&s_before[lc], (unsigned)__popcll(m)); }
+                todo &= ~m;
+            }
+            if (slab0 + j == g) { m0 = c0[j]; m1 = c1[j]; }
         }
-        carry += total;
     }
-    const unsigned wmx = wave_max(mx);
-    if (lane == 0) s_wmax[wave] = wmx;
+    // records before my tiles, in the band; longest queue
+    const unsigned wa = wave_sum(sum_all), wb = wave_sum(sum_before), wm = wave_max(mx);
+    const int t = t_lo + g * SGS_SCAN_THREADS + tid;                   // my tile
+    const unsigned c = m0.x + m0.y + m0.z + m0.w + m1.x + m1.y + m1.z + m1.w;
+    const unsigned incl = wave_incl_scan(c, lane);
+    if (lane == 63) s_wi[wave] = incl;
+    if (lane == 0) { s_wa[wave] = wa; s_wb[wave] = wb; s_wm[wave] = wm; }
     __syncthreads();
-    // Render order: longest queues first (log2 classes).  k_tile_render's blocks are dispatched in index order
-    // and a long tile costs as much as the whole kernel's average share, so it must not start last.
-    if (tid == 0) {
-        unsigned run = 0;
-        for (int c = 32; c >= 0; --c) { const unsigned v = s_cls[c]; s_cls[c] = run; run += v; }
+    unsigned total = 0, base = 0, wbase = 0, tmax = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        total += s_wa[w]; base += s_wb[w]; tmax = s_wm[w] > tmax ? s_wm[w] : tmax;
+        wbase += w < wave ? s_wi[w] : 0u;
+    }
+    // Render order: longest queues first (log2 classes).  k_tile_render's blocks are dispatched in index order and a
+    // long tile costs as much as the whole kernel's average share, so it must not start last.  Inside a class: by tile.
+    if (tid < 33) {
+        unsigned first = 0;
+        for (int k = 32; k > tid; --k) first += s_all[k];
+        s_cur[tid] = first + s_before[tid];
     }
     __syncthreads();
-    for (int t = t_lo + tid; t < t_hi; t += SGS_SCAN_THREADS) {
-        const unsigned b = tile_offset[(size_t)t * SGS_XCDS];
-        const unsigned e = (t + 1 < t_hi) ? tile_offset[(size_t)(t + 1) * SGS_XCDS] : carry;
-        const unsigned c = e - b;
+    if (t < t_hi) {
+        unsigned run = base + wbase + incl - c;
+        const unsigned begin = run;
+        uint4 o0, o1;
+        o0.x = run; run += m0.x; o0.y = run; run += m0.y; o0.z = run; run += m0.z; o0.w = run; run += m0.w;
+        o1.x = run; run += m1.x; o1.y = run; run += m1.y; o1.z = run; run += m1.z; o1.w = run;
+        uint4* op = reinterpret_cast<uint4*>(tile_offset + (size_t)t * SGS_XCDS);
+        op[0] = o0; op[1] = o1;
+        (void)begin;
+    }
+    {
+        const unsigned pos = class_take(s_cur, queue_class(c), t < t_hi, lane);
         // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
-        tile_order[atomicAdd(&s_cls[c ? 32 - __clz((int)c) : 0], 1u)] = uint4{(unsigned)t, b, c, 0u};
+        if (t < t_hi) tile_order[pos] = uint4{(unsigned)t, base + wbase + incl - c, c, 0u};
     }
-    if (tid == 0) {
-        unsigned tmax = 0;
-        for (int w = 0; w < SGS_SCAN_THREADS / SGS_WAVE; ++w) tmax = s_wmax[w] > tmax ? s_wmax[w] : tmax;
-        tile_offset[(size_t)t_hi * SGS_XCDS] = carry;      // end of the band's last queue (k_bin_emit never reads past it)
-        st->d_total = carry;
+    if (g == 0 && tid == 0) {
+        tile_offset[(size_t)t_hi * SGS_XCDS] = total;      // end of the band's last queue (k_bin_emit never reads past it)
+        st->d_total = total;
         st->max_tile_len = tmax;
-        st->overflow = (unsigned long long)carry > (unsigned long long)P.rec_capacity ? 1u : 0u;
+        st->overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity ? 1u : 0u;
     }
 }
 
@@ -723,11 +774,18 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
                                                               const uint2* __restrict__ blk_list,
                                                               const unsigned* __restrict__ blk_len,
                                                               unsigned long long* __restrict__ rec,
+                                                              unsigned* __restrict__ tile_count,
                                                               const FrameStatus* __restrict__ st) {
     SGS_DYNAMIC_LDS(unsigned, s_next);               // P.win_tiles write cursors
     __shared__ LiveChunks lc;
-    if (st->overflow) return;
     const int tid = threadIdx.x;
+    {   // k_tile_scan has consumed the band's counters: zero again for the next frame (no per-frame memset), also
+        // when this frame overflowed
+        uint4* z = reinterpret_cast<uint4*>(tile_count + (size_t)P.row_begin * P.gx * SGS_XCDS);
+        const unsigned nz = (unsigned)((P.row_end - P.row_begin) * P.gx) * (SGS_XCDS / 4);
+        for (unsigned i = blockIdx.x * SGS_BIN_THREADS + tid; i < nz; i += gridDim.x * SGS_BIN_THREADS) z[i] = uint4{0u, 0u, 0u, 0u};
+    }
+    if (st->overflow) return;
     const unsigned b = bin_b(P);
     const int n_sweeps = bin_sweeps(P);
     {
