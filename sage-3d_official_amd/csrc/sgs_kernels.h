@@ -537,8 +537,16 @@ __device__ __forceinline__ unsigned bin_b(const FrameParams& P) { return blockId
 __device__ __forceinline__ int bin_w(const FrameParams& P) { return (int)(blockIdx.x / bin_B(P)); }
 #define SGS_RANGES_PER_SWEEP (SGS_BIN_THREADS / SGS_RANGE_CHUNKS)
 #define SGS_SWEEPS_PER_PASS (SGS_MAX_LIVE / SGS_BIN_THREADS)
+#ifndef SGS_RANGE_BLOCK
+#define SGS_RANGE_BLOCK 1            // consecutive ranges a workgroup takes at a time (experiment)
+#endif
+// the j-th range of workgroup b: blocks of SGS_RANGE_BLOCK consecutive ranges, dealt round-robin to the workgroups
+__device__ __forceinline__ long long bin_range(const FrameParams& P, int j) {
+    return ((long long)(j / SGS_RANGE_BLOCK) * bin_B(P) + bin_b(P)) * SGS_RANGE_BLOCK + (j % SGS_RANGE_BLOCK);
+}
 __device__ __forceinline__ int bin_sweeps(const FrameParams& P) {
-    const int mine = (P.n_ranges - (int)bin_b(P) + (int)bin_B(P) - 1) / (int)bin_B(P);   // ranges b, b+B, ...
+    const int n_blocks = (P.n_ranges + SGS_RANGE_BLOCK - 1) / SGS_RANGE_BLOCK;
+    const int mine = ((n_blocks - (int)bin_b(P) + (int)bin_B(P) - 1) / (int)bin_B(P)) * SGS_RANGE_BLOCK;
     return (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP;
 }
 __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const unsigned long long* __restrict__ vismask,
@@ -549,7 +557,7 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     unsigned vis = 0;
     for (int sw = sweep0; sw < sweep1; ++sw) {
         const int j = sw * SGS_RANGES_PER_SWEEP + (int)(threadIdx.x / SGS_RANGE_CHUNKS);     // j-th range of this workgroup
-        const long long r = (long long)bin_b(P) + (long long)j * bin_B(P);
+        const long long r = bin_range(P, j);
         const long long chunk = r * SGS_RANGE_CHUNKS + (threadIdx.x % SGS_RANGE_CHUNKS);
         if (r < P.n_ranges && chunk < P.n_chunks) {
             const unsigned long long vm = vismask[chunk];
