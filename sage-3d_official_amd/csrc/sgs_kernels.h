@@ -584,15 +584,31 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
 // stores at base + (its rank in the ballot), i.e. the wave writes one contiguous run per tile.
 // Only chunks whose lanes overlap heavily take this path (near-camera surfaces: 64 splats over the same
 // ~150 tiles); the others walk one rect per lane.
+#define SGS_WALK_TILES 8
+#define SGS_FLUSH_ROUNDS 8
 template <bool EMIT>
 __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __restrict__ binrec, const LiveChunks& lc,
                                          int wr0, int wr1, unsigned* s_arr, unsigned long long* __restrict__ rec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
+    // a wave's chunks are a chain of (list entry -> 16-B record load -> walk): the next chunk's records are requested
+    // before the current chunk is walked, so that their latency hides behind the walk
+    uint4 br_next = {0u, 0u, 0u, 0u};
+    bool live_next = false;
+    if ((unsigned)wave < nlive) {
+        live_next = (lc.mask[wave] >> lane) & 1ull;
+        if (live_next) br_next = binrec[lc.chunk[wave] * SGS_WAVE + (unsigned)lane];
+    }
     for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
         unsigned slot = 0, key = 0, x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
-        if ((lc.mask[k] >> lane) & 1ull) {
-            const uint4 br = binrec[lc.chunk[k] * SGS_WAVE + (unsigned)lane];
+        const uint4 br = br_next;
+        const bool live = live_next;
+        {
+            const unsigned kn = k + (unsigned)nwaves;
+            live_next = kn < nlive && ((lc.mask[min(kn, (unsigned)SGS_MAX_LIVE - 1u)] >> lane) & 1ull);
+            if (live_next) br_next = binrec[lc.chunk[kn] * SGS_WAVE + (unsigned)lane];
+        }
+        if (live) {
             slot = br.w;
             const int ya = max((int)(br.y >> 16), wr0), yb = min((int)(br.z >> 16), wr1);
             if (yb > ya) {
@@ -607,8 +623,9 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
         if (ux1 <= ux0 || uy1 <= uy0) continue;                              // nothing in this window
         const unsigned area = (ux1 - ux0) * (uy1 - uy0), total = wave_sum(cnt);
         if (area * 16u <= total) {
-            // tile-major pays ~30 cycles per union tile, lane-major ~(16 x multiplicity + 30) per four records:
-            // worth it only when the lanes overlap heavily (>= 16 records per tile of the union rect)
+            // tile-major pays ~300 cycles per union tile here (a ballot -> scalar -> one-lane-atomic chain at ~1 wave per
+            // SIMD; thresholds of 8, 4 and 2 records per tile were measured and lose): worth it only when the lanes overlap
+            // heavily (>= 16 records per tile of the union rect)
             for (unsigned ty = uy0; ty < uy1; ++ty) {
                 const bool row_on = on && ty >= y0 && ty < y1;
                 const unsigned row = ty * (unsigned)P.gx;
@@ -627,22 +644,27 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
                 }
             }
         } else if (on) {
-            // lane-major: every lane walks its own rect, four tiles per trip so the LDS atomics overlap
+            // lane-major: every lane walks its own rect, SGS_WALK_TILES tiles per trip.  These kernels run ~1 wave per
+            // SIMD, so what a trip costs is the LENGTH of its dependent chain, not its instruction count: every tile's
+            // (row, column) comes from its own index (i + 0.5) / w — exact in fp32 for rects of up to 256 tiles — instead
+            // of stepping a shared (tx, row) pair, and the LDS atomics of a trip are all in flight together
+            // (measured: ~560 cycles per 4-tile trip with the stepped version).
             const unsigned w = x1 - x0;
-            unsigned tx = 0, row = y0 * (unsigned)P.gx + x0;
-            for (unsigned i = 0; i < cnt; i += 4) {
-                unsigned tl[4], dst[4];
-                const unsigned nv = min(4u, cnt - i);
+            const float rw = 1.0f / (float)w;
+            const unsigned origin = y0 * (unsigned)P.gx + x0;
+            for (unsigned i = 0; i < cnt; i += SGS_WALK_TILES) {
+                unsigned tl[SGS_WALK_TILES], dst[SGS_WALK_TILES];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    tl[u] = row + tx;
-                    if (++tx == w) { tx = 0; row += (unsigned)P.gx; }
+                for (int u = 0; u < SGS_WALK_TILES; ++u) {
+                    const unsigned iu = i + (unsigned)u;
+                    const unsigned ty = (unsigned)(((float)iu + 0.5f) * rw);
+                    tl[u] = origin + ty * (unsigned)P.gx + (iu - ty * w);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
+                for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
                 if (EMIT) {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) if ((unsigned)u < nv) rec[dst[u]] = r;
+                    for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) rec[dst[u]] = r;
                 }
             }
         }
@@ -685,7 +707,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
                                                                unsigned* __restrict__ blk_len,
                                                                FrameStatus* __restrict__ st, unsigned long long* prof) {
 #ifdef SGS_TILE_PROF
-    unsigned long long bt0 = clock64(), bt_find = 0, bt_walk = 0, bt_flush = 0, btm = bt0;
+    unsigned long long bt0 = clock64(), bt_find = 0, bt_walk = 0, bt_flush = 0, bt_big = 0, btm = bt0;
 #define SGS_BPROF(acc) do { unsigned long long now_ = clock64(); acc += now_ - btm; btm = now_; } while (0)
 #else
 #define SGS_BPROF(acc) do { } while (0)
@@ -718,6 +740,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
                      [&](const unsigned* tl, unsigned, unsigned, unsigned) { atomicAdd(&s_cnt[tl[0]], 1u); });
         __syncthreads();
+        SGS_BPROF(bt_big);
         // flush: one device-scope atomic per touched tile — its return value is our base in the tile's sub-queue.
         // Every wave sweeps a 1/8 of the window's counters 64 at a time; the touched ones are compacted with a
         // ballot straight into the workgroup's (tile, base) list (no LDS list of touched tiles: LDS is what limits
@@ -725,25 +748,25 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         uint2* out = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
         {
             const int lane = tid & 63, wave = tid >> 6;
-            // waves interleave 128-tile slabs of the used counters; two rounds per trip: two atomics in flight per lane
-            for (int i0 = wave * 128; i0 < used; i0 += (SGS_BIN_THREADS / 64) * 128) {
-                unsigned tl[2], c[2], pre[2], base[2];
-                unsigned long long m[2];
+            // waves interleave slabs of SGS_FLUSH_ROUNDS x 64 counters; a trip's atomics (device scope, ~1 us each way)
+            // are all in flight together: at 1080p a wave makes 2 trips instead of 8 round trips in sequence
+            for (int i0 = wave * (SGS_FLUSH_ROUNDS * 64); i0 < used; i0 += (SGS_BIN_THREADS / 64) * (SGS_FLUSH_ROUNDS * 64)) {
+                unsigned tl[SGS_FLUSH_ROUNDS], c[SGS_FLUSH_ROUNDS], pre[SGS_FLUSH_ROUNDS], base[SGS_FLUSH_ROUNDS];
                 unsigned tot = 0;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < SGS_FLUSH_ROUNDS; ++u) {
                     tl[u] = (unsigned)(i0 + u * 64 + lane);
-                    c[u] = s_cnt[tl[u]];
-                    m[u] = __ballot(c[u] != 0u);
-                    pre[u] = tot + (unsigned)__popcll(m[u] & lanemask_lt(lane));
-                    tot += (unsigned)__popcll(m[u]);
+                    c[u] = tl[u] < (unsigned)used ? s_cnt[tl[u]] : 0u;
+                    const unsigned long long m = __ballot(c[u] != 0u);
+                    pre[u] = tot + (unsigned)__popcll(m & lanemask_lt(lane));
+                    tot += (unsigned)__popcll(m);
                 }
                 if (tot == 0u) continue;                                // (wave-uniform)
                 unsigned k0 = 0;
                 if (lane == 0) k0 = atomicAdd(&s_nlist, tot);
                 k0 = __shfl(k0, 0);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < SGS_FLUSH_ROUNDS; ++u) {
                     base[u] = 0;
                     if (c[u] != 0u) {
                         s_cnt[tl[u]] = 0;                             // ready for the next window
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < SGS_FLUSH_ROUNDS; ++u)
                     if (c[u] != 0u) out[k0 + pre[u]] = make_uint2(tl[u], base[u]);
             }
         }
@@ -768,7 +791,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 #ifdef SGS_TILE_PROF
     if (tid == 0 && prof && bin_w(P) == 0) {
         unsigned long long* o = prof + (size_t)b * 8;
-        o[0] = lc.n; o[1] = bt_find; o[2] = bt_walk; o[3] = bt_flush; o[4] = s_nlist; o[5] = n_vis; o[6] = clock64() - bt0; o[7] = bt0;
+        o[0] = lc.n; o[1] = bt_find; o[2] = bt_walk; o[3] = bt_flush; o[4] = s_nlist; o[5] = n_vis; o[6] = clock64() - bt0; o[7] = bt_big;
     }
 #endif
 }

@@ -19,6 +19,9 @@ for ci, rows in ((5, None), (70, None), (140, None), (20, (27, 36)), (140, (27, 
             r.render(cams[ci], gs, out_band=slab, tile_rows=rows, timing=True)
     st = r.last_stats
     p = r.debug_buffer(101, np.uint64).reshape(-1, 8).astype(np.float64)
-    nlive, find, walk, flush, nlist, nvis, tot, t0 = p.T
-    print(f"cam {ci} rows {rows}: count stage {st['ms']['count']*1e3:.0f} us N_v={st['n_visible']} D={st['d_total']} | per block mean: live chunks {nlive.mean():.0f} touched tiles {nlist.mean():.0f} vis {nvis.mean():.0f} | "
-          f"cycles find {find.mean():.0f} walk {walk.mean():.0f} (max {walk.max():.0f}) flush {flush.mean():.0f} (max {flush.max():.0f}) total {tot.mean():.0f} (max {tot.max():.0f}) | kernel span {(t0+tot).max()-t0.min():.0f} cyc, start spread {t0.max()-t0.min():.0f}")
+    nlive, find, walk, flush, nlist, nvis, tot, big = p.T
+    order = np.argsort(-tot)[:5]
+    print(f"cam {ci} rows {rows}: count stage {st['ms']['count']*1e3:.0f} us N_v={st['n_visible']} D={st['d_total']} | per workgroup mean (max): "
+          f"find {find.mean():.0f} ({find.max():.0f})  walk {walk.mean():.0f} ({walk.max():.0f})  big-rect walk {big.mean():.0f} ({big.max():.0f})  "
+          f"flush {flush.mean():.0f} ({flush.max():.0f})  total {tot.mean():.0f} ({tot.max():.0f}) cycles; touched tiles {nlist.mean():.0f}, live chunks {nlive.mean():.0f}")
+    print("   slowest five:", [(int(b), int(find[b]), int(walk[b]), int(big[b]), int(flush[b]), int(nlive[b]), int(nvis[b])) for b in order], "(wg, find, walk, big, flush, live chunks of the last pass, visible)")
