@@ -165,8 +165,11 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
                      const sgs_config* cfg, int tile_row_begin, int tile_row_end, float* out_rgb,
                      sgs_stats* stats, void* hip_stream);
 
-/* Completes frames issued with SGS_FLAG_ASYNC: synchronises the stream and reports the status and
- * statistics of the most recent frame. */
+/* Completes frames issued with SGS_FLAG_ASYNC: waits for the stream of the MOST RECENT frame and for every
+ * pipelined frame in flight, checks the status of every frame issued since the previous synchronisation and
+ * reports the statistics of the most recent one.  A caller that spreads asynchronous, non-pipelined frames over
+ * several streams of its own must synchronise the earlier streams itself (one stream per context is the
+ * intended use; pipelined frames are the library's way to overlap frames). */
 int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats);
 
 /* fp32 RGB -> uint8 RGBA (alpha 255), the shape cam.get_rgba() returns (simple_env.py:1380-1386;

@@ -225,6 +225,26 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     if (row_begin < 0) row_begin = 0;
     if (row_begin > row_end) SGS_FAIL(ctx, SGS_ERR_INVALID, "tile_row_begin %d > tile_row_end %d", row_begin, row_end);
     if (cfg && cfg->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d > 3", cfg->sh_degree);
+    if (cfg) {
+        // what the kernels lean on: depth keys are the bits of a POSITIVE float >= near_z (unsigned order, the composite's
+        // bucket index (key >> 18) - (bits(near_z) >> 18), 1 / tz), and the thresholds are compared as bit patterns
+        if (!(cfg->near_z > 0.f) || !(cfg->far_z > cfg->near_z)) SGS_FAIL(ctx, SGS_ERR_INVALID, "need 0 < near_z < far_z (got %g, %g)", cfg->near_z, cfg->far_z);
+        if (!(cfg->alpha_min > 0.f) || !(cfg->alpha_min < 1.f) || !(cfg->alpha_max >= cfg->alpha_min) || !(cfg->alpha_max < 1.f))
+            SGS_FAIL(ctx, SGS_ERR_INVALID, "need 0 < alpha_min <= alpha_max < 1 (got %g, %g)", cfg->alpha_min, cfg->alpha_max);
+        if (!(cfg->t_min > 0.f) || !(cfg->t_min < 1.f)) SGS_FAIL(ctx, SGS_ERR_INVALID, "need 0 < t_min < 1 (got %g)", cfg->t_min);
+        if (!(cfg->dilation >= 0.f) || !(cfg->clamp > 0.f)) SGS_FAIL(ctx, SGS_ERR_INVALID, "need dilation >= 0 and clamp > 0");
+    }
+    {   // the view must be rigid (sage_gs.h): k_preprocess's fp32 screen-bound exclusion prices a Gaussian's footprint with
+        // |J|_F^2 s_max^2, which a scaled or sheared view would break silently (a USD xformOp:scale != 1 has to be applied
+        // to the Gaussians' means and scales by the caller)
+        const float* V = cam->view;
+        for (int r = 0; r < 3; ++r)
+            for (int c = r; c < 3; ++c) {
+                const double d = (double)V[4 * r] * V[4 * c] + (double)V[4 * r + 1] * V[4 * c + 1] + (double)V[4 * r + 2] * V[4 * c + 2];
+                if (!(std::fabs(d - (r == c ? 1.0 : 0.0)) < 1.0e-3))
+                    SGS_FAIL(ctx, SGS_ERR_INVALID, "camera view is not rigid: rows %d.%d of its 3x3 give %g", r, c, d);
+            }
+    }
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
     if (gx > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "width %d exceeds %d tiles per row", cam->width, SGS_WT);
     const int win_tiles = (row_end - row_begin) * gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;
@@ -709,9 +729,17 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
         }
         SGS_HIP(ctx, hipStreamSynchronize(stream));
         if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;
+        // The redo below goes through sgs_render, which takes ring slots of its own (from next_slot, two or more per
+        // grow-and-retry) — i.e. slots of frames of THIS chunk that have not been looked at yet.  So every frame's
+        // verdict and statistics are taken out of the ring before anything is re-rendered.
+        bool over[kStatusRing];
         for (int i = 0; i < cn; ++i) {
+            over[i] = ctx->h_status[i].overflow != 0;
             if (stats) collect(ctx, i, stats + c0 + i, scene->n, tl[i], px[i], scene->sh_rows, false);
-            if (ctx->h_status[i].overflow) {
+        }
+        ctx->next_slot = 0; ctx->pending_begin = 0; ctx->pending_count = 0;
+        for (int i = 0; i < cn; ++i) {
+            if (over[i]) {
                 // redo this one frame synchronously (grows the queues), then carry on
                 int rb = tile_row_begin, re = tile_row_end;
                 float* out = out_rgb + (size_t)(c0 + i) * cams[c0 + i].width * cams[c0 + i].height * 3;

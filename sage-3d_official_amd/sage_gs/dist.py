@@ -173,11 +173,13 @@ class ShardedRenderer:
         self._turn = 0
         self.last_stats = None       # statistics of the last batch this rank rendered (per-frame averages)
 
-    def render(self, camera, scene, *, config=None, sync=False):
-        """One frame: every rank renders its band into its slab and joins the gather; rank dst gets the frame."""
+    def render(self, camera, scene, *, config=None):
+        """One frame: every rank renders its band into its slab and joins the gather; rank dst gets the frame.
+        The band is rendered synchronously: a frame that exceeds the record capacity is re-rendered after the queues
+        have grown (an asynchronous frame would render nothing and the stale slab would travel)."""
         r0, r1 = self.g.band
         if r1 > r0:
-            self.r.render(camera, scene, config=config, out_band=self.g.slab, sync=sync, **self.g.render_rows)
+            self.r.render(camera, scene, config=config, out_band=self.g.slab, sync=True, **self.g.render_rows)
         return self.g.gather()
 
     def render_batch(self, cameras, scene, *, config=None, timing=False):

@@ -144,6 +144,11 @@ class Renderer:
 
     def _scene_of(self, g):
         if isinstance(g, Scene):
+            if g._r is not self:
+                raise ValueError("this Scene was uploaded by another Renderer (another context, possibly another GPU); "
+                                 "upload the Gaussians with the renderer that draws them")
+            if g.handle is None:
+                raise ValueError("this Scene has been freed")
             return g
         cached = getattr(g, "_sgs_scene", None)
         if cached is None or cached._r is not self or cached.handle is None:
@@ -209,6 +214,10 @@ class Renderer:
         elif out_band is not None:
             if tile_rows is None:
                 raise ValueError("out_band needs tile_rows")
+            if r1 < 0 or r1 > camera.tile_rows:      # "to the end", as the C ABI reads it
+                r1 = camera.tile_rows
+            if not 0 <= r0 <= r1:
+                raise ValueError(f"tile_rows {tile_rows} is not a band of the frame's {camera.tile_rows} tile rows")
             y0, y1 = r0 * 16, min(r1 * 16, camera.height)
             if (out_band.device != self.device or out_band.dtype != torch.float32 or not out_band.is_contiguous()
                     or out_band.dim() != 3 or out_band.shape[0] < y1 - y0
@@ -337,6 +346,8 @@ def default_renderer(device=None) -> Renderer:
 def render(camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """The drop-in call surface named by BASELINE.json: one frame, float32 [H,W,3] on the scene's GPU."""
+    if isinstance(gaussians, Scene):             # an uploaded scene is drawn by the renderer (GPU) that holds it
+        return gaussians._r.render(camera, gaussians, config=config, out=out)
     dev = gaussians.means.device if isinstance(gaussians, Gaussians) else None
     if dev is not None and dev.type != "cuda":
         dev = None

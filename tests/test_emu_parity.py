@@ -153,6 +153,37 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
         assert (batch[i] == seq[i]).all() and stats[i].d_total > 0
 
 
+def test_batch_on_a_fresh_context_survives_overflowing_frames():
+    """sgs_render_batch on a context whose record capacity is too small for EVERY frame (round-1 advisor finding): the
+    redo of frame 0 took ring slots 0, 1, ... — the slots of the batch's later frames — and cleared their overflow
+    flags before they were looked at, so frame 1 came back unrendered with frame 0's statistics.  Every frame's verdict
+    is now read before anything is re-rendered."""
+    import ctypes as C
+    from sage_gs import _capi
+    d = emu_harness.EmuRenderer(record_capacity=1024)
+    try:
+        scene = pc.random_scene(1200, 9, 0, scale=(0.1, 0.5))
+        d.upload(*scene)
+        d.set_record_capacity(1024)
+        cams = []
+        for k in range(5):
+            V = np.eye(4, dtype=np.float32); V[0, 3] = 0.2 * k - 0.4
+            cams.append(onp.Camera(96, 96, 80.0, 80.0, 48.0, 48.0, V))
+        arr = (_capi.SgsCamera * len(cams))(*[_capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy,
+                                                                np.asarray(c.view, np.float32).reshape(4, 4).tolist()) for c in cams])
+        batch = np.full((len(cams), 96, 96, 3), -1.0, np.float32)
+        stats = (_capi.SgsStats * len(cams))()
+        cfg = d.lib.default_config()
+        d.lib.check(d.lib.sgs_render_batch(d.ctx, d.scene, arr, len(cams), C.byref(cfg), 0, -1, batch.ctypes.data, stats, None), d.ctx)
+        for i, c in enumerate(cams):
+            single, st = d.render(c)
+            assert st["d_total"] > 1024
+            assert (batch[i] == single).all(), f"frame {i} of the batch differs from the frame rendered alone"
+            assert stats[i].d_total == st["d_total"] and stats[i].n_visible == st["n_visible"]
+    finally:
+        d.close()
+
+
 @pytest.mark.parametrize("case", __import__("known_answer_cases").ALL, ids=lambda f: f.__name__)
 def test_kernels_against_closed_form_answers(drv, case):
     """The analytic cases that pin the oracle, run straight against the kernels (emulator) — no oracle involved."""
@@ -190,6 +221,14 @@ def test_argument_errors_are_reported_not_swallowed(drv):
     expect_invalid(call(cfg=bad), "tile_row_phase")
     bad.tile_row_phase = -1
     expect_invalid(call(cfg=bad), "tile_row_phase")
+    # what the kernels assume of the constants and of the view (round-1 advisor finding: near_z <= 0 breaks the depth-key order)
+    for field, value, word in (("near_z", 0.0, "near_z"), ("near_z", -1.0, "near_z"), ("far_z", 0.1, "near_z"),
+                               ("alpha_min", 0.0, "alpha_min"), ("alpha_min", float("nan"), "alpha_min"),
+                               ("alpha_max", 1.0, "alpha_min"), ("t_min", 0.0, "t_min"), ("t_min", float("inf"), "t_min")):
+        bad = lib.default_config(); setattr(bad, field, value)
+        expect_invalid(call(cfg=bad), word)
+    scaled = np.eye(4, dtype=np.float32); scaled[:3, :3] *= 2.0            # e.g. a USD xformOp:scale folded into the view
+    expect_invalid(call(cam=_capi.make_camera(32, 32, 30.0, 30.0, 16.0, 16.0, scaled.tolist())), "rigid")
     assert lib.sgs_set_record_capacity(ctx, 0) == -1
     assert lib.sgs_debug_read(ctx, 999, None, 0) == -1
     # an unknown backend is refused at creation, with a message that needs no context
