@@ -63,6 +63,9 @@ def _lib(real="f64"):
         lib.orc_frame_free.argtypes = [C.POINTER(OrcFrame)]
         lib.orc_frame_free.restype = None
         lib.orc_max_threads.restype = C.c_int
+        lib.orc_pixel_variants.restype = C.c_int64
+        lib.orc_pixel_variants.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcConfig), C.c_int, C.c_int, C.c_double,
+                                           C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _libs[real] = lib
     return _libs[real]
 
@@ -95,11 +98,46 @@ def make_config(near=0.2, far=1e30, dilation=0.3, clamp=1.3, alpha_min=1.0 / 255
     return cfg
 
 
+class Recheck:
+    """The oracle's two-sided answer for threshold-sensitive pixels (orc_pixel_variants): holds the C frame of one
+    oracle run alive.  recheck(ys, xs, got) -> (best_err[K], leaves[K], capped[K]): for each listed pixel the smallest
+    max-over-channels |variant - got| over every admissible set of alpha-cut / stop decisions inside the margin."""
+
+    def __init__(self, lib, fp, cfg, rel_margin, cap=12):
+        self._lib, self._fp, self._cfg, self.rel_margin, self.cap = lib, fp, cfg, float(rel_margin), int(cap)
+
+    def __call__(self, ys, xs, got):
+        got = np.ascontiguousarray(got, np.float32).reshape(-1, 3)
+        best = np.zeros(len(got)); leaves = np.zeros(len(got), np.int64); capped = np.zeros(len(got), bool)
+        e, c = C.c_double(), C.c_int()
+        for i, (y, x) in enumerate(zip(ys, xs)):
+            g = (C.c_float * 3)(*[float(v) for v in got[i]])
+            leaves[i] = self._lib.orc_pixel_variants(self._fp, C.byref(self._cfg), int(x), int(y), self.rel_margin,
+                                                     self.cap, g, C.byref(e), C.byref(c))
+            best[i], capped[i] = e.value, bool(c.value)
+        return best, leaves, capped
+
+    def close(self):
+        if self._fp is not None:
+            self._lib.orc_frame_free(self._fp)
+            self._fp = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+REL_MARGIN = 1.0e-4     # relative distance to a threshold below which a differently rounded evaluation may decide otherwise
+
+
 def render(means, scales, quats, opacities, sh, sh_degree, cam, cfg=None, tile_row_begin=0,
            tile_row_end=-1, threads=0, real="f64", want="all"):
     """Run the C oracle.  `cam` is an oracle_np.Camera-like object or an OrcCamera.
 
     Returns (image float32 [H,W,3], aux dict).  want="image" skips copying the intermediates.
+    aux["recheck"] (checker build only) evaluates threshold-sensitive pixels two-sidedly — see Recheck.
     """
     if not isinstance(cam, OrcCamera):
         cam = make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.view)
@@ -131,5 +169,8 @@ def render(means, scales, quats, opacities, sh, sh_degree, cam, cfg=None, tile_r
     aux["margin"] = _np(f.margin, (H, W), np.float32)
     aux["depth_image"] = _np(f.depth_img, (H, W), np.float32)
     aux["final_T"] = _np(f.final_T, (H, W), np.float32)
-    lib.orc_frame_free(fp)
+    if real == "f64":
+        aux["recheck"] = Recheck(lib, fp, cfg, REL_MARGIN)      # owns the frame from here on
+    else:
+        lib.orc_frame_free(fp)
     return img, aux

@@ -233,10 +233,11 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
     Returns dict(image[H,W,3], final_T[H,W], depth_image[H,W] (sum T alpha z),
     n_contrib[H,W] (index+1 of the last blended record),
     consumed[T] (records any pixel of the tile examined = the D_f term), margin[H,W]).
-    `margin` is the smallest relative distance |alpha/alpha_min - 1| of any examined (pixel,
-    Gaussian) pair to the alpha cut-off: fp32 and fp64 evaluations may legitimately decide
-    differently there, and the blend then jumps by up to alpha_min*T*c.  (The other discontinuity,
-    T(1-alpha) == t_min, moves a pixel by at most t_min*c = 1e-4*c and needs no special care.)
+    `margin` is the smallest relative distance of any examined (pixel, Gaussian) pair to one of S6's two
+    thresholds — |alpha/alpha_min - 1| (the cut-off: the blend jumps by alpha_min*T*c there) and, for pairs past the
+    cut-off, |T(1-alpha)/t_min - 1| (the stop: the pair's alpha*T*c is blended or not, up to ~1e-2*c when alpha is
+    near alpha_max).  fp32 and fp64 evaluations may legitimately decide differently inside that margin;
+    `pixel_variants` enumerates what each admissible decision gives.
     """
     cfg = cfg.f32()
     gx, gy = cam.grid
@@ -272,6 +273,7 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
                 mg = np.where(live, np.minimum(mg, np.abs(alpha / cfg.alpha_min - 1.0)), mg)
                 hit = live & (alpha >= cfg.alpha_min)
                 testT = T * (1.0 - alpha)
+                mg = np.where(hit, np.minimum(mg, np.abs(testT / cfg.t_min - 1.0)), mg)
                 stop = hit & (testT < cfg.t_min)
                 blend = hit & ~stop
                 C = np.where(blend[..., None], C + (alpha * T)[..., None] * rgb[g], C)
@@ -284,6 +286,52 @@ def composite(pre, offsets, ids, cam: Camera, cfg: Config, tile_row_begin=0, til
             img[sl] = C + T[..., None] * bg
             finT[sl] = T; ncon[sl] = nc; margin[sl] = mg; zimg[sl] = Z
     return dict(image=img, final_T=finT, n_contrib=ncon, consumed=consumed, margin=margin, depth_image=zimg)
+
+
+def pixel_variants(pre, offsets, ids, cam: Camera, cfg: Config, px: int, py: int, rel_margin=1.0e-4, cap=12):
+    """Two-sided evaluation of one pixel: every colour an evaluation may produce that decides the pairs lying within
+    `rel_margin` (relative) of the alpha cut-off or of the stop threshold either way (depth-first over the branch
+    points, at most `cap` on a path).  Returns float32 [L,3]; L == 1 when no decision of the pixel is that close.
+    The checker accepts a pixel iff it matches ONE of these within the parity tolerance."""
+    cfg = cfg.f32()
+    gx, _ = cam.grid
+    t = (py // TILE) * gx + px // TILE
+    q = ids[offsets[t]:offsets[t + 1]]
+    xy = pre["xy"].astype(np.float64); con = pre["conic"].astype(np.float64)
+    op = pre["opacity"].astype(np.float64); rgb = pre["rgb"].astype(np.float64)
+    bg = np.asarray(cfg.background, np.float64)
+    leaves = []
+
+    def walk(k, T, C, depth):
+        C = C.copy()
+        while k < len(q):
+            g = q[k]; k += 1
+            dx = xy[g, 0] - px; dy = xy[g, 1] - py
+            power = -0.5 * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) - con[g, 1] * dx * dy
+            if power > 0.0:
+                continue
+            alpha = min(cfg.alpha_max, op[g] * math.exp(power))
+            hit = alpha >= cfg.alpha_min
+            if abs(alpha / cfg.alpha_min - 1.0) < rel_margin and depth < cap:
+                depth += 1
+                walk(k, T, C, depth)                     # this pair skipped ...
+                hit = True                               # ... or taken
+            if not hit:
+                continue
+            testT = T * (1.0 - alpha)
+            stop = testT < cfg.t_min
+            if abs(testT / cfg.t_min - 1.0) < rel_margin and depth < cap:
+                depth += 1
+                leaves.append(C + T * bg)                # the pixel ends here ...
+                stop = False                             # ... or this pair is blended
+            if stop:
+                break
+            C = C + alpha * T * rgb[g]
+            T = testT
+        leaves.append(C + T * bg)
+
+    walk(0, 1.0, np.zeros(3), 0)
+    return np.asarray(leaves, np.float32).reshape(-1, 3)
 
 
 def render(means, scales, quats, opacities, sh, sh_degree, cam: Camera, cfg: Config = None,

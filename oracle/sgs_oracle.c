@@ -195,6 +195,9 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
 #endif
                 if (alpha < (real)cfg->alpha_min) continue;
                 real testT = T * (1 - alpha);
+#ifdef ORC_MARGIN
+                { double m2 = fabs((double)testT / (double)cfg->t_min - 1.0); if (m2 < mg) mg = m2; }
+#endif
                 if (testT < (real)cfg->t_min) { ++k; break; }
                 real wgt = alpha * T;
                 C[0] += wgt * (real)f->rgb[3 * g]; C[1] += wgt * (real)f->rgb[3 * g + 1]; C[2] += wgt * (real)f->rgb[3 * g + 2];
@@ -209,6 +212,75 @@ static void composite_tile(orc_frame* f, int tx, int ty, const orc_config* cfg) 
             f->final_T[p] = (float)T; f->n_contrib[p] = nc; f->margin[p] = (float)mg; f->depth_img[p] = (float)Z;
         }
     f->consumed[t] = used_max;
+}
+
+/* Two-sided evaluation of ONE pixel (the checker's answer to S6's two discontinuities).  A (pixel, Gaussian) pair whose
+ * alpha lies within rel_margin (relative) of alpha_min may legitimately be taken or skipped by a differently rounded
+ * evaluation, and a pair whose T(1-alpha) lies within rel_margin of t_min may legitimately end the pixel or be blended.
+ * This walks the pixel's queue and BRANCHES at every such decision (depth-first, at most `cap` branch points on a
+ * path; beyond that the nominal decision is taken and *capped is set), evaluates the colour of every leaf and returns
+ * in *best_err the smallest max-over-channels |leaf - got| — i.e. `got` is accepted iff it matches the result of
+ * SOME admissible set of decisions within the tolerance the caller applies.  Returns the number of leaves (1 = the
+ * pixel has no decision inside the margin).  The frame must still hold its per-Gaussian arrays and queues. */
+typedef struct { const orc_frame* f; const orc_config* cfg; const int32_t* q; int64_t n; int px, py; double rm; int cap;
+                 const float* got; double best; int64_t leaves; int capped; } orc_var;
+
+static void var_leaf(orc_var* v, real T, const real C[3]) {
+    double e = 0;
+    for (int c = 0; c < 3; ++c) {
+        double d = fabs((double)(float)(C[c] + T * (real)v->cfg->bg[c]) - (double)v->got[c]);
+        if (!(d <= e)) e = d;                                    /* NaN propagates as "no match" */
+    }
+    if (!(e >= v->best)) v->best = e;
+    v->leaves++;
+}
+
+static void var_walk(orc_var* v, int64_t k, real T, real C0, real C1, real C2, int depth) {
+    const orc_frame* f = v->f; const orc_config* cfg = v->cfg;
+    real C[3] = {C0, C1, C2};
+    for (; k < v->n; ++k) {
+        int32_t g = v->q[k];
+        real dx = (real)f->xy[2 * g] - (real)v->px, dy = (real)f->xy[2 * g + 1] - (real)v->py;
+        real power = (real)-0.5 * ((real)f->conic[3 * g] * dx * dx + (real)f->conic[3 * g + 2] * dy * dy)
+                     - (real)f->conic[3 * g + 1] * dx * dy;
+        if (power > 0) continue;
+        real alpha = (real)f->opacity[g] * (real)exp((double)power);
+        if (alpha > (real)cfg->alpha_max) alpha = (real)cfg->alpha_max;
+        int hit = alpha >= (real)cfg->alpha_min;
+        if (fabs((double)alpha / (double)cfg->alpha_min - 1.0) < v->rm) {
+            if (depth < v->cap) {
+                ++depth;
+                var_walk(v, k + 1, T, C[0], C[1], C[2], depth);  /* this pair skipped ... */
+                hit = 1;                                         /* ... or taken (continues below) */
+            } else v->capped = 1;
+        }
+        if (!hit) continue;
+        real testT = T * (1 - alpha);
+        int stop = testT < (real)cfg->t_min;
+        if (fabs((double)testT / (double)cfg->t_min - 1.0) < v->rm) {
+            if (depth < v->cap) {
+                ++depth;
+                var_leaf(v, T, C);                               /* the pixel ends here ... */
+                stop = 0;                                        /* ... or this pair is blended */
+            } else v->capped = 1;
+        }
+        if (stop) break;
+        real wgt = alpha * T;
+        C[0] += wgt * (real)f->rgb[3 * g]; C[1] += wgt * (real)f->rgb[3 * g + 1]; C[2] += wgt * (real)f->rgb[3 * g + 2];
+        T = testT;
+    }
+    var_leaf(v, T, C);
+}
+
+int64_t orc_pixel_variants(const orc_frame* f, const orc_config* cfg, int px, int py, double rel_margin, int cap,
+                           const float got[3], double* best_err, int* capped) {
+    if (px < 0 || py < 0 || px >= f->width || py >= f->height) return -1;
+    int t = (py / TILE) * f->gx + px / TILE;
+    orc_var v = {f, cfg, f->ids + f->offsets[t], f->offsets[t + 1] - f->offsets[t], px, py, rel_margin, cap, got, 1e300, 0, 0};
+    var_walk(&v, 0, 1, 0, 0, 0, 0);
+    if (best_err) *best_err = v.best;
+    if (capped) *capped = v.capped;
+    return v.leaves;
 }
 
 void orc_frame_free(orc_frame* f) {

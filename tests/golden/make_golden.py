@@ -61,16 +61,25 @@ def config1_fixture():
     cam = onp.Camera(128, 128, 64.0, 64.0, 64.0, 64.0, np.eye(4, dtype=np.float32))
     img, aux = onp.render(*scene, cam)
     pre = aux["pre"]
+    # two-sided answers for the threshold-sensitive pixels (margin < 1e-4): every colour an admissible evaluation gives
+    ys, xs = np.nonzero(aux["margin"] < 1.0e-4)
+    var, ptr = [], [0]
+    for y, x in zip(ys, xs):
+        v = onp.pixel_variants(pre, aux["offsets"], aux["ids"], cam, onp.Config(), int(x), int(y), 1.0e-4)
+        var.append(v); ptr.append(ptr[-1] + len(v))
     np.savez_compressed(os.path.join(HERE, "config1_golden.npz"),
                         n=2500, seed=0, width=128, height=128, f=64.0,
                         image=img.astype(np.float32), margin=aux["margin"].astype(np.float32),
+                        flag_yx=np.stack([ys, xs], 1).astype(np.int32), flag_ptr=np.asarray(ptr, np.int32),
+                        flag_rgb=(np.concatenate(var) if var else np.zeros((0, 3))).astype(np.float32),
                         offsets=aux["offsets"].astype(np.int32), ids=aux["ids"].astype(np.int32),
                         rect=pre["rect"].astype(np.int16), tiles=pre["tiles"].astype(np.int32),
                         depth_bits=pre["depth"].view(np.uint32), n_contrib=aux["n_contrib"].astype(np.int32),
                         n_visible=aux["n_visible"], D=aux["D"], D_f=aux["D_f"])
-    print("config1_golden.npz: D =", aux["D"], "D_f =", aux["D_f"])
+    print("config1_golden.npz: D =", aux["D"], "D_f =", aux["D_f"], "threshold-sensitive pixels:", len(ys), "variants:", ptr[-1])
 
 
 if __name__ == "__main__":
-    pose_fixture()
+    if "--frames-only" not in sys.argv:          # (the pose fixture imports the reference; the frame fixture does not)
+        pose_fixture()
     config1_fixture()

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 import oracle_c
 import oracle_np as onp
 import parity_cases as pc
-from conftest import assert_frame_close
+from conftest import assert_frame_close, stored_variants
 
 
 class GpuDriver:
@@ -238,7 +238,7 @@ def test_3m_scene_crop_vs_oracle(drv, big_scene):
     assert (img_ref == img).all()
     assert st_ref["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"] and st["d_total"] <= aux["D"]
     sl = slice(r0 * 16, r1 * 16)
-    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="3M scene band")
+    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], aux["recheck"], what="3M scene band", y0=sl.start)
 
 
 def test_4k_frame_multi_window_binning(drv):
@@ -271,7 +271,7 @@ def test_4k_frame_multi_window_binning(drv):
     ref, aux = oracle_c.render(*sc.as_tuple(), ocam, None, r0, r1, want="image")
     assert st_bref["d_total"] == aux["D"] and st_b["n_visible"] == aux["n_visible"]
     sl = slice(r0 * 16, r1 * 16)
-    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], cmax=2.0, what="4K band")
+    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], aux["recheck"], what="4K band", y0=sl.start)
 
 
 def test_culling_never_changes_a_pixel_stress(drv):
@@ -344,7 +344,7 @@ def test_against_committed_golden_fixture(drv):
     off, ids, _, _ = drv.intermediates()
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
-    assert_frame_close(img, g["image"], g["margin"], cmax=2.5, what="golden config1")
+    assert_frame_close(img, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1")
 
 
 def test_batch_equals_single_frames(drv):
@@ -414,7 +414,7 @@ def test_render_function_surface():
     assert isinstance(img, torch.Tensor) and img.shape == (256, 256, 3) and img.dtype == torch.float32 and img.is_cuda
     ocam = onp.Camera(256, 256, 128.0, 128.0, 128.0, 128.0, np.eye(4, dtype=np.float32))
     ref, aux = oracle_c.render(*sc.as_tuple(), ocam)
-    assert_frame_close(img.cpu().numpy(), ref, aux["margin"], cmax=2.5, what="render()")
+    assert_frame_close(img.cpu().numpy(), ref, aux["margin"], aux["recheck"], what="render()")
 
 
 # ---- "next" rows on the GPU ------------------------------------------------------------

@@ -244,3 +244,86 @@ def test_permutation_invariance_and_rigid_motion():
     moved, _ = oracle_c.render((means @ R.T + t).astype(np.float32), scales, q2.astype(np.float32), opac, sh, deg, cam2)
     assert np.abs(moved - base).max() < 2e-3          # fp32 re-rounding of means/quats/view moves a few pixels slightly
     assert np.abs(moved - base).mean() < 2e-5
+
+
+# ---- the two-sided evaluation of threshold-sensitive pixels (what conftest.assert_frame_close leans on) --------------
+def _variants(which, scene, cam, aux, x, y):
+    if which == "numpy":
+        return onp.pixel_variants(aux["pre"], aux["offsets"], aux["ids"], cam, onp.Config(), x, y, 1.0e-4).astype(np.float64)
+    # the C restatement reports the distance to the nearest variant; recover the variants by probing with each candidate
+    return aux["recheck"]
+
+
+@BOTH
+def test_two_sided_alpha_cutoff(which):
+    """One Gaussian whose alpha at the centre pixel sits 5e-5 (relative) above 1/255: a correctly rounded evaluation may
+    blend it or skip it there.  Both restatements must offer exactly those two colours — and nothing in between."""
+    from conftest import assert_frame_close
+    o = np.float32((1.0 + 5.0e-5) / 255.0)
+    sc = _scene([[0, 0, 4.0]], [[0.3] * 3], [o], [[4.0, 4.0, 4.0]])
+    cam = _cam()
+    img, aux = _render(which, sc, cam)
+    col = 0.5 + C0 * 4.0
+    assert aux["margin"][32, 32] < 1.0e-4 and np.allclose(img[32, 32], float(o) * col, atol=1e-7)
+    if which == "numpy":
+        v = _variants(which, sc, cam, aux, 32, 32)
+        assert v.shape == (2, 3) and np.allclose(np.sort(v[:, 0]), [0.0, float(o) * col], atol=1e-7)
+        recheck = lambda ys, xs, got: (np.array([np.abs(v - g).max(axis=1).min() for g in np.asarray(got, np.float64).reshape(-1, 3)]),
+                                       np.full(len(ys), len(v)), np.zeros(len(ys), bool))
+    else:
+        recheck = aux["recheck"]
+        for cand, ok in ((0.0, True), (float(o) * col, True), (0.5 * float(o) * col, False)):
+            best, leaves, capped = recheck([32], [32], np.full((1, 3), cand, np.float32))
+            assert leaves[0] == 2 and not capped[0] and (best[0] < 1e-6) == ok, (cand, best)
+        best, leaves, _ = recheck([40], [40], img[40:41, 40].astype(np.float32))
+        assert leaves[0] == 1 and best[0] < 1e-7               # an ordinary pixel: one leaf, the nominal colour
+    ref = np.asarray(img, np.float32)
+    for value, ok in ((0.0, True), (float(o) * col, True), (0.5 * float(o) * col, False)):
+        got = ref.copy(); got[32, 32] = value
+        if ok:
+            assert_frame_close(got, ref, aux["margin"], recheck, what=f"two-sided cut-off {value:.4f}")
+        else:                                                  # 0.5 * o * c = 7.8e-3 from either admissible colour
+            with pytest.raises(AssertionError, match="match NO admissible evaluation"):
+                assert_frame_close(got, ref, aux["margin"], recheck, what="two-sided cut-off (in between)")
+
+
+@BOTH
+def test_two_sided_stop_threshold(which):
+    """T(1-alpha) == t_min to rounding: the first splat leaves T = 0.01, the second (alpha clamped to 0.99) gives
+    T(1-alpha) = 1e-4 — the pixel may stop before it (S6: the stopping splat is not blended) or blend it (0.0099 c2,
+    ten times the parity tolerance) and go on to the third."""
+    sc = _scene([[0, 0, 2.0], [0, 0, 3.0], [0, 0, 4.0]], [[0.5] * 3] * 3, [0.999, 0.999, 0.5],
+                [[2.0, 0, 0], [0, 2.0, 0], [0, 0, 2.0]])
+    cam = _cam()
+    img, aux = _render(which, sc, cam)
+    c1 = np.maximum(0, 0.5 + C0 * np.array([2.0, 0, 0])); c2 = np.maximum(0, 0.5 + C0 * np.array([0, 2.0, 0]))
+    c3 = np.maximum(0, 0.5 + C0 * np.array([0, 0, 2.0]))
+    stop = 0.99 * c1
+    T2 = 0.01 * (1 - 0.99)
+    go_on = 0.99 * c1 + 0.99 * 0.01 * c2 + 0.5 * T2 * c3          # third: alpha 0.5, T2 (1 - 0.5) = 5e-7 < t_min -> stops unblended
+    go_on_stop3 = 0.99 * c1 + 0.99 * 0.01 * c2
+    assert aux["margin"][32, 32] < 1.0e-4
+    if which == "numpy":
+        v = _variants(which, sc, cam, aux, 32, 32)
+        assert len(v) == 2
+        assert min(np.abs(v - stop).max(axis=1)) < 1e-6 and min(np.abs(v - go_on_stop3).max(axis=1)) < 1e-6
+    else:
+        for cand, ok in ((stop, True), (go_on_stop3, True), (go_on, True), (0.5 * (stop + go_on_stop3), False)):
+            best, leaves, _ = aux["recheck"]([32], [32], np.asarray(cand, np.float32).reshape(1, 3))
+            assert leaves[0] == 2 and (best[0] < 1e-3) == ok, (cand, best)
+
+
+def test_two_sided_variants_agree_between_restatements():
+    """On config 1 every threshold-sensitive pixel has the same variants in both restatements."""
+    scene, cam = onp.config1_scene(n=2500, seed=0)
+    cam = onp.Camera(128, 128, 64.0, 64.0, 64.0, 64.0, np.eye(4, dtype=np.float32))
+    _, a = onp.render(*scene, cam)
+    _, c = oracle_c.render(*scene, cam)
+    ys, xs = np.nonzero(a["margin"] < 1.0e-4)
+    assert len(ys) >= 1 and ((c["margin"] < 1.0e-4) == (a["margin"] < 1.0e-4)).all()
+    for y, x in zip(ys, xs):
+        v = onp.pixel_variants(a["pre"], a["offsets"], a["ids"], cam, onp.Config(), int(x), int(y), 1.0e-4)
+        assert len(v) >= 2
+        for leaf in v:
+            best, leaves, capped = c["recheck"]([y], [x], leaf.reshape(1, 3))
+            assert leaves[0] == len(v) and best[0] < 2e-6 and not capped[0]
