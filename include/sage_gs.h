@@ -52,6 +52,9 @@ enum {
                                     * the axis-aligned extent only (production: exact ellipse/rectangle test).  D, tile
                                     * offsets and queues then are exactly the reference's; frames must be bit-identical
                                     * either way */
+    SGS_FLAG_NO_CHUNK_CULL = 1u << 6, /* tests: project every chunk of the scene (the production path first tests each
+                                    * 64-Gaussian chunk's bounding sphere against the frame / the band of tile rows and skips
+                                    * the chunks that cannot reach it).  N_v, D, queues and frames must not change */
     SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
                                     * the library's internal streams (a few frames in flight, each with its own
                                     * intermediates: one frame's binning fills the compute units another frame's
@@ -172,6 +175,12 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
  * intended use; pipelined frames are the library's way to overlap frames). */
 int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats);
 
+/* Records queued per FRAME tile row (out[r], r < n_rows <= 4096), summed over every frame rendered since the last call with
+ * reset != 0 — each frame adds the rows it rendered (its band).  This is the per-row cost from which cost-balanced
+ * tile-row bands are cut (SURVEY.md §8e "optional cost-balanced ranges from the previous frame's per-row D"); the
+ * reference has no counterpart (it shards by scene only, generate_images.py:136-139).  Synchronises the device. */
+int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset);
+
 /* fp32 RGB -> uint8 RGBA (alpha 255), the shape cam.get_rgba() returns (simple_env.py:1380-1386;
  * generate_images.py:428-431).  Both buffers are device buffers. */
 int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int height,
@@ -183,6 +192,7 @@ enum {
     SGS_BUF_TILE_OFFSETS = 0,      /* uint32[T+1]                                                */
     SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues in (depth, index) order — complete only with SGS_FLAG_FULL_SORT */
     SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    slot i holds Gaussian i: i if live this frame, 0xFFFFFFFF if culled; S = ceil(N/64)*64 */
+    SGS_BUF_CHUNK_SKIPPED = 4,     /* uint8[ceil(N/64)]  1 = the 64-Gaussian chunk (in layout order) was skipped by its bounds */
     SGS_BUF_SPLATS       = 3       /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
 };
 int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);

@@ -38,6 +38,7 @@ struct sgs_scene {
     int sh_degree = 0, sh_rows = 0;
     float4* geom = nullptr;
     float4* shq = nullptr;
+    float4* cbound = nullptr;           // per chunk: bounding sphere of the means + largest scale (k_chunk_bounds)
     unsigned* perm_host = nullptr;      // Z-order: layout position -> original index (nullptr = identity)
 };
 
@@ -87,7 +88,11 @@ struct sgs_ctx {
     int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
                                              // 64-KB window: binning alone 380 -> 305 us at 3840x2160, but such workgroups overlap worse
                                              // with the other frames in flight (sweep 1717 -> 1657 frames/s), so it is opt-in
-    bool morton = false;                     // Z-order the scene at upload (SGS_MORTON=1): for scenes stored in no spatial order
+    bool morton = true;                      // Z-order the scene at upload (SGS_MORTON=0 keeps the caller's order): a chunk of 64
+                                             // Gaussians is then a compact patch, which is what makes the per-chunk bounds
+                                             // (k_chunk_bounds / chunk_outside) worth testing — trained scenes come in no spatial order
+    unsigned long long* row_acc = nullptr;   // records queued per frame tile row, summed over the frames since the last
+                                             // sgs_row_records(reset) — what cost-balanced tile-row bands are cut from
     const sgs_scene* last_scene = nullptr;
     int64_t rec_cap_wanted = 16ll << 20;
     // status ring
@@ -247,6 +252,7 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     }
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
     if (gx > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "width %d exceeds %d tiles per row", cam->width, SGS_WT);
+    if (gy_frame > SGS_MAX_ROWS) SGS_FAIL(ctx, SGS_ERR_INVALID, "height %d exceeds %d tile rows", cam->height, SGS_MAX_ROWS);
     const int win_tiles = (row_end - row_begin) * gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;
     const int win_rows = std::max(1, win_tiles / gx);
     if ((row_end - row_begin + win_rows - 1) / win_rows > SGS_MAX_WINDOWS)
@@ -339,7 +345,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     const unsigned bin_blocks = (unsigned)std::min<int64_t>(ctx->bin_grid, P.n_ranges);
     if (P.n_chunks > 0)
         hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
-                           scene->geom, scene->shq, L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, st);
+                           scene->geom, scene->shq, L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, scene->cbound, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
@@ -349,7 +355,7 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
     const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
-                       L.tile_offset, L.tile_order, st);
+                       L.tile_offset, L.tile_order, ctx->row_acc, st);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
@@ -464,6 +470,8 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->d_status), sizeof(FrameStatus) * kStatusRing)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->row_acc), sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMalloc", e);
+    if ((e = hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMemset", e);
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
     if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
@@ -489,6 +497,7 @@ int sgs_destroy(sgs_ctx* ctx) {
         if (L.done) (void)hipEventDestroy(L.done);
     }
     if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->row_acc) (void)hipFree(ctx->row_acc);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     if (ctx->ev) {
         for (int i = 0; i < kStatusRing; ++i)
@@ -532,7 +541,8 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
     auto bail = [&](int code) { sgs_scene_free(ctx, sc); return code; };
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&sc->geom), npad * SGS_GEOM_ROWS * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&sc->shq), npad * sc->sh_rows * sizeof(float4))) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&sc->shq), npad * sc->sh_rows * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&sc->cbound), (npad / 64) * 2 * sizeof(float4))) != hipSuccess) {
         ctx->err = std::string("sgs_scene_upload: hipMalloc: ") + hipGetErrorString(e);
         return bail(e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP);
     }
@@ -604,8 +614,10 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
             const unsigned grid = (unsigned)((npad + 255) / 256);
             hipLaunchKernelGGL(sgs::k_scene_layout, dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows, d_perm,
                                dev[0], dev[1], dev[2], dev[3], dev[4], sc->geom, sc->shq);
+            hipLaunchKernelGGL(sgs::k_chunk_bounds, dim3((unsigned)((sc->n_chunks + 3) / 4)), dim3(256), 0, 0, (long long)n,
+                               (long long)sc->n_chunks, sc->geom, sc->cbound);
             if ((e = hipDeviceSynchronize()) != hipSuccess) {
-                ctx->err = std::string("sgs_scene_upload: k_scene_layout: ") + hipGetErrorString(e);
+                ctx->err = std::string("sgs_scene_upload: k_scene_layout / k_chunk_bounds: ") + hipGetErrorString(e);
                 rc = SGS_ERR_HIP;
             }
         }
@@ -622,6 +634,7 @@ int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene) {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); }
     if (scene->geom) (void)hipFree(scene->geom);
     if (scene->shq) (void)hipFree(scene->shq);
+    if (scene->cbound) (void)hipFree(scene->cbound);
     if (scene->perm_host) free(scene->perm_host);
     if (ctx && ctx->last_scene == scene) ctx->last_scene = nullptr;
     delete scene;
@@ -753,6 +766,17 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
     return SGS_OK;
 }
 
+int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (n_rows < 0 || n_rows > SGS_MAX_ROWS || (n_rows > 0 && !out)) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad row buffer (%d rows)", n_rows);
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    SGS_HIP(ctx, hipDeviceSynchronize());
+    static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters");
+    if (n_rows > 0) SGS_HIP(ctx, hipMemcpy(out, ctx->row_acc, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
+    if (reset) SGS_HIP(ctx, hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS));
+    return SGS_OK;
+}
+
 int sgs_pack_rgba8(sgs_ctx* ctx, const float* rgb, uint8_t* rgba, int width, int height, void* hip_stream) {
     if (!ctx) return SGS_ERR_INVALID;
     if (!rgb || !rgba || width <= 0 || height <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad pack arguments");
@@ -780,6 +804,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_SORTED_SLOTS: src = L.sorted_out; have = (s.overflow || !L.sorted_out) ? 0 : (int64_t)s.d_total * 4; break;
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: src = L.splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
+        case SGS_BUF_CHUNK_SKIPPED: have = n_chunks; break;
         case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
@@ -798,6 +823,13 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         for (int64_t i = 0; (i + 1) * 4 <= n; ++i)
             ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i * SGS_XCDS];
         free(tmp);
+    }
+    if (what == SGS_BUF_CHUNK_SKIPPED) {
+        std::vector<unsigned long long> vm((size_t)std::max<int64_t>(1, n_chunks)), bm(vm.size());
+        hipError_t e = hipMemcpy(vm.data(), L.vismask, (size_t)n_chunks * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(bm.data(), L.bigmask, (size_t)n_chunks * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+        for (int64_t i = 0; i < n; ++i) ((unsigned char*)host_dst)[i] = vm[(size_t)i] == 0ull && bm[(size_t)i] == ~0ull;
     }
     if (elem) {
         // a splat lives at its Gaussian's index; the per-chunk visibility masks say which are live.

@@ -125,6 +125,81 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
     }
 }
 
+// Upload: a bounding sphere of the means of every 64-Gaussian chunk plus the chunk's largest scale, two float4 per chunk:
+// (cx, cy, cz, R) (s_max, 0, 0, 0).  k_preprocess tests it against the frame's band of pixel rows before it loads
+// anything else of the chunk (chunk_outside below): with the scene in Z-order a chunk is a patch of a few decimetres, so
+// a rank that owns a band of tile rows touches only the chunks that can reach it, and a single GPU skips what lies
+// behind the camera or outside the image.  One wave per chunk; runs once per scene.
+__global__ __launch_bounds__(256) void k_chunk_bounds(long long n, long long n_chunks, const float4* __restrict__ geom,
+                                                      float4* __restrict__ cbound) {
+    const int lane = threadIdx.x & 63;
+    const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (chunk >= n_chunks) return;
+    const long long pos = chunk * SGS_WAVE + lane;
+    const bool real = pos < n;                                   // the last chunk is padded
+    const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
+    const float4 g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
+    float lo[3] = {real ? g0.x : 3.0e38f, real ? g0.y : 3.0e38f, real ? g0.z : 3.0e38f};
+    float hi[3] = {real ? g0.x : -3.0e38f, real ? g0.y : -3.0e38f, real ? g0.z : -3.0e38f};
+    float sm = real ? fmaxf(g1.x, fmaxf(g1.y, g1.z)) : 0.f;
+    bool bad = real && !(g0.x == g0.x && g0.y == g0.y && g0.z == g0.z && sm == sm);       // NaN anywhere: never cull this chunk
+    for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], d)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], d)); }
+        sm = fmaxf(sm, __shfl_xor(sm, d));
+    }
+    const float cx = 0.5f * (lo[0] + hi[0]), cy = 0.5f * (lo[1] + hi[1]), cz = 0.5f * (lo[2] + hi[2]);
+    const float dx = g0.x - cx, dy = g0.y - cy, dz = g0.z - cz;
+    float r = real ? sqrtf(dx * dx + dy * dy + dz * dz) : 0.f;
+    for (int d = 32; d >= 1; d >>= 1) r = fmaxf(r, __shfl_xor(r, d));
+    r = r * 1.0001f + 1.0e-6f * (fabsf(cx) + fabsf(cy) + fabsf(cz)) + 1.0e-30f;          // padded for its own rounding
+    if (__ballot(bad) != 0ull || !(r < 3.0e37f) || !(sm < 3.0e37f)) r = __uint_as_float(0x7f800000u);   // +inf: keep always
+    if (lane == 0) {
+        cbound[2 * chunk] = make_float4(cx, cy, cz, r);
+        cbound[2 * chunk + 1] = make_float4(sm, 0.f, 0.f, 0.f);
+    }
+}
+
+// Can ANY Gaussian of a chunk (means inside the sphere (c, R), scales <= s_max) be visible in this frame / band?
+// Wave-uniform, fp64, conservative with respect to the per-Gaussian exclusion in preprocess_chunk: that one keeps a
+// Gaussian only if  tz > near,  px + rb + ex >= 1,  px - rb - ex < 16 gx,  py + rb + ey >= cull_y0 + 1,  py - rb - ey < cull_y1
+// with  px = fx tx / tz + cx - 0.5,  rb = (3 sqrt(2 lmax + 0.3163) + 1) 1.001 + 0.5,  lmax = (fmax / tz)^2 k smax^2 + dilation,
+// k = 2 + lx^2 + ly^2.  sqrt(a + b) <= sqrt(a) + sqrt(b) gives  rb <= A smax / tz + c0  with A = 1.001 * 3 sqrt(2 k) fmax and
+// c0 = 1.001 (3 sqrt(2 dilation + 0.3163) + 1) + 0.5, so each condition, multiplied by tz > 0, is implied false for the whole
+// sphere when a LINEAR form  n . t + A s_max  is negative at the sphere's most favourable point  n . c + |n| R  (t = view-space
+// position).  The comparison carries a relative slack of 1e-4 of the magnitudes involved (ex, ey <= 1e-5 |p| + 0.01 and the
+// rounding of the evaluation itself) and one extra pixel.  A non-finite radius (NaN means, see k_chunk_bounds) keeps the chunk.
+__device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4 b0, const float4 b1) {
+    const double R = (double)b0.w, sm = (double)b1.x;
+    if (!(R < 1.0e37)) return false;
+    const double mx = b0.x, my = b0.y, mz = b0.z;
+    const double tx = (double)P.view[0] * mx + (double)P.view[1] * my + (double)P.view[2] * mz + (double)P.view[3];
+    const double ty = (double)P.view[4] * mx + (double)P.view[5] * my + (double)P.view[6] * mz + (double)P.view[7];
+    const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
+    const double Rp = R * 1.0001 + 1.0e-6 * (fabs(tx) + fabs(ty) + fabs(tz));      // the view transform of the centre rounds too
+    if (tz + Rp < (double)P.near_z || tz - Rp > (double)P.far_z) return true;
+    const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
+    const double fmx = fmax((double)P.fx, (double)P.fy);
+    const double A = 1.001 * 3.0 * sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * fmx * 1.0001;
+    const double c0 = 1.001 * (3.0 * sqrt(2.0 * (double)P.dilation + 0.3163) + 1.0) + 0.5 + 1.0;      // + one pixel of slack
+    const double d = A * sm;
+    // form(u, f, off) = f u + off tz + d, maximised over the sphere; negative => the condition fails for every member
+    const double zmag = fabs(tz) + Rp;
+#define SGS_PLANE_NEG(U, F, OFF)                                                                         \
+    (((F) * (U) + (OFF) * tz + sqrt((F) * (F) + (OFF) * (OFF)) * Rp + d) <                               \
+     -1.0e-4 * (fabs((F) * (U)) + fabs(OFF) * zmag + sqrt((F) * (F) + (OFF) * (OFF)) * Rp + d))
+    const double ox0 = (double)P.cx - 0.5 + c0;                                     // px + rb >= 0     (weaker than >= 1)
+    const double ox1 = (double)(SGS_TILE_PX * P.gx) - (double)P.cx + 0.5 + c0;      // px - rb <  16 gx
+    const double oy0 = (double)P.cy - 0.5 - (double)P.cull_y0 + c0;                 // py + rb >= cull_y0
+    const double oy1 = (double)P.cull_y1 - (double)P.cy + 0.5 + c0;                 // py - rb <  cull_y1
+    if (SGS_PLANE_NEG(tx, (double)P.fx, ox0)) return true;
+    if (SGS_PLANE_NEG(tx, -(double)P.fx, ox1)) return true;
+    if (SGS_PLANE_NEG(ty, (double)P.fy, oy0)) return true;
+    if (SGS_PLANE_NEG(ty, -(double)P.fy, oy1)) return true;
+#undef SGS_PLANE_NEG
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------
 // S1: SH colour.  `row0` points at this lane's float4 in row 0 of its chunk; rows are 64 float4 apart.
 template <int DEG>
@@ -372,10 +447,16 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
                                                     unsigned long long* __restrict__ bigmask,
                                                     unsigned* __restrict__ big_list,
                                                     uint4* __restrict__ binrec,
+                                                    const float4* __restrict__ cbound,
                                                     FrameStatus* __restrict__ st) {
     const int lane = threadIdx.x & 63;
     const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (chunk >= P.n_chunks) return;                       // wave-uniform
+    // chunks that cannot reach this frame / this rank's band of tile rows cost 32 bytes, not a sweep of their rows
+    if (!(P.flags & 64u) && chunk_outside(P, cbound[2 * chunk], cbound[2 * chunk + 1])) {
+        if (lane == 0) { vismask[chunk] = 0ull; bigmask[chunk] = ~0ull; }   // (bigmask is only read under a non-zero
+        return;                                                             //  vismask: all-ones marks "skipped" for tests)
+    }
     preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, chunk, lane);
 }
 
@@ -417,8 +498,10 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
                                                                 const unsigned* __restrict__ tile_count,
                                                                 unsigned* __restrict__ tile_offset,
                                                                 uint4* __restrict__ tile_order,
+                                                                unsigned long long* __restrict__ row_acc,
                                                                 FrameStatus* __restrict__ st) {
     constexpr int NW = SGS_SCAN_THREADS / SGS_WAVE;
+    __shared__ unsigned s_row[SGS_SCAN_THREADS + 2];  // records per tile row among my 1024 tiles (-> row_acc, see the end)
     __shared__ unsigned s_all[33], s_before[33];      // tiles per log2(queue length) class: whole band / before my tiles
     __shared__ unsigned s_cur[33];                    // my tiles' cursors: first render position of each class for them
     __shared__ unsigned s_wa[NW], s_wb[NW], s_wm[NW], s_wi[NW];
@@ -426,6 +509,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
     const int t_lo = P.row_begin * P.gx, t_hi = P.row_end * P.gx;      // the tiles this call renders: rects are clipped
     const int g = (int)blockIdx.x;                                     // to them in k_preprocess (a rank scans 1/N)
     if (tid < 33) { s_all[tid] = 0; s_before[tid] = 0; }
+    for (int i = tid; i < SGS_SCAN_THREADS + 2; i += SGS_SCAN_THREADS) s_row[i] = 0;
     __syncthreads();
     unsigned sum_all = 0, sum_before = 0, mx = 0;
     uint4 m0 = {0u, 0u, 0u, 0u}, m1 = m0;            // my tile's eight sub-counts
@@ -496,6 +580,21 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParam
         const unsigned pos = class_take(s_cur, queue_class(c), t < t_hi, lane);
         // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
         if (t < t_hi) tile_order[pos] = uint4{(unsigned)t, base + wbase + incl - c, c, 0u};
+    }
+    {   // records per FRAME tile row, accumulated over frames (sgs_row_records: what cost-balanced bands are cut from)
+        const int first_y = (t_lo + g * SGS_SCAN_THREADS) / P.gx;
+        const int my_y = t < t_hi ? t / P.gx - first_y : -1;
+        if (P.gx >= SGS_WAVE) {                      // a wave's 64 consecutive tiles lie in two rows at most
+            const int ya = (t_lo + g * SGS_SCAN_THREADS + wave * SGS_WAVE) / P.gx - first_y;
+            const unsigned sa = wave_sum(my_y == ya ? c : 0u), sb = wave_sum(my_y == ya + 1 ? c : 0u);
+            if (lane == 0) { if (sa) atomicAdd(&s_row[ya], sa); if (sb) atomicAdd(&s_row[ya + 1], sb); }
+        } else if (my_y >= 0 && c) atomicAdd(&s_row[my_y], c);
+        __syncthreads();
+        for (int i = tid; i < SGS_SCAN_THREADS + 2; i += SGS_SCAN_THREADS) {
+            const unsigned v = s_row[i];
+            const int fr = (first_y + i) * P.row_stride + P.row_phase;
+            if (v && fr < SGS_MAX_ROWS) atomicAdd(&row_acc[fr], (unsigned long long)v);
+        }
     }
     if (g == 0 && tid == 0) {
         tile_offset[(size_t)t_hi * SGS_XCDS] = total;      // end of the band's last queue (k_bin_emit never reads past it)

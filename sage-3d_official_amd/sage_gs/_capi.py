@@ -12,9 +12,9 @@ import os
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
-FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL = 1, 2, 4, 8, 16, 32
+FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL, FLAG_NO_CHUNK_CULL = 1, 2, 4, 8, 16, 32, 64
 BACKEND_CPU, BACKEND_HIP = 0, 1
-BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS = 0, 1, 2, 3
+BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED = 0, 1, 2, 3, 4
 
 ERR_NAMES = {-1: "SGS_ERR_INVALID", -2: "SGS_ERR_HIP", -3: "SGS_ERR_OOM", -4: "SGS_ERR_OVERFLOW",
              -5: "SGS_ERR_BACKEND"}
@@ -25,7 +25,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 # every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
 EXPORTS = ("sgs_version", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
            "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_free", "sgs_render",
-           "sgs_render_rgbd", "sgs_render_batch", "sgs_frame_sync", "sgs_pack_rgba8", "sgs_debug_read")
+           "sgs_render_rgbd", "sgs_render_batch", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
 
 
 class SgsError(RuntimeError):
@@ -92,6 +92,7 @@ class Lib:
         lib.sgs_render_batch.argtypes = [vp, vp, C.POINTER(SgsCamera), i32, C.POINTER(SgsConfig), i32,
                                          i32, vp, C.POINTER(SgsStats), vp]
         lib.sgs_frame_sync.argtypes = [vp, C.POINTER(SgsStats)]
+        lib.sgs_row_records.argtypes = [vp, vp, i32, i32]
         lib.sgs_pack_rgba8.argtypes = [vp, vp, vp, i32, i32, vp]
         lib.sgs_debug_read.argtypes = [vp, i32, vp, i64]; lib.sgs_debug_read.restype = i64
 

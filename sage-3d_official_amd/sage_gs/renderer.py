@@ -184,7 +184,7 @@ class Renderer:
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
-               return_aux=False, pipelined=False, loose_cull=False, interleave=None):
+               return_aux=False, pipelined=False, loose_cull=False, interleave=None, chunk_cull=True):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
@@ -235,6 +235,7 @@ class Renderer:
         flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
                 (_capi.FLAG_FULL_SORT if full_sort else 0) | \
                 (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
+                (0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
@@ -259,6 +260,13 @@ class Renderer:
         self._lib.check(self._lib.sgs_frame_sync(self._ctx, C.byref(st)), self._ctx)
         self.last_stats = st.as_dict()
         return self.last_stats
+
+    def row_records(self, n_rows: int, reset: bool = True) -> np.ndarray:
+        """Records queued per frame tile row, summed over the frames rendered since the last reset (int64 [n_rows]):
+        the per-row cost that cost-balanced tile-row bands are cut from (sage_gs.dist).  Synchronises the device."""
+        out = np.zeros(int(n_rows), np.int64)
+        self._lib.check(self._lib.sgs_row_records(self._ctx, out.ctypes.data, int(n_rows), 1 if reset else 0), self._ctx)
+        return out
 
     def render_batch(self, cameras: Sequence[Camera], gaussians, *, config: Optional[RenderConfig] = None,
                      out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False):

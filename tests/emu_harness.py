@@ -67,7 +67,9 @@ class EmuRenderer:
         self.scene = sc
         self.n = arrs[0].shape[0]
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
+               chunk_cull=True):
+        flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
         flags |= _capi.FLAG_LOOSE_CULL if loose_cull else 0
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
@@ -104,6 +106,14 @@ class EmuRenderer:
 
     def set_record_capacity(self, n):
         self.lib.check(self.lib.sgs_set_record_capacity(self.ctx, int(n)), self.ctx)
+
+    def chunk_skipped(self):
+        return self.debug(_capi.BUF_CHUNK_SKIPPED, np.uint8)
+
+    def row_records(self, n_rows, reset=True):
+        out = np.zeros(int(n_rows), np.int64)
+        self.lib.check(self.lib.sgs_row_records(self.ctx, out.ctypes.data, int(n_rows), 1 if reset else 0), self.ctx)
+        return out
 
     def debug(self, what, dtype, count_hint=None):
         have = self.lib.sgs_debug_read(self.ctx, what, None, 0)

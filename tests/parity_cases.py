@@ -45,6 +45,16 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     drv.upload(*scene)
     # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them
     img, st = drv.render(cam, cfg, rows)
+    # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
+    # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
+    drv.row_records(0, reset=True)
+    img_all, st_all = drv.render(cam, cfg, rows, chunk_cull=False)
+    assert (img_all == img).all() and st_all["n_visible"] == st["n_visible"] and st_all["d_total"] == st["d_total"] \
+        and st_all["d_fetched"] == st["d_fetched"], f"{what}: chunk culling changed the frame"
+    # the per-row record counters (what cost-balanced bands are cut from) add up to D
+    gy_ = (cam.height + 15) // 16
+    rr = drv.row_records(gy_, reset=True)
+    assert int(rr.sum()) == st_all["d_total"] and (rr[:rows[0]] == 0).all() and (rows[1] < 0 or (rr[rows[1]:] == 0).all())
     # test hook: order every queue completely (production binning)
     img_full, st_full = drv.render(cam, cfg, rows, full_sort=True)
     assert (img_full == img).all(), f"{what}: lazy and full sort must blend the same records in the same order"
@@ -168,6 +178,37 @@ def case_interleaved_rows(drv, stride, n=2500, res=(208, 150)):
             assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
     assert seen.all() and pix == w * h
     assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
+
+
+def case_chunk_bounds(drv, n=6000, res=(208, 150)):
+    """Per-chunk bounds (k_chunk_bounds / chunk_outside): a scene much wider than the view, so most 64-Gaussian chunks
+    (Z-ordered at upload) lie outside the image or behind the camera.  The skipped chunks must hold no visible Gaussian
+    — N_v, D, queues and frames equal the oracle's and the no-culling run's, for the full frame and for bands of tile
+    rows (where chunks above and below the band are skipped too) — and a good share of the chunks must actually be
+    skipped, or the test would prove nothing."""
+    # a wall 24 m x 12 m facing the camera at ~6 m (the view covers a tenth of it) and a cloud behind the camera
+    means, scales, quats, opac, sh, deg = random_scene(n, 17, 1, box=((-12, 12), (-6, 6), (5.9, 6.1)), scale=(0.02, 0.12))
+    rng = np.random.default_rng(18)
+    back = rng.random(n) < 0.3
+    means[back, 2] = rng.uniform(-10.0, -2.0, int(back.sum())).astype(np.float32)
+    scene = (means, scales, quats, opac, sh, deg)
+    w, h = res
+    view = look_at_view((0.3, -0.2, -1.0), (0.5, 0.4, 6.0))
+    cam = onp.Camera(w, h, 0.9 * w, 0.9 * w, w / 2.0 + 3.3, h / 2.0 - 2.1, view)
+    gy = (h + 15) // 16
+    n_chunks = (n + 63) // 64
+    skipped = {}
+    for rows in ((0, -1), (0, 2), (gy // 2, gy // 2 + 1), (gy - 2, gy)):
+        check_against_oracle(drv, scene, cam, rows=rows, what=f"chunk bounds rows {rows}")
+        drv.render(cam, None, rows)
+        sk = drv.chunk_skipped()
+        assert len(sk) == n_chunks
+        skipped[rows] = int(sk.sum())
+        drv.render(cam, None, rows, chunk_cull=False)
+        assert int(drv.chunk_skipped().sum()) == 0
+    assert skipped[(0, -1)] > 0.4 * n_chunks, skipped              # most of the scene is outside the view
+    for rows in list(skipped)[1:]:
+        assert skipped[rows] > skipped[(0, -1)], skipped            # a band skips what is above / below it as well
 
 
 def case_tile_rows(drv, n=2500, res=(208, 150)):

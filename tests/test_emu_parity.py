@@ -40,6 +40,10 @@ def test_tile_row_bands(drv):
     pc.case_tile_rows(drv, n=1200, res=(112, 100))
 
 
+def test_chunk_bounds_skip_only_invisible_chunks(drv):
+    pc.case_chunk_bounds(drv, n=6000, res=(208, 150))
+
+
 @pytest.mark.parametrize("stride", [2, 3])
 def test_interleaved_tile_rows(drv, stride):
     pc.case_interleaved_rows(drv, stride, n=1200, res=(112, 100))

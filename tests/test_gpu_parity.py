@@ -30,7 +30,8 @@ class GpuDriver:
             self.scene.free()
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
-    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False, interleave=None):
+    def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False, interleave=None,
+               chunk_cull=True):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
@@ -39,11 +40,11 @@ class GpuDriver:
             owned = len(range(interleave[1], (cam.height + 15) // 16, interleave[0]))
             band = self.torch.full((16 * owned, cam.width, 3), -1.0, dtype=self.torch.float32, device="cuda:0")
             img = self.r.render(c, self.scene, config=k, out_band=band, tile_rows=None if rows == (0, -1) else rows,
-                                full_sort=full_sort, loose_cull=loose_cull, interleave=interleave)
+                                full_sort=full_sort, loose_cull=loose_cull, interleave=interleave, chunk_cull=chunk_cull)
             return img.cpu().numpy(), self.r.last_stats
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
         img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
-                            full_sort=full_sort, loose_cull=loose_cull)
+                            full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull)
         return img.cpu().numpy(), self.r.last_stats
 
     def render_aux(self, cam, cfg=None):
@@ -57,6 +58,13 @@ class GpuDriver:
 
     def set_record_capacity(self, n):
         self.r.set_record_capacity(n)
+
+    def chunk_skipped(self):
+        from sage_gs import _capi
+        return self.r.debug_buffer(_capi.BUF_CHUNK_SKIPPED, np.uint8)
+
+    def row_records(self, n_rows, reset=True):
+        return self.r.row_records(n_rows, reset)
 
     def close(self):
         if self.scene is not None:
@@ -101,6 +109,10 @@ def test_empty_and_all_culled(drv):
 
 def test_tile_row_bands(drv):
     pc.case_tile_rows(drv, n=6000, res=(400, 300))
+
+
+def test_chunk_bounds_skip_only_invisible_chunks(drv):
+    pc.case_chunk_bounds(drv, n=60_000, res=(640, 400))
 
 
 @pytest.mark.parametrize("stride", [2, 3, 8])
