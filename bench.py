@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — frames/sec of the 3DGS scene-render hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 3|4|5]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one frame: one pass of the hot path (SH -> projection -> AABB -> binning -> per-tile sort
 -> composite) over the whole scene for one camera of the seeded pose list, scene already resident in
 HBM (uploaded once per scene, as the reference loads a stage once — generate_images.py:320-327).
-Workload at N=1: BASELINE.json configs[2], the configuration the metric is quoted on — a ~3 M-Gaussian
-synthetic InteriorGS-like scene, SH degree 3, 1920x1080 (InteriorGS itself is not available offline).
-N > 1 (one process per GPU, scene replicated — 708 MB): the frames of the sweep are independent units, so a step is
-one pose PER GPU with no data-path collective ("weak" scaling: N*K frames in the timed region).  BASELINE configs[3],
-every frame sharded by tile row over the ranks and gathered to rank 0 over RCCL/xGMI ("strong"), is timed right
-afterwards and reported under `also_measured` (`--shard rows` makes it the headline instead).
 
-Prints ONE JSON line on rank 0 with the contract's fields plus `roofline` (dominant kernel, measured
-live with HIP events on the launch stream) and `cpu_baseline` (the oracle's C port on the host cores).
+Workloads (BASELINE.md numbering; the scene is synthetic, InteriorGS is not available offline):
+  config 3 (N = 1 default)  BASELINE.json configs[2], the configuration the metric is quoted on: make_room(3 M, seed 2),
+                            SH degree 3, 1920x1080, reference lens, 256-pose sweep (4 positions x 64 headings).
+  config 4 (N > 1 default)  configs[3]: the same frames, every frame sharded by tile row over the N ranks (cost-balanced
+                            contiguous bands) and gathered to rank 0 over RCCL/xGMI — "strong" scaling: K frames in total.
+                            The camera-sharded sweep (one pose per GPU per step, no data-path collective, "weak") is timed
+                            right afterwards and reported under `also_measured` (`--shard cameras` swaps the roles).
+  config 5                  configs[4]: the scene at 3840x2160, 360 cameras at 1-degree yaw steps from one position; both
+                            shardings as above.
+Step i renders pose (i * 77) mod n_poses — 77 is coprime to 256 and 360, so ANY K steps sample the whole sweep evenly and
+`--steps 20` measures the same workload as `--steps 100`.
+
+Prints ONE JSON line on rank 0 with the contract's fields plus
+  roofline      the dominant kernel (the fused sort + composite) against the HBM roofline, from its duration ALONE (one
+                frame at a time, HIP events on the launch stream — the figure `rocprofv3 --kernel-trace --stats` of
+                `--no-pipeline` reproduces, profiles/), with SURVEY.md §8(d)'s bytes; never from the overlapped span;
+  latency_ms    one frame at a time, host-timed call -> frame complete (what a get_rgb()-style caller sees);
+  cpu_baseline  the oracle's C port on the host cores, on a bounded sample of the same workload.
 """
 import argparse
 import json
@@ -27,6 +37,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_LANE_OPS = 78.6e12    # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the 157 TFLOP/s fp32 peak counts an FMA twice)
+POSE_STRIDE = 77
 
 
 def parse():
@@ -34,25 +46,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", type=int, choices=(3, 4, 5), default=None,
+                    help="BASELINE.md configuration (default: 3 at N=1, 4 at N>1)")
     ap.add_argument("--gaussians", type=int, default=3_000_000, help="scene size (default: BASELINE configs[2])")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--shard", choices=("rows", "cameras"), default="cameras",
-                    help="N>1 headline: camera shards (default: one pose per GPU per step, no data-path collective, weak "
-                         "scaling) or tile-row shards + RCCL gather (BASELINE configs[3], strong scaling); the other "
-                         "mode is timed afterwards and reported under 'also_measured'")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--shard", choices=("rows", "cameras"), default="rows",
+                    help="N>1 headline: tile-row shards + RCCL gather (BASELINE configs[3], strong scaling; default) or camera "
+                         "shards (one pose per GPU per step, no data-path collective, weak scaling); the other mode is "
+                         "timed afterwards and reported under 'also_measured'")
+    ap.add_argument("--bands", choices=("balanced", "even", "interleave"), default="balanced",
+                    help="tile-row shards: contiguous bands re-cut by cost from the previous batch (default), the even "
+                         "9,9,9,9,8,8,8,8 split, or every N-th row")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
     ap.add_argument("--secondary-timeout", type=float, default=180.0,
                     help="N>1: seconds after which a stuck second measurement is abandoned and the headline printed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
-    ap.add_argument("--interleave", action="store_true",
-                    help="tile-row shards own every N-th row instead of a contiguous band (balanced, but every rank bins more splats)")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
     ap.add_argument("--event-stride", type=int, default=4,
                     help="bracket the stages of every n-th frame of the timed region with HIP events (recording them on "
-                         "every frame costs ~4 %% of the sweep's throughput; the per-stage times are averages over the "
-                         "sampled frames)")
+                         "every frame costs ~4 %% of the sweep's throughput)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
                          "independent frames in flight on the library's internal streams)")
@@ -83,6 +97,12 @@ def cpu_baseline(scene, cams, budget_s):
                       f"OpenMP x{cores}), {t_total:.1f} s"}
 
 
+def pct(xs):
+    import numpy as np
+    return {"p10": float(np.percentile(xs, 10)), "p50": float(np.percentile(xs, 50)), "p90": float(np.percentile(xs, 90)),
+            "mean": float(np.mean(xs)), "n": len(xs)}
+
+
 def main():
     args = parse()
     import numpy as np
@@ -90,7 +110,7 @@ def main():
     import torch.distributed as dist
     from sage_gs import Renderer, scenes
     from sage_gs._capi import STAGE_NAMES
-    from sage_gs.dist import ShardedRenderer, shard_cameras
+    from sage_gs.dist import ShardedRenderer
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,19 +132,35 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    config = args.config or (3 if world == 1 else 4)
+    width = args.width or (3840 if config == 5 else 1920)
+    height = args.height or (2160 if config == 5 else 1080)
+
     # ---- workload: deterministic synthetic scene + pose list (identical on every rank) ---------------
-    scene = scenes.make_room(args.gaussians, seed=2)
-    cams = scenes.room_cameras(scene, args.width, args.height, n_positions=4, n_yaw=64, seed=2)
-    r = Renderer(device, record_capacity=96 << 20)
+    scene = scenes.cached_room(args.gaussians, seed=2)          # make_room(n, seed=2), kept in /tmp between processes
+    if config == 5:
+        cams = scenes.sweep_cameras(scene, width, height, n=360, seed=2)
+        pose_desc = "360-camera sweep, 1-degree yaw steps at one position"
+    else:
+        cams = scenes.room_cameras(scene, width, height, n_positions=4, n_yaw=64, seed=2)
+        pose_desc = "256-pose sweep (4 positions x 64 headings)"
+    n_poses = len(cams)
+    r = Renderer(device, record_capacity=(192 << 20) if config == 5 else (96 << 20))
     gs = r.upload(scenes.to_gaussians(scene, device))
     K, W = args.steps, args.warmup
     timing = not args.no_events
-
     pipelined = not args.no_pipeline
+    pose_set = f"config{config}:{args.gaussians}:{width}x{height}:W{W}:K{K}:stride{POSE_STRIDE}"
+
+    def pose(i):
+        return (i * POSE_STRIDE) % n_poses
+
     # frames of the sweep are independent: up to four are in flight per GPU, each with its own output buffer
-    frames = [torch.zeros((args.height, args.width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
+    frames = [torch.zeros((height, width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
     frame = frames[0]
-    sharded = ShardedRenderer(r, args.height, args.width, interleave=args.interleave) if world > 1 else None
+    sharded = None
+    if world > 1:
+        sharded = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
 
     def fence():
         torch.cuda.synchronize(device)
@@ -132,38 +168,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    def cam_of_step(i, rk):
-        """Camera shards: step i is one pose PER RANK (rank rk renders pose i*world + rk of the sweep)."""
-        return cams[(i * world + rk) % len(cams)]
-
     def run_cameras(first, count, timed):
-        """`count` steps, one frame per rank per step, no data-path collective.  Returns this rank's per-frame average
-        statistics; every frame of the region is checked for overflow."""
+        """Camera shards: step i is one pose PER RANK (rank rk renders pose (i * world + rk) of the strided sweep); no
+        data-path collective.  Returns this rank's per-frame average statistics; every frame is checked for overflow."""
         for i in range(count):
-            r.render(cam_of_step(first + i, rank), gs, out=frames[i % len(frames)], sync=False,
+            r.render(cams[pose((first + i) * world + rank)], gs, out=frames[i % len(frames)], sync=False,
                      timing=timed and i % max(1, args.event_stride) == 0, pipelined=pipelined)
         return r.sync() if count else None                # completes the frames in flight (all lanes)
 
     def run_rows(first, count, timed):
         """`count` frames, each sharded by tile row over all ranks and gathered to rank 0 (RCCL): the bands of `batch`
-        frames are rendered through the pipelined lanes and travel in one asynchronous gather, double-buffered."""
+        frames are rendered through the pipelined lanes and travel in one asynchronous exchange, double-buffered."""
         acc, n_acc, i = None, 0, 0
         while i < count:
             nb = min(sharded.batch, count - i) if pipelined else 1
-            batch_cams = [cams[(first + i + j) % len(cams)] for j in range(nb)]
+            batch_cams = [cams[pose(first + i + j)] for j in range(nb)]
             sharded.last_stats = None
             if pipelined:
                 sharded.render_batch(batch_cams, gs, timing=timed)
                 st = sharded.last_stats
             else:
-                r0, r1 = sharded.g.band
-                st = None
-                if r1 > r0:
-                    r.render(batch_cams[0], gs, out_band=sharded.g.slab, sync=False, timing=timed, **sharded.g.render_rows)
-                sharded.g.gather()
-                if r1 > r0:
-                    st = r.sync()
-            if st is not None:
+                sharded.render(batch_cams[0], gs)
+                st = r.last_stats
+            if st is not None and timed:
                 if acc is None:
                     acc = {"ms": {n: 0.0 for n in STAGE_NAMES}, "ms_total": 0.0}
                 for n in STAGE_NAMES:
@@ -194,95 +221,113 @@ def main():
 
     rows_primary = world > 1 and args.shard == "rows"
     elapsed, avg = measure(run_rows if rows_primary else run_cameras, W, K, timing)
-    frames_total = K if rows_primary else K * world       # camera shards: one frame per rank per step (weak scaling)
+    frames_total = K if (rows_primary or world == 1) else K * world       # camera shards: one frame per rank per step
 
-    # ---- per-frame algorithmic bytes of rank 0's frames (deterministic; outside the timed region) -----
+    # ---- the same frames one at a time on rank 0 (outside the timed region): kernel durations ALONE, algorithmic bytes,
+    #      and the host-timed latency of a synchronous frame -------------------------------------------------------------
     stage_bytes = {n: 0 for n in STAGE_NAMES}
-    iso_ms = {n: 0.0 for n in STAGE_NAMES}                 # the same launches one frame at a time (no overlap)
-    frame_ms = []                                          # GPU time of each of those frames, first launch -> last
+    iso_ms = {n: [] for n in STAGE_NAMES}
+    frame_ms, latency = [], []
     counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
+    pixels = 0
     if rank == 0:
-        rows = sharded.g.band if rows_primary else None
-        for i in range(K):
-            if rows is None:
-                r.render(cam_of_step(W + i, 0), gs, out=frame, timing=timing)
-            else:
-                r.render(cams[(W + i) % len(cams)], gs, out_band=sharded.g.slab, timing=timing, **sharded.g.render_rows)
+        own = sharded.g.render_target(0) if rows_primary else {"out": frame}      # (rows: rank 0's band of the even split)
+        sel = [pose(W + i) for i in range(K)] if (rows_primary or world == 1) else [pose((W + i) * world) for i in range(K)]
+        for p in sel:
+            r.render(cams[p], gs, timing=timing, **own)
             st = r.last_stats
             frame_ms.append(st["ms_total"])
             for n in STAGE_NAMES:
-                iso_ms[n] += st["ms"][n]
-            for n in STAGE_NAMES:
+                iso_ms[n].append(st["ms"][n])
                 stage_bytes[n] += st["bytes"][n]
             for k in ("n_visible", "d_total", "d_fetched"):
                 counts[k] += st[k]
             counts["max_tile_len"] = max(counts["max_tile_len"], st["max_tile_len"])
             counts["n_spill_tiles"] += st["n_spill_tiles"]
+            pixels += st["n_pixels"]
+        torch.cuda.synchronize(device)
+        for p in sel:                                       # no events: call -> frame complete, as a caller sees it
+            t0 = time.perf_counter()
+            r.render(cams[p], gs, **own)
+            latency.append(1e3 * (time.perf_counter() - t0))
     if world > 1:
         dist.barrier()
 
     if rank == 0:
-        frames_here = K
+        nfr = max(1, K)
+        mean = lambda xs: float(np.mean(xs)) if len(xs) else 0.0
+        cfg_name = {3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}[config]
+        bands_desc = {"balanced": "cost-balanced contiguous bands", "even": "even contiguous bands", "interleave": "interleaved rows"}[args.bands]
         out = {
             "metric": "frames/sec, 3M-Gaussian InteriorGS-like scene @1080p (+ achieved HBM GB/s in roofline)",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
             "scaling": "strong" if rows_primary else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[2]: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
-                                   f"SH deg 3, {args.width}x{args.height}, reference lens (8/20.955), 256-pose yaw sweep",
+            "config": {"workload": f"{cfg_name}: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
+                                   f"SH deg 3, {width}x{height}, reference lens (8/20.955), {pose_desc}; step i = pose (i*{POSE_STRIDE}) mod {n_poses}",
+                       "pose_set": pose_set,
                        "parallelism": "1 GPU" if world == 1 else
-                                      (f"tile-row shard x{world} ({'interleaved rows' if sharded.interleave else 'contiguous bands'}) + RCCL gather to rank 0"
-                                       + (f" (bands of {sharded.batch} frames per collective)" if pipelined else "")
+                                      (f"tile-row shard x{world} ({bands_desc}) + RCCL gatherv to rank 0"
+                                       + (f" (bands of {sharded.batch} frames per exchange)" if pipelined else "")
                                        if rows_primary
                                        else f"camera shard x{world}: one pose per GPU per step, scene replicated, no data-path collective"),
-                       "per_frame": {k: (v / max(1, frames_here) if k not in ("max_tile_len",) else v) for k, v in counts.items()}},
+                       "per_frame": {k: (v / nfr if k != "max_tile_len" else v) for k, v in counts.items()}},
         }
-        if avg is not None and timing and frames_here > 0:
-            ms = avg["ms"]
+        if timing and frame_ms:
             stages = {}
             for n in STAGE_NAMES:
-                b = stage_bytes[n] / frames_here
-                stages[n] = {"ms": ms[n], "alg_bytes": b, "GBps": (b / (ms[n] * 1e-3) / 1e9) if ms[n] > 0 else None,
-                             "ms_alone": iso_ms[n] / frames_here}
-            dom = max(STAGE_NAMES, key=lambda n: ms[n])
-            ach = stages[dom]["GBps"] or 0.0
-            traffic = valu_busy = lds_conf = valu_insts = None
+                b = stage_bytes[n] / nfr
+                ms_alone = mean(iso_ms[n])
+                stages[n] = {"ms_alone": ms_alone, "alg_bytes": b, "GBps": (b / (ms_alone * 1e-3) / 1e9) if ms_alone > 0 else None,
+                             "ms_in_flight": (avg["ms"][n] if avg is not None else None)}
+            dom = max(STAGE_NAMES, key=lambda n: stages[n]["ms_alone"])
+            D, Df, P = counts["d_total"] / nfr, counts["d_fetched"] / nfr, pixels / nfr
+            ms_dom = stages[dom]["ms_alone"]
+            # K4 sort = D x 8 B x 2, K5 composite = 40 D_f + 12 P.  D = records actually queued.
+            b_fused, b_k5, b_tight = 16 * D + 40 * Df + 12 * P, 40 * Df + 12 * P, stages["render"]["alg_bytes"]
+            gbps = lambda b: b / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
+            traffic = valu_busy = lds_conf = valu = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tpath):
-                try:                         # PMC passes of the same frames (scripts/gpu_round_profile.sh), committed
-                    tj = json.load(open(tpath))
-                    traffic = tj.get(dom)
-                    valu_busy = tj.get("_valu_busy", {}).get(dom)
-                    lds_conf = tj.get("_lds_bank_conflict_share", {}).get(dom)
-                    valu_insts = tj.get("_valu_insts", {}).get(dom)
+                try:         # PMC passes (scripts/gpu_round_profile.sh) are only quoted for the pose set they were taken on
+                    tj = json.load(open(tpath)).get(pose_set)
+                    if tj:
+                        traffic = tj.get(dom)
+                        valu_busy = tj.get("_valu_busy", {}).get(dom)
+                        lds_conf = tj.get("_lds_bank_conflict_share", {}).get(dom)
+                        vi = tj.get("_valu_insts", {}).get(dom)
+                        if vi and ms_dom > 0:
+                            valu = {"inst_per_launch": vi, "lane_ops_per_s": vi * 64.0 / (ms_dom * 1e-3),
+                                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS,
+                                    "basis": "SQ_INSTS_VALU of the committed PMC passes of this pose set / ms_alone"}
                 except Exception:
                     traffic = None
-            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                               "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf,
-                               # fp32-VALU fraction of the composite.  Lane operations (wave instructions x 64,
-                               # an FMA counted once) per second of the launch alone, against 256 CUs x 4 SIMDs x 32 lanes
-                               # x 2.4 GHz = 78.6 T lane-ops/s (the 157 TFLOP/s fp32 peak counts an FMA twice)
-                               "valu": ({"inst_per_launch": valu_insts,
-                                         "lane_ops_per_s": valu_insts * 64.0 / (iso_ms[dom] / frames_here * 1e-3),
-                                         "peak_lane_ops_per_s": 78.6e12,
-                                         "frac": valu_insts * 64.0 / (iso_ms[dom] / frames_here * 1e-3) / 78.6e12,
-                                         "basis": "SQ_INSTS_VALU of the committed PMC passes / ms_alone"}
-                                        if valu_insts and iso_ms[dom] > 0 else None),
-                               "avg_launch_ms": ms[dom], "alg_bytes_per_launch": stages[dom]["alg_bytes"],
-                               "stages": stages, "gpu_ms_per_frame": avg["ms_total"],
-                               "frame_ms_alone": ({"p10": float(np.percentile(frame_ms, 10)), "p50": float(np.percentile(frame_ms, 50)),
-                                                   "p90": float(np.percentile(frame_ms, 90)), "mean": float(np.mean(frame_ms))}
-                                                  if frame_ms and timing else None),
-                               "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
-                               "events_on_every_nth_frame": max(1, args.event_stride),
-                               "note": "the dominant kernel is VALU-issue-bound, not HBM-bound (valu_busy = share of its cycles "
-                                       "with the vector ALU executing, from the committed PMC passes); ms = HIP-event duration inside the timed region (frames overlap when "
-                                       "frames_in_flight > 1, so a launch shares the chip); ms_alone = the same launch "
-                                       "with nothing else running"}
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_tile_render (fused per-tile sort K4 + composite K5)" if dom == "render" else dom,
+                "achieved": gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0),
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": (gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0)) / HBM_PEAK_GBPS,
+                "basis": "algorithmic bytes per launch / average duration of the launch ALONE (HIP events, one frame at a time)",
+                "avg_launch_ms": ms_dom, "alg_bytes_per_launch": b_fused if dom == "render" else stages[dom]["alg_bytes"],
+                "accountings": ({"survey_k4_k5": {"bytes": b_fused, "formula": "16 D + 40 D_f + 12 P", "frac": gbps(b_fused) / HBM_PEAK_GBPS},
+                                 "survey_k5_only": {"bytes": b_k5, "formula": "40 D_f + 12 P", "frac": gbps(b_k5) / HBM_PEAK_GBPS},
+                                 "builder_tight": {"bytes": b_tight, "formula": "8 D + 36 D_f + 12 P (the sort never writes records back)",
+                                                   "frac": gbps(b_tight) / HBM_PEAK_GBPS}} if dom == "render" else None),
+                "traffic": traffic, "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf, "valu": valu,
+                "pmc_pose_set": pose_set if traffic is not None else None,
+                "stages": stages,
+                "frame_ms_alone": pct(frame_ms),
+                "gpu_ms_per_frame_in_flight": avg["ms_total"] if avg is not None else None,
+                "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
+                "events_on_every_nth_frame": max(1, args.event_stride),
+                "note": "the composite is VALU-issue-bound, not HBM-bound (valu.frac = share of the fp32 vector peak); ms_alone = a "
+                        "launch with nothing else running; ms_in_flight = HIP-event span inside the timed region, where frames "
+                        "overlap (not a kernel duration: it includes waiting for the lane's previous kernel)"}
+        if latency:
+            out["latency_ms"] = dict(pct(latency), what="one frame at a time, host-timed call -> frame complete (no events)")
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, cams[W:], args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(scene, [cams[pose(W + i)] for i in range(min(K, 32))], args.cpu_seconds)
     else:
         out = None
 
@@ -306,9 +351,9 @@ def main():
             n2 = K * world if rows_primary else K
             second = {"shard": "cameras" if rows_primary else "rows", "value": n2 / dt2, "unit": "frames/s", "steps": K,
                       "ms_per_step": 1e3 * dt2 / K, "scaling": "weak" if rows_primary else "strong",
-                      "parallelism": (f"camera shard x{world}" if rows_primary else
-                                      f"tile-row shard x{world} ({'interleaved rows' if sharded.interleave else 'contiguous bands'}) + RCCL gather to rank 0"
-                                      + (f" (bands of {sharded.batch} frames per collective)" if pipelined else ""))}
+                      "parallelism": (f"camera shard x{world}: one pose per GPU per step, no data-path collective" if rows_primary else
+                                      f"tile-row shard x{world} + RCCL gatherv to rank 0"
+                                      + (f" (bands of {sharded.batch} frames per exchange)" if pipelined else ""))}
         except Exception as e:           # noqa: BLE001 - reported, never fatal for the headline
             second = {"error": f"{type(e).__name__}: {e}"[:300]}
         finished.set()

@@ -178,7 +178,9 @@ int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats);
 /* Records queued per FRAME tile row (out[r], r < n_rows <= 4096), summed over every frame rendered since the last call with
  * reset != 0 — each frame adds the rows it rendered (its band).  This is the per-row cost from which cost-balanced
  * tile-row bands are cut (SURVEY.md §8e "optional cost-balanced ranges from the previous frame's per-row D"); the
- * reference has no counterpart (it shards by scene only, generate_images.py:136-139).  Synchronises the device. */
+ * reference has no counterpart (it shards by scene only, generate_images.py:136-139).  Covers the frames that have
+ * been completed (synchronous frames, or asynchronous ones after sgs_frame_sync); frames still in flight may be
+ * counted partly. */
 int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset);
 
 /* fp32 RGB -> uint8 RGBA (alpha 255), the shape cam.get_rgba() returns (simple_env.py:1380-1386;

@@ -770,7 +770,8 @@ int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset) {
     if (!ctx) return SGS_ERR_INVALID;
     if (n_rows < 0 || n_rows > SGS_MAX_ROWS || (n_rows > 0 && !out)) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad row buffer (%d rows)", n_rows);
     SGS_HIP(ctx, hipSetDevice(ctx->device));
-    SGS_HIP(ctx, hipDeviceSynchronize());
+    // (no device-wide synchronisation: a sweep's framebuffer exchange may be in flight on another stream and must not
+    //  be waited for here; the frames the caller has synchronised are complete, and that is the contract)
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters");
     if (n_rows > 0) SGS_HIP(ctx, hipMemcpy(out, ctx->row_acc, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
     if (reset) SGS_HIP(ctx, hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS));

@@ -6,25 +6,29 @@ generate_images.py:136-139); this is BASELINE.json's design: every rank holds th
 rows, and the bands are gathered to rank 0 over xGMI.  Tiles are independent after binning, so the
 gathered frame is bit-identical to a single-GPU frame (tests: tile-row union == full frame).
 
-Which rows a rank owns: a contiguous band of equal height by default, or (`interleave=True`) every R-th row — rank r of R
-owns frame tile rows r, r+R, r+2R, ...  An indoor view puts most of its depth complexity into a few rows around the
-horizon, so equal bands are uneven (the slowest of 8 ranks carries 1.5x the mean of the 256-pose sweep) while every R-th
-row gives each rank the same mix whatever the camera looks at.  Interleaved rows are stored compactly
-(`Renderer.render(interleave=(R, r))`), so slabs stay equal-size and the collective is unchanged; rank 0 re-interleaves
-the rows when it hands out a frame (one device copy).  It is opt-in because it does not pay on the indoor sweep
-(measured per rank on one MI355X, frames pipelined, ms per frame of the slowest rank, contiguous -> interleaved:
-R=2 0.168 -> 0.171, R=4 0.136 -> 0.134, R=8 0.112 -> 0.101): a splat covers 2-3 tile rows, so every rank then projects,
-shades and bins ~1.7x the splats a contiguous band sees, and the copy on rank 0 eats what is left.  Bands balanced by
-queue length did better in the same experiment (R=8 0.087, R=4 0.116) but need a calibration pass and unequal slabs.
+What a rank pays for: the library tests every 64-Gaussian chunk of the (Z-ordered) scene against the rank's band
+before it touches it (csrc: k_chunk_bounds / chunk_outside), so projection, SH, binning, sorting and blending all
+scale with what the band can see — not with the scene.
 
-The one exchange step is a gather of equal-size slabs (`torch.distributed.gather`; backend "nccl" is
-RCCL on ROCm, "gloo" in the CPU tests).  Rank 0 receives straight into views of its frame buffer,
-so there is no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.3 MB per rank at 8 ranks): seven
-peers land on seven distinct xGMI links of rank 0 concurrently, so the step is latency-, not
-bandwidth-bound — one collective per frame, no ring.
+Which rows a rank owns:
+  * default — contiguous bands as even as they come: 68 rows over 8 ranks = 9,9,9,9,8,8,8,8 (`row_partition`);
+  * `balance=True` — contiguous bands of equal COST.  An indoor view puts most of its depth complexity into a few
+    rows around the horizon, so equal bands leave the slowest of 8 ranks at ~1.5x the mean.  Every rank reports the
+    records its rows queued (`Renderer.row_records`, from the frames it just rendered), one tiny all-reduce makes the
+    per-row profile of the whole frame known everywhere, and the next batch's bands are cut from it
+    (`balanced_partition`: minimal largest band cost) — a sweep's views change slowly, so the previous batch predicts
+    the next;
+  * `interleave=True` — every R-th row (rank r owns rows r, r+R, ...): balanced whatever the camera looks at, but a
+    splat covers 2-3 tile rows, so every rank then projects and bins ~1.7x the splats of a contiguous band, and rank 0
+    has to re-interleave the rows (one copy).  Opt-in; measured slower than balanced bands.
 
-For a sweep of independent frames (`ShardedRenderer.render_batch`) the bands of B frames are rendered through the
-renderer's pipelined lanes and travel in one asynchronous collective, double-buffered against the next batch.
+The one exchange step is a gatherv of exact slabs: rank 0 posts one receive per (peer, frame) straight into the rows of
+its frame buffer, every peer one send per frame, all in ONE group (`torch.distributed.batch_isend_irecv`; on the
+"nccl" backend — RCCL on ROCm — that is a single ncclGroupStart/End of ncclSend/ncclRecv, i.e. a gatherv with
+the seven peers on seven distinct xGMI links of rank 0 concurrently; "gloo" in the CPU tests).  Bands may therefore be
+of any height and there is no padding and no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.1 MB per rank at 8
+ranks): latency-, not bandwidth-bound — so a sweep ships the bands of B frames per group, asynchronously, double-
+buffered against the rendering of the next batch (`ShardedRenderer.render_batch`).
 
 `shard_cameras` is the other natural partition (frames of a sweep are independent units): no
 data-path collective at all.
@@ -33,6 +37,7 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -40,13 +45,77 @@ TILE = 16
 
 
 def row_partition(n_tile_rows: int, world: int) -> List[Tuple[int, int]]:
-    """Contiguous bands of ceil(rows/world) tile rows; trailing ranks may get fewer (or none).
-    Uniform band height lets rank 0 gather directly into its frame buffer; the critical path
-    (largest band) is the same as for the most even split."""
+    """Contiguous bands, as even as they come: the first (rows mod world) ranks get one row more
+    (68 rows, 8 ranks -> 9,9,9,9,8,8,8,8).  Ranks beyond the rows get empty bands."""
     if world <= 0:
         raise ValueError("world must be positive")
-    per = (n_tile_rows + world - 1) // world
-    return [(min(r * per, n_tile_rows), min((r + 1) * per, n_tile_rows)) for r in range(world)]
+    base, extra = divmod(n_tile_rows, world)
+    bands, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < extra else 0)
+        bands.append((a, b))
+        a = b
+    return bands
+
+
+def balanced_partition(cost: Sequence[float], world: int, max_rows: Optional[int] = None) -> List[Tuple[int, int]]:
+    """Contiguous bands over len(cost) rows that minimise the largest band cost (cost[r] >= 0 per row; a band holds at
+    most `max_rows` rows — the capacity of a rank's slab).  Bisection on the bottleneck over the prefix sums with a
+    greedy feasibility test, then the greedy cut at the optimum; bands left over are made by halving the costliest
+    ones, so no rank that could have rows stays idle.  Deterministic: every rank computes the same bands from the
+    same costs."""
+    n = len(cost)
+    if world <= 0:
+        raise ValueError("world must be positive")
+    c = np.maximum(np.nan_to_num(np.asarray(cost, np.float64), nan=0.0, posinf=0.0), 0.0)
+    if max_rows is None:
+        max_rows = n
+    if max_rows * world < n:
+        raise ValueError(f"{world} bands of at most {max_rows} rows cannot cover {n} rows")
+    if n == 0:
+        return [(0, 0)] * world
+    pre = np.concatenate([[0.0], np.cumsum(c)])
+    if not pre[-1] > 0.0:            # nothing to balance
+        return row_partition(n, world)
+
+    def cut(limit):
+        """Greedy bands of cost <= limit (and <= max_rows rows), or None if they need more than `world` bands."""
+        bands, a = [], 0
+        while a < n:
+            if len(bands) == world:
+                return None
+            b = int(np.searchsorted(pre, pre[a] + limit, side="right")) - 1      # furthest b with pre[b] - pre[a] <= limit
+            b = min(b, a + max_rows, n)
+            if b <= a:
+                return None          # a single row exceeds the limit
+            # the rows left must still fit the bands left
+            if n - b > (world - len(bands) - 1) * max_rows:
+                return None
+            bands.append((a, b))
+            a = b
+        return bands
+
+    lo, hi = float(c.max()), float(pre[-1]) + 1.0
+    if cut(hi) is None:              # only the row cap binds: cost plays no part
+        return row_partition(n, world)
+    for _ in range(64):
+        mid = 0.5 * (lo + hi)
+        if cut(mid) is not None:
+            hi = mid
+        else:
+            lo = mid
+        if hi - lo <= 1e-9 * max(1.0, hi):
+            break
+    bands = cut(hi)
+    while len(bands) < min(world, n):
+        k = max(range(len(bands)), key=lambda i: (bands[i][1] - bands[i][0] > 1, pre[bands[i][1]] - pre[bands[i][0]]))
+        a, b = bands[k]
+        if b - a <= 1:
+            break
+        m = min(range(a + 1, b), key=lambda x: max(pre[x] - pre[a], pre[b] - pre[x]))      # the most even cut
+        bands[k:k + 1] = [(a, m), (m, b)]
+    bands += [(n, n)] * (world - len(bands))
+    return bands
 
 
 def shard_cameras(n_cameras: int, rank: int, world: int) -> range:
@@ -54,139 +123,276 @@ def shard_cameras(n_cameras: int, rank: int, world: int) -> range:
     return range(rank, n_cameras, world)
 
 
-class FrameGather:
-    """Buffers and the collective for gathering tile-row bands of H x W frames to rank `dst`.
+class _Works:
+    """The handles of one exchange; wait() completes it (and, for the gloo-with-GPU-tensors debugging path, lands the
+    host-staged slabs in the device buffers)."""
 
-    batch=None: one frame, slab = [slab_rows, W, C].  batch=B: B frames per collective, slab = [B, slab_rows, W, C]
-    (a sweep's frames are independent, so their bands can travel together: one collective per B frames)."""
+    def __init__(self, works, after=None):
+        self._works, self._after = list(works or []), after
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self._after is not None:
+            self._after()
+            self._after = None
+
+
+class FrameGather:
+    """Buffers and the exchange for gathering the tile-row bands of H x W frames to rank `dst`.
+
+    batch=None: one frame; batch=B: B frames per exchange (a sweep's frames are independent, so their bands travel
+    together).  Rank dst owns the frames themselves ([B,] H, W, C — `frames()` / `frame(b)` are views of that buffer for
+    contiguous bands) and renders its own band in place; every other rank owns a slab of `max_band_rows` tile rows per
+    frame.  `render_target(b)` gives the keyword arguments for `Renderer.render` that put this rank's rows where the
+    exchange expects them.  Bands can be replaced between exchanges (`set_bands`: cost-balanced sharding) as long as
+    every rank installs the same ones."""
 
     def __init__(self, height: int, width: int, device, rank: Optional[int] = None, world: Optional[int] = None,
                  group=None, dst: int = 0, channels: int = 3, dtype=torch.float32, batch: Optional[int] = None,
-                 interleave: bool = False):
+                 interleave: bool = False, max_band_rows: Optional[int] = None):
         self.group = group
         self.interleave = bool(interleave)
         self.rank = dist.get_rank(group) if rank is None else rank
         self.world = dist.get_world_size(group) if world is None else world
-        self.dst, self.h, self.w = dst, height, width
+        self.dst, self.h, self.w, self.c = dst, height, width, channels
         self.batch = batch
         self.n_tile_rows = (height + TILE - 1) // TILE
-        self.bands = row_partition(self.n_tile_rows, self.world)
-        self.slab_rows = ((self.n_tile_rows + self.world - 1) // self.world) * TILE      # pixel rows per slab
-        self.band = self.bands[self.rank]
+        even = -(-self.n_tile_rows // self.world)
+        # a slab holds up to this many tile rows: room for cost-balanced bands (a cheap band — ceiling, floor — may be
+        # several times the even height)
+        self.max_band_rows = min(self.n_tile_rows, max(even, int(max_band_rows) if max_band_rows else 4 * even))
+        nb = 1 if batch is None else int(batch)
+        self._nb = nb
         if self.interleave:          # rank r owns frame rows r, r+world, ...; `band` then counts OWNED rows
             self.bands = [(0, len(range(r, self.n_tile_rows, self.world))) for r in range(self.world)]
-            self.band = self.bands[self.rank]
-        lead = () if batch is None else (int(batch),)
-        # every rank's slab has the same shape; rank dst owns the padded buffer the slabs land in
-        if self.rank == dst:
-            self.padded = torch.zeros((self.world,) + lead + (self.slab_rows, width, channels), dtype=dtype, device=device)
-            self.slab = self.padded[self.rank]
-            self._views = [self.padded[i] for i in range(self.world)]
+            rows_cap = even
         else:
-            self.padded = None
-            self.slab = torch.zeros(lead + (self.slab_rows, width, channels), dtype=dtype, device=device)
-            self._views = None
+            self.bands = row_partition(self.n_tile_rows, self.world)
+            rows_cap = self.max_band_rows
+        self.band = self.bands[self.rank]
+        self._frames = None
+        self._compact = None
+        self._slab = None
+        if self.rank == dst:
+            self._frames = torch.zeros((nb, height, width, channels), dtype=dtype, device=device)
+            if self.interleave and self.world > 1:
+                # compact images of every rank's rows land here; frames are assembled on request (one copy)
+                self._compact = torch.zeros((self.world, nb, rows_cap * TILE, width, channels), dtype=dtype, device=device)
+        else:
+            self._slab = torch.zeros((nb, rows_cap * TILE, width, channels), dtype=dtype, device=device)
+
+    # -- bands ------------------------------------------------------------------------------------------------------
+    def set_bands(self, bands: Sequence[Tuple[int, int]]):
+        """Install a new partition (contiguous bands only); must be called with the same bands on every rank."""
+        if self.interleave:
+            raise ValueError("interleaved rows are fixed by (world, rank)")
+        bands = [(int(a), int(b)) for a, b in bands]
+        if len(bands) != self.world or bands[0][0] != 0 or bands[-1][1] != self.n_tile_rows or \
+                any(b < a or b - a > self.max_band_rows for a, b in bands) or \
+                any(bands[i][0] != bands[i - 1][1] for i in range(1, len(bands))):
+            raise ValueError(f"not a partition of {self.n_tile_rows} tile rows into {self.world} bands of <= "
+                             f"{self.max_band_rows} rows: {bands}")
+        self.bands = bands
+        self.band = bands[self.rank]
+
+    def _px(self, band) -> Tuple[int, int]:
+        return band[0] * TILE, min(band[1] * TILE, self.h)
 
     @property
     def band_pixel_rows(self) -> Tuple[int, int]:
         if self.interleave:
             raise ValueError("interleaved rows are not one range of pixel rows")
-        return self.band[0] * TILE, min(self.band[1] * TILE, self.h)
+        return self._px(self.band)
+
+    @property
+    def slab(self) -> torch.Tensor:
+        """The tensor this rank's rows are written to ([rows, W, C], or [B, rows, W, C] with batch=B): rank dst's own
+        rows of the frame buffer (contiguous bands), its compact image (interleaved), or the slab of another rank."""
+        if self.rank != self.dst:
+            t = self._slab
+        elif self._compact is not None:
+            t = self._compact[self.rank]
+        elif self.interleave:                   # world == 1
+            t = self._frames
+        else:
+            y0, y1 = self._px(self.band)
+            t = self._frames[:, y0:y1]
+        return t[0] if self.batch is None else t
+
+    def render_target(self, b: int = 0) -> dict:
+        """Keyword arguments for Renderer.render that select this rank's rows of frame b and where they are stored."""
+        if self.interleave and self.world > 1:
+            buf = self._compact[self.rank] if self.rank == self.dst else self._slab
+            return {"out_band": buf[b], "interleave": (self.world, self.rank)}
+        if self.rank == self.dst:
+            return {"out": self._frames[b], "tile_rows": self.band}
+        return {"out_band": self._slab[b], "tile_rows": self.band}
 
     @property
     def render_rows(self) -> dict:
-        """Keyword arguments for Renderer.render that select this rank's rows (out_band = a slab of this object)."""
-        if self.interleave:
-            return {"interleave": (self.world, self.rank)} if self.world > 1 else {"tile_rows": self.band}
+        """The row selection alone (for callers that manage their own output buffers)."""
+        if self.interleave and self.world > 1:
+            return {"interleave": (self.world, self.rank)}
         return {"tile_rows": self.band}
 
-    def _assemble(self, padded: torch.Tensor) -> torch.Tensor:
-        """[world, slab_rows, W, C] -> [H, W, C]: a view for contiguous bands, one copy for interleaved rows."""
-        if self.interleave and self.world > 1:
-            k = self.slab_rows // TILE
-            v = padded.view(self.world, k, TILE, self.w, -1).permute(1, 0, 2, 3, 4)       # [k, world, 16, W, C]
-            return v.reshape(k * self.world * TILE, self.w, -1)[: self.h]
-        return padded.reshape(self.world * self.slab_rows, self.w, -1)[: self.h]
+    # -- the exchange ---------------------------------------------------------------------------------------------------
+    def _rows_px(self, r: int) -> int:
+        """Pixel rows of one frame that rank r contributes."""
+        if self.interleave:
+            return self.bands[r][1] * TILE
+        y0, y1 = self._px(self.bands[r])
+        return y1 - y0
 
-    def _collective(self, n: Optional[int], async_op: bool):
-        src = self.slab if n is None else self.slab[:n]
-        outs = None
+    def _global(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def exchange(self, n: Optional[int] = None, async_op: bool = False) -> Optional[_Works]:
+        """Gatherv of the first n frames' bands to rank dst, as ONE group of point-to-point operations.  Returns the
+        handle (async_op) or None once complete."""
+        n = self._nb if n is None else int(n)
+        if not 0 < n <= self._nb:
+            raise ValueError(f"1..{self._nb} frames per exchange")
+        if self.world == 1:
+            return None
+        mine = self._frames if self.rank == self.dst else self._slab
+        gloo_gpu = mine.is_cuda and dist.get_backend(self.group) == "gloo"
+        ops, staged = [], []
         if self.rank == self.dst:
-            outs = self._views if n is None else [v[:n] for v in self._views]
-        if src.is_cuda and dist.get_backend(self.group) == "gloo":
-            # debugging aid (several ranks on one GPU under gloo): stage through the host
-            host = src.cpu()
-            houts = [torch.empty_like(host) for _ in range(self.world)] if self.rank == self.dst else None
-            dist.gather(host, houts, dst=self.dst, group=self.group)
-            if self.rank == self.dst:
-                for o, h in zip(outs, houts):
-                    o.copy_(h)
-            return None
-        return dist.gather(src, outs, dst=self.dst, group=self.group, async_op=async_op)
+            for r in range(self.world):
+                rows = self._rows_px(r)
+                if r == self.dst or rows <= 0:
+                    continue
+                for b in range(n):
+                    if self.interleave:
+                        view = self._compact[r][b, :rows]
+                    else:
+                        y0 = self.bands[r][0] * TILE
+                        view = self._frames[b, y0:y0 + rows]
+                    if gloo_gpu:                 # debugging aid (several ranks on one GPU under gloo): stage through the host
+                        host = torch.empty(view.shape, dtype=view.dtype)
+                        staged.append((view, host))
+                        view = host
+                    ops.append(dist.P2POp(dist.irecv, view, self._global(r), self.group))
+        else:
+            rows = self._rows_px(self.rank)
+            if rows > 0:
+                for b in range(n):
+                    src = self._slab[b, :rows]
+                    if gloo_gpu:
+                        src = src.cpu()
+                        staged.append((None, src))       # kept alive until the send has completed
+                    ops.append(dist.P2POp(dist.isend, src, self._global(self.dst), self.group))
+        works = dist.batch_isend_irecv(ops) if ops else []
 
-    def gather(self) -> Optional[torch.Tensor]:
-        """Collective (single-frame buffers).  Returns the assembled [H,W,C] frame on rank dst (contiguous bands: a view
-        of the receive buffer, no copy)."""
-        if self.batch is not None:
-            raise ValueError("gather() is for single-frame buffers; use gather_batch()")
-        if self.world > 1:
-            self._collective(None, False)
-        if self.rank != self.dst:
-            return None
-        return self._assemble(self.padded)
-
-    def gather_batch(self, n: Optional[int] = None, async_op: bool = False):
-        """Collective over the first n frames of a batched buffer.  Returns the work handle (None when complete)."""
-        if self.batch is None:
-            raise ValueError("gather_batch() needs batch=B buffers")
-        if self.world > 1:
-            return self._collective(n, async_op)
+        def land():
+            for view, host in staged:
+                if view is not None:
+                    view.copy_(host)
+        h = _Works(works, land if staged else None)
+        if async_op:
+            return h
+        h.wait()
         return None
 
-    def frames(self, n: Optional[int] = None) -> Optional[torch.Tensor]:
-        """Rank dst: the gathered batch as a [n, world, slab_rows, W, C] view (contiguous bands: frame b = rows of [b]
-        stacked, cut at H; interleaved: use frame(b))."""
-        if self.rank != self.dst:
-            return None
-        v = self.padded.permute(1, 0, 2, 3, 4)
-        return v if n is None else v[:n]
+    # -- single-frame convenience ---------------------------------------------------------------------------------------
+    def gather(self) -> Optional[torch.Tensor]:
+        """Exchange (single-frame buffers).  Returns the [H,W,C] frame on rank dst (contiguous bands: the frame buffer
+        itself, no copy)."""
+        if self.batch is not None:
+            raise ValueError("gather() is for single-frame buffers; use exchange()")
+        self.exchange(1)
+        return self.frame(0)
 
-    def frame(self, b: int) -> Optional[torch.Tensor]:
-        """Rank dst: frame b of the gathered batch, assembled to [H,W,C] (one copy)."""
+    def gather_batch(self, n: Optional[int] = None, async_op: bool = False):
+        if self.batch is None:
+            raise ValueError("gather_batch() needs batch=B buffers")
+        return self.exchange(n, async_op)
+
+    def frames(self, n: Optional[int] = None) -> Optional[torch.Tensor]:
+        """Rank dst: the gathered frames, [n, H, W, C] (contiguous bands: a view of the receive buffer)."""
         if self.rank != self.dst:
             return None
-        return self._assemble(self.padded[:, b])
+        n = self._nb if n is None else n
+        if self._compact is not None:
+            return torch.stack([self.frame(b) for b in range(n)])
+        return self._frames[:n]
+
+    def frame(self, b: int = 0) -> Optional[torch.Tensor]:
+        """Rank dst: frame b, [H, W, C] (contiguous bands: a view; interleaved rows: assembled with one copy)."""
+        if self.rank != self.dst:
+            return None
+        if self._compact is not None:
+            k = self._compact.shape[2] // TILE
+            v = self._compact[:, b].view(self.world, k, TILE, self.w, self.c).permute(1, 0, 2, 3, 4)   # [k, world, 16, W, C]
+            return v.reshape(k * self.world * TILE, self.w, self.c)[: self.h]
+        return self._frames[b]
 
 
 class ShardedRenderer:
-    """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows,
-    the bands are gathered to rank `dst`."""
+    """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows, the
+    bands are gathered to rank `dst`.  balance=True re-cuts the bands of a sweep by cost (see the module docstring)."""
 
-    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8, interleave: bool = False):
+    # cost of a tile row = records queued in it + this many "records" per tile of fixed work (clearing, scanning and
+    # writing a tile costs about as much as blending a few dozen records; scripts/band_balance2.py)
+    TILE_COST = 48.0
+
+    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8,
+                 interleave: bool = False, balance: bool = False):
+        if balance and interleave:
+            raise ValueError("interleaved rows are balanced by construction; balance=True is for contiguous bands")
         self.r = renderer
         self.h, self.w, self.group, self.dst = height, width, group, dst
-        self.interleave = bool(interleave)
+        self.interleave, self.balance = bool(interleave), bool(balance)
         self.g = FrameGather(height, width, renderer.device, group=group, dst=dst, interleave=self.interleave)
         self.batch = int(batch)
         self._ring = None            # two batched buffers: one travels while the other is rendered into
         self._pending = [None, None]
         self._turn = 0
+        self._cost_work = None       # the all-reduce of the previous batch's per-row records
+        self._cost = None
+        self.bands = list(self.g.bands)
         self.last_stats = None       # statistics of the last batch this rank rendered (per-frame averages)
 
+    @property
+    def world(self) -> int:
+        return self.g.world
+
     def render(self, camera, scene, *, config=None):
-        """One frame: every rank renders its band into its slab and joins the gather; rank dst gets the frame.
+        """One frame: every rank renders its band and joins the exchange; rank dst gets the frame.
         The band is rendered synchronously: a frame that exceeds the record capacity is re-rendered after the queues
         have grown (an asynchronous frame would render nothing and the stale slab would travel)."""
         r0, r1 = self.g.band
         if r1 > r0:
-            self.r.render(camera, scene, config=config, out_band=self.g.slab, sync=True, **self.g.render_rows)
+            self.r.render(camera, scene, config=config, sync=True, **self.g.render_target(0))
         return self.g.gather()
+
+    # -- cost-balanced bands ---------------------------------------------------------------------------------------------
+    def _post_costs(self, n_frames: int):
+        """After a batch: every rank contributes the records its rows queued; one small all-reduce, posted BEFORE the
+        batch's exchange so that it does not queue behind 25 MB per frame on the communicator."""
+        g = self.g
+        rec = self.r.row_records(g.n_tile_rows, reset=True).astype(np.float64) / max(1, n_frames)
+        dev = "cpu" if dist.get_backend(self.group) == "gloo" else self.r.device
+        self._cost = torch.from_numpy(rec).to(dev)
+        self._cost_work = dist.all_reduce(self._cost, group=self.group, async_op=True) if self.world > 1 else None
+
+    def _rebalance(self):
+        if self._cost is None:
+            return
+        if self._cost_work is not None:
+            self._cost_work.wait()
+            self._cost_work = None
+        cost = self._cost.cpu().numpy() + self.TILE_COST * ((self.w + TILE - 1) // TILE)
+        self._cost = None
+        self.bands = balanced_partition(cost, self.world, self.g.max_band_rows)
 
     def render_batch(self, cameras, scene, *, config=None, timing=False):
         """Up to `batch` independent frames (a sweep): the bands are rendered through the renderer's pipelined lanes
-        and travel in ONE asynchronous collective, which overlaps with the next call's rendering (two buffers
-        alternate).  Returns the FrameGather holding this batch; its contents are complete after .finish() (or the
-        next-but-one render_batch call)."""
+        and travel in ONE asynchronous group of sends/receives, which overlaps with the next call's rendering (two
+        buffers alternate).  Returns the FrameGather holding this batch; its contents are complete after .finish() (or
+        the next-but-one render_batch call)."""
         n = len(cameras)
         if n == 0 or n > self.batch:
             raise ValueError(f"1..{self.batch} cameras per batch")
@@ -195,22 +401,29 @@ class ShardedRenderer:
                                       interleave=self.interleave) for _ in range(2)]
         k = self._turn
         self._turn ^= 1
-        if self._pending[k] is not None:           # the collective that last read this buffer
+        if self._pending[k] is not None:           # the exchange that last read this buffer
             self._pending[k].wait()
             self._pending[k] = None
         g = self._ring[k]
+        if self.balance:
+            self._rebalance()                      # bands cut from the previous batch's per-row records (same on all ranks)
+            g.set_bands(self.bands)
         r0, r1 = g.band
         if r1 > r0:
             for b, cam in enumerate(cameras):
-                self.r.render(cam, scene, config=config, out_band=g.slab[b], sync=False, pipelined=True, timing=timing,
-                              **g.render_rows)
-            self.last_stats = self.r.sync()        # bands complete (all lanes) before the collective reads them
-        self._pending[k] = g.gather_batch(n, async_op=True)
+                self.r.render(cam, scene, config=config, sync=False, pipelined=True, timing=timing, **g.render_target(b))
+            self.last_stats = self.r.sync()        # bands complete (all lanes) before the exchange reads them
+        if self.balance:
+            self._post_costs(n)
+        self._pending[k] = g.exchange(n, async_op=True)
         return g
 
     def finish(self):
-        """Wait for the collectives in flight."""
+        """Wait for the exchanges in flight."""
         for k in (0, 1):
             if self._pending[k] is not None:
                 self._pending[k].wait()
                 self._pending[k] = None
+        if self._cost_work is not None:
+            self._cost_work.wait()
+            self._cost_work = None

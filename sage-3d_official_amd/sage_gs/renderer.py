@@ -263,7 +263,7 @@ class Renderer:
 
     def row_records(self, n_rows: int, reset: bool = True) -> np.ndarray:
         """Records queued per frame tile row, summed over the frames rendered since the last reset (int64 [n_rows]):
-        the per-row cost that cost-balanced tile-row bands are cut from (sage_gs.dist).  Synchronises the device."""
+        the per-row cost that cost-balanced tile-row bands are cut from (sage_gs.dist).  Covers completed frames (call after sync())."""
         out = np.zeros(int(n_rows), np.int64)
         self._lib.check(self._lib.sgs_row_records(self._ctx, out.ctypes.data, int(n_rows), 1 if reset else 0), self._ctx)
         return out

@@ -203,6 +203,33 @@ def make_room(n, seed=1, size=None, height=2.8, sh_degree=3, n_rooms=None):
                        MODEL_TO_WORLD.copy(), (sx, sy, height), rooms)
 
 
+def cached_room(n, seed=1, cache_dir=None, **kw):
+    """`make_room`, kept on disk between processes (the generator takes ~25 s for 3 M Gaussians; benchmarks and profiling
+    runs that start many processes on one box load the arrays instead).  cache_dir=None -> $SGS_SCENE_CACHE or
+    /tmp/sage_gs_scenes; any failure to read or write the cache falls back to generating."""
+    import os
+    if kw:
+        return make_room(n, seed=seed, **kw)
+    d = cache_dir or os.environ.get("SGS_SCENE_CACHE") or "/tmp/sage_gs_scenes"
+    path = os.path.join(d, f"room_{int(n)}_{int(seed)}_v1.npz")
+    try:
+        z = np.load(path)
+        return SceneArrays(z["means"], z["scales"], z["quats"], z["opacities"], z["sh"], int(z["sh_degree"]),
+                           z["model_to_world"], tuple(float(v) for v in z["extent"]), tuple(tuple(float(v) for v in r) for r in z["rooms"]))
+    except Exception:
+        pass
+    sc = make_room(n, seed=seed)
+    try:
+        os.makedirs(d, exist_ok=True)
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        np.savez(tmp, means=sc.means, scales=sc.scales, quats=sc.quats, opacities=sc.opacities, sh=sc.sh, sh_degree=sc.sh_degree,
+                 model_to_world=sc.model_to_world, extent=np.asarray(sc.extent), rooms=np.asarray(sc.rooms))
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return sc
+
+
 def view_from_yaw(position, yaw, pitch=0.0):
     """world->camera matrix of a camera at `position` (world, Z up) looking along heading `yaw`
     (radians about +Z, 0 = +X) with `pitch` up; camera axes +X right, +Y down, +Z forward."""
@@ -237,6 +264,21 @@ def room_cameras(scene: SceneArrays, width=1920, height=1080, n_positions=4, n_y
         for k in range(n_yaw):
             cams.append(Camera(width, height, fx, fy, cx, cy, view_from_yaw(pos, 2 * math.pi * k / n_yaw)))
     return cams
+
+
+def sweep_cameras(scene: SceneArrays, width=3840, height=2160, n=360, position=None, seed=0):
+    """BASELINE.md config 5 / SURVEY.md §8d: a 360-degree camera sweep — `n` cameras at ONE eye-height position, yaw
+    steps of 360/n degrees (1 degree at n = 360), the reference's lens (fx = 1466 px at 3840).  This is the shape of the
+    reference's batch caller (generate_images.py:408-436: one pose per waypoint, same scene, same camera).  `position`
+    defaults to a seeded point inside the scene's first room."""
+    from .renderer import Camera
+    fx, fy, cx, cy = reference_intrinsics(width, height)
+    if position is None:
+        rng = np.random.default_rng(seed + 2000)
+        x0, y0, x1, y1 = (scene.rooms or ((0.0, 0.0, scene.extent[0], scene.extent[1]),))[0]
+        position = (rng.uniform(x0 + 1.0, x1 - 1.0), rng.uniform(y0 + 1.0, y1 - 1.0), EYE_HEIGHT)
+    position = (float(position[0]), float(position[1]), float(position[2]) if len(position) > 2 else EYE_HEIGHT)
+    return [Camera(width, height, fx, fy, cx, cy, view_from_yaw(position, 2 * math.pi * k / n)) for k in range(n)]
 
 
 def to_gaussians(scene: SceneArrays, device):

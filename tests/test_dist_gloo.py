@@ -1,6 +1,9 @@
-"""The N>1 path on CPU: world_size-2 (and 3) `gloo` runs of the tile-row partition + framebuffer gather
+"""The N>1 path on CPU: world_size-2 (and 3) `gloo` runs of the tile-row partition + framebuffer gatherv
 (sage_gs/dist.py).  Each rank contributes the oracle's render of ITS band of tile rows; rank 0 must end up
-with the full frame, bit-identical to an un-sharded render (tiles are independent after binning)."""
+with the full frame, bit-identical to an un-sharded render (tiles are independent after binning).  The
+ShardedRenderer's host logic (batches in flight, cost-balanced bands, the per-row all-reduce) runs here against a
+stand-in renderer that copies rows of known frames; the real renderer runs it on the GPU (test_gpu_sharded.py)."""
+import itertools
 import os
 import socket
 
@@ -10,20 +13,55 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sage_gs.dist import FrameGather, row_partition, shard_cameras
+from sage_gs.dist import FrameGather, ShardedRenderer, balanced_partition, row_partition, shard_cameras
 
 
 def test_row_partition_covers_rows_once():
-    for rows, world in ((68, 1), (68, 2), (68, 4), (68, 8), (135, 8), (3, 8), (16, 16), (1, 4)):
+    assert [b - a for a, b in row_partition(68, 8)] == [9, 9, 9, 9, 8, 8, 8, 8]
+    assert [b - a for a, b in row_partition(135, 8)] == [17] * 7 + [16]                   # 4K
+    assert [b - a for a, b in row_partition(68, 4)] == [17] * 4 and [b - a for a, b in row_partition(68, 2)] == [34, 34]
+    for rows, world in ((68, 1), (68, 2), (68, 4), (68, 8), (135, 8), (3, 8), (16, 16), (1, 4), (0, 3)):
         bands = row_partition(rows, world)
         assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == rows
-        per = -(-rows // world)
-        for r, (a, b) in enumerate(bands):
-            assert 0 <= b - a <= per and a == min(r * per, rows)
-            if r:
-                assert a == bands[r - 1][1]
+        sizes = [b - a for a, b in bands]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+        for r in range(1, world):
+            assert bands[r][0] == bands[r - 1][1]
     assert [len(shard_cameras(10, r, 4)) for r in range(4)] == [3, 3, 2, 2]
     assert sorted(i for r in range(4) for i in shard_cameras(10, r, 4)) == list(range(10))
+
+
+def _bottleneck(cost, bands):
+    return max(sum(cost[a:b]) for a, b in bands)
+
+
+def test_balanced_partition_is_optimal_and_respects_the_row_cap():
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        n = int(rng.integers(1, 13)); world = int(rng.integers(1, 6))
+        cost = np.round(rng.exponential(10.0, n) ** rng.uniform(0.5, 2.0), 3)
+        cap = int(rng.integers(-(-n // world), n + 1))
+        bands = balanced_partition(cost, world, cap)
+        assert len(bands) == world and bands[0][0] == 0 and bands[-1][1] == n
+        assert all(0 <= b - a <= cap for a, b in bands) and all(bands[i][0] == bands[i - 1][1] for i in range(1, world))
+        assert sum(b > a for a, b in bands) == min(world, n)                      # nobody idle who could work
+        # brute force over every cut
+        best = np.inf
+        for cuts in itertools.combinations_with_replacement(range(n + 1), world - 1):
+            edges = (0,) + cuts + (n,)
+            cand = [(edges[i], edges[i + 1]) for i in range(world)]
+            if all(b - a <= cap for a, b in cand):
+                best = min(best, _bottleneck(cost, cand))
+        assert _bottleneck(cost, bands) <= best * (1 + 1e-6) + 1e-9, (cost, world, cap, bands, best)
+    # an indoor-like profile: the horizon rows carry the records
+    cost = np.concatenate([np.full(20, 5.0), np.full(10, 300.0), np.full(38, 40.0)])
+    bal, even = balanced_partition(cost, 8, 36), row_partition(68, 8)
+    assert _bottleneck(cost, bal) < 0.5 * _bottleneck(cost, even)
+    assert balanced_partition(cost, 8, 36) == bal                                 # deterministic
+    assert balanced_partition(np.zeros(68), 8) == row_partition(68, 8)          # nothing to balance: the even split
+    assert _bottleneck(np.ones(68), balanced_partition(np.ones(68), 8)) == 9
+    with pytest.raises(ValueError):
+        balanced_partition(np.ones(68), 8, 8)                                     # 8 x 8 rows cannot cover 68
 
 
 def _free_port():
@@ -38,16 +76,20 @@ def _owned_pixel_rows(g):
     return rows
 
 
-def _worker(rank, world, port, h, w, n, q, interleave=False):
+def _init(rank, world, port):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (os.path.join(root, "oracle"), os.path.join(root, "sage-3d_official_amd")):
         if p not in sys.path:
             sys.path.insert(0, p)
-    import oracle_c
-    import oracle_np as onp
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _worker(rank, world, port, h, w, n, q, interleave=False):
+    _init(rank, world, port)
+    import oracle_c
+    import oracle_np as onp
     try:
         scene, _ = onp.config1_scene(n=n, seed=3)
         cam = onp.Camera(w, h, 0.6 * w, 0.6 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
@@ -60,6 +102,7 @@ def _worker(rank, world, port, h, w, n, q, interleave=False):
             for dst_row, src_row in _owned_pixel_rows(g):
                 g.slab[dst_row] = torch.from_numpy(whole[src_row])
         elif r1 > r0:
+            assert g.render_rows == {"tile_rows": (r0, r1)}
             band, _ = oracle_c.render(*scene, cam, None, r0, r1, threads=1, want="image")
             y0, y1 = g.band_pixel_rows
             g.slab[: y1 - y0] = torch.from_numpy(band[y0:y1])
@@ -74,57 +117,77 @@ def _worker(rank, world, port, h, w, n, q, interleave=False):
         dist.destroy_process_group()
 
 
+def _spawn(target, world, *args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(240)
+        assert p.exitcode == 0
+    return q.get(timeout=5)
+
+
+def _worker_entry(rank, world, port, h, w, n, interleave, q):
+    _worker(rank, world, port, h, w, n, q, interleave)
+
+
 @pytest.mark.parametrize("world,res,interleave", [(2, (112, 160), False), (3, (100, 72), False), (2, (24, 40), False),
                                                   (2, (112, 160), True), (3, (100, 72), True), (3, (24, 40), True)])
 def test_tile_row_gather_gloo(world, res, interleave):
     h, w = res
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, h, w, 1500, q, interleave)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(180)
-        assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    assert _spawn(_worker_entry, world, h, w, 1500, interleave) is True
 
 
-def _batch_worker(rank, world, port, h, w, q, interleave=False):
-    """Batched bands: B frames per collective, asynchronous, partial last batch (FrameGather(batch=B))."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def _pattern(b, rows, w):
+    """frame b, pixel row y: value 1000 b + y (+ column / channel pattern) -> any misplaced slab shows."""
+    return 1000.0 * b + rows.view(-1, 1, 1) + 0.001 * torch.arange(w, dtype=torch.float32).view(1, -1, 1) \
+        + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
+
+
+def _batch_worker(rank, world, port, h, w, interleave, q):
+    """Batched bands: B frames per exchange, asynchronous, partial last batch, and — contiguous bands — a re-partition
+    into UNEQUAL bands between exchanges (the gatherv moves exact slabs; nothing is padded)."""
+    _init(rank, world, port)
     try:
         B = 4
         g = FrameGather(h, w, torch.device("cpu"), batch=B, interleave=interleave)
-        if interleave:
-            pairs = _owned_pixel_rows(g)
-            dst_rows = torch.tensor([d for d, _ in pairs], dtype=torch.long)
-            src_rows = torch.tensor([s_ for _, s_ in pairs], dtype=torch.float32)
-        else:
-            y0, y1 = g.band_pixel_rows
-            dst_rows = torch.arange(0, y1 - y0, dtype=torch.long)
-            src_rows = torch.arange(y0, y1, dtype=torch.float32)
         ok = True
-        for n in (B, 3):                                       # a full batch, then a partial one reusing the buffer
-            g.slab.fill_(-7.0)
+        rounds = [(B, None), (3, None)]
+        if not interleave:
+            gy = g.n_tile_rows
+            uneven = [(0, 1)] + [(1, 1)] * (world - 2) + [(1, gy)] if gy > 1 and world > 1 else None      # rank 0 one row, last rank the rest
+            if uneven is not None and gy - 1 <= g.max_band_rows:
+                rounds.append((2, uneven))
+        for n, bands in rounds:
+            if bands is not None:
+                g.set_bands(bands)
+            if interleave:
+                pairs = _owned_pixel_rows(g)
+                dst_rows = torch.tensor([d for d, _ in pairs], dtype=torch.long)
+                src_rows = torch.tensor([s_ for _, s_ in pairs], dtype=torch.float32)
+            else:
+                y0, y1 = g.band_pixel_rows
+                dst_rows = torch.arange(0, y1 - y0, dtype=torch.long)
+                src_rows = torch.arange(y0, y1, dtype=torch.float32)
+            if rank == 0:
+                g._frames.fill_(-7.0)
+            else:
+                g.slab.fill_(-7.0)
             for b in range(n):
-                # frame b, pixel row y: value 1000 b + y (+ channel/column pattern) -> any misplaced slab shows
-                rows = src_rows.view(-1, 1, 1)
-                g.slab[b, dst_rows] = 1000.0 * b + rows + 0.001 * torch.arange(w, dtype=torch.float32).view(1, -1, 1) \
-                    + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
+                if len(dst_rows):
+                    g.slab[b][dst_rows] = _pattern(b, src_rows, w)
             work = g.gather_batch(n, async_op=True)
             if work is not None:
                 work.wait()
             if rank == 0:
-                exp_rows = torch.arange(h, dtype=torch.float32).view(-1, 1, 1)
                 for b in range(n):
-                    exp = 1000.0 * b + exp_rows + 0.001 * torch.arange(w, dtype=torch.float32).view(1, -1, 1) \
-                        + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
                     f = g.frame(b)
-                    ok = ok and tuple(f.shape) == (h, w, 3) and bool((f == exp).all())
+                    ok = ok and tuple(f.shape) == (h, w, 3) and bool((f == _pattern(b, torch.arange(h, dtype=torch.float32), w)).all())
                 v = g.frames(n)
-                ok = ok and tuple(v.shape) == (n, world, g.slab_rows, w, 3)
+                ok = ok and tuple(v.shape) == (n, h, w, 3) and bool((v[n - 1] == g.frame(n - 1)).all())
             else:
                 assert g.frame(0) is None and g.frames() is None
         if rank == 0:
@@ -137,13 +200,106 @@ def _batch_worker(rank, world, port, h, w, q, interleave=False):
 @pytest.mark.parametrize("world,res,interleave", [(2, (112, 160), False), (3, (100, 72), False), (3, (100, 72), True)])
 def test_batched_tile_row_gather_gloo(world, res, interleave):
     h, w = res
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_batch_worker, args=(r, world, port, h, w, q, interleave)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(180)
-        assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    assert _spawn(_batch_worker, world, h, w, interleave) is True
+
+
+class _RowCopyRenderer:
+    """Stand-in for sage_gs.Renderer in the host-logic test: a 'frame' is a known array, rendering a band copies its
+    rows to where Renderer.render would put them, and the per-row record counters follow a known cost profile."""
+
+    def __init__(self, frames, costs):
+        self.device = torch.device("cpu")
+        self.frames, self.costs = frames, costs
+        self.acc = np.zeros(costs.shape[1], np.int64)
+        self.calls = []
+
+    def render(self, cam, scene, *, config=None, out=None, out_band=None, tile_rows=None, interleave=None, sync=True,
+               pipelined=False, timing=False):
+        f = self.frames[cam]
+        h = f.shape[0]
+        if interleave is not None:
+            stride, phase = interleave
+            for k, row in enumerate(range(phase, (h + 15) // 16, stride)):
+                y0, y1 = 16 * row, min(16 * row + 16, h)
+                out_band[16 * k:16 * k + y1 - y0] = f[y0:y1]
+                self.acc[row] += self.costs[cam, row]
+            return out_band
+        r0, r1 = tile_rows
+        y0, y1 = 16 * r0, min(16 * r1, h)
+        if out is not None:
+            out[y0:y1] = f[y0:y1]
+        else:
+            out_band[:y1 - y0] = f[y0:y1]
+        self.acc[r0:r1] += self.costs[cam, r0:r1]
+        self.calls.append((cam, r0, r1))
+        return out if out is not None else out_band
+
+    def sync(self):
+        return {"ms": {}, "ms_total": 0.0}
+
+    def row_records(self, n_rows, reset=True):
+        out = self.acc[:n_rows].copy()
+        if reset:
+            self.acc[:] = 0
+        return out
+
+
+def _sharded_worker(rank, world, port, h, w, mode, q):
+    _init(rank, world, port)
+    try:
+        gy = (h + 15) // 16
+        n_frames = 11
+        rng = np.random.default_rng(5)                                         # identical on every rank
+        frames = torch.from_numpy(rng.random((n_frames, h, w, 3)).astype(np.float32))
+        # records per row: a moving "horizon" peak
+        costs = np.array([[2000 + 60000 * np.exp(-0.5 * ((r - (2 + 0.4 * c)) / 1.0) ** 2) for r in range(gy)] for c in range(n_frames)]).astype(np.int64)
+        rr = _RowCopyRenderer(frames, costs)
+        sr = ShardedRenderer(rr, h, w, batch=3, interleave=(mode == "interleave"), balance=(mode == "balance"))
+        ok = True
+        # single frames
+        for c in (0, 4):
+            f = sr.render(c, None)
+            if rank == 0:
+                ok = ok and bool((f == frames[c]).all())
+        # a sweep in batches of 3 (last one partial), two batches in flight
+        got, held = [], []
+        bands_seen = []
+        rr.row_records(gy, reset=True)                                         # the sweep starts from clean counters
+        for c0 in range(0, n_frames, 3):
+            cams = list(range(c0, min(n_frames, c0 + 3)))
+            g = sr.render_batch(cams, None)
+            bands_seen.append(tuple(g.bands))
+            held.append((g, cams))
+            if len(held) == 2:
+                g0, cams0 = held.pop(0)
+                sr._pending[sr._ring.index(g0)].wait() if sr._pending[sr._ring.index(g0)] is not None else None
+                if rank == 0:
+                    got += [(c, g0.frame(i).clone()) for i, c in enumerate(cams0)]
+        sr.finish()
+        for g0, cams0 in held:
+            if rank == 0:
+                got += [(c, g0.frame(i).clone()) for i, c in enumerate(cams0)]
+        if rank == 0:
+            ok = ok and sorted(c for c, _ in got) == list(range(n_frames)) and all(bool((f == frames[c]).all()) for c, f in got)
+        # every rank must have used the same bands for the same batch
+        gathered = [None] * world
+        dist.all_gather_object(gathered, bands_seen)
+        ok = ok and all(b == gathered[0] for b in gathered)
+        if mode == "balance":
+            even = tuple(row_partition(gy, world))
+            ok = ok and bands_seen[0] == even and any(b != even for b in bands_seen[1:])      # first batch even, later ones re-cut
+            # the re-cut bands are those of the PREVIOUS batch's mean profile (+ the fixed per-tile cost)
+            prev = costs[0:3].mean(axis=0) + ShardedRenderer.TILE_COST * ((w + 15) // 16)
+            ok = ok and list(bands_seen[1]) == balanced_partition(prev, world, sr.g.max_band_rows)
+        else:
+            ok = ok and len(set(bands_seen)) == 1
+        if rank == 0:
+            q.put(ok)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "interleave"), (2, "balance"), (3, "balance")])
+def test_sharded_renderer_host_logic_gloo(world, mode):
+    assert _spawn(_sharded_worker, world, 150, 72, mode) is True

@@ -180,60 +180,117 @@ def big_scene():
     return sc, cams
 
 
+def _check_frame_properties(drv, ocam, n_gauss, bands, stride=8, background=False):
+    """Size-independent properties of one full-size frame of the scene uploaded in `drv` (the oracle cannot run these
+    sizes in seconds): queues strictly ordered by (depth bits, index), D == sum of rect areas, tile-row bands and
+    interleaved rows reproduce the frame bit for bit (the multi-GPU sharding property), the lazy sort consumes what the
+    full sort consumed, culling hooks never change a pixel, determinism, background linearity."""
+    W, H = ocam.width, ocam.height
+    gy = (H + 15) // 16
+    prod, st_prod = drv.render(ocam, full_sort=True)                    # production binning (tight rects)
+    full, st = drv.render(ocam, full_sort=True, loose_cull=True)          # reference binning: the structures checked below
+    assert (prod == full).all() and st_prod["d_total"] <= st["d_total"] and st_prod["d_fetched"] <= st["d_fetched"]
+    assert np.isfinite(full).all() and full.min() >= 0.0
+    assert 0 < st["n_visible"] <= n_gauss and st["d_total"] >= st["n_visible"] and st["d_fetched"] <= st["d_total"]
+    off, ids, slot_ids, splats = drv.intermediates()
+    # (1) every queue is sorted by (depth bits, index); the offsets are a partition of D
+    assert off[-1] == st["d_total"] and (np.diff(off) >= 0).all() and len(off) == ((W + 15) // 16) * gy + 1
+    key_of = np.zeros(n_gauss, np.uint64); key_of[slot_ids] = splats[:, 9].astype(np.uint64)
+    comp = (key_of[ids] << np.uint64(32)) | ids.astype(np.uint64)
+    tile_of = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    same = tile_of[1:] == tile_of[:-1]
+    assert (comp[1:][same] > comp[:-1][same]).all(), "a queue is not strictly ordered by (depth, index)"
+    del comp, tile_of, same, key_of
+    # (2) D == sum of rect areas of the visible splats (a checksum of the binning)
+    x0, y0 = splats[:, 10] & 0xffff, splats[:, 10] >> 16
+    x1, y1 = splats[:, 11] & 0xffff, splats[:, 11] >> 16
+    assert int(((x1 - x0).astype(np.int64) * (y1 - y0)).sum()) == st["d_total"]
+    # (2b) the per-chunk bounds skipped no visible Gaussian
+    no_cull, st_nc = drv.render(ocam, chunk_cull=False)
+    assert (no_cull == full).all() and st_nc["n_visible"] == st["n_visible"] and st_nc["d_total"] == st_prod["d_total"]
+    # (3) tile-row bands reproduce the full frame bit-exactly (the multi-GPU sharding property)
+    union = np.zeros_like(full); d_sum = 0
+    for r0, r1 in bands:
+        band, st_b = drv.render(ocam, None, (r0, r1))
+        union[r0 * 16:min(r1 * 16, H)] = band[r0 * 16:min(r1 * 16, H)]
+        d_sum += st_b["d_total"]
+    assert (union == full).all() and d_sum == st_prod["d_total"] and bands[0][0] == 0 and bands[-1][1] == gy
+    # (3b) so do interleaved rows (rank p of `stride` owns rows p, p+stride, ...), and their queues add up to the frame's
+    union = np.zeros_like(full); d_sum = 0
+    for phase in range(stride):
+        comp_img, st_p = drv.render(ocam, interleave=(stride, phase))
+        for k, row in enumerate(range(phase, gy, stride)):
+            ya, yb = 16 * row, min(16 * row + 16, H)
+            union[ya:yb] = comp_img[16 * k: 16 * k + (yb - ya)]
+        d_sum += st_p["d_total"]
+    assert (union == full).all() and d_sum == st_prod["d_total"]
+    # (4) idempotence / determinism
+    again, _ = drv.render(ocam)
+    assert (again == full).all()
+    # (5) lazy sort under reference binning consumes exactly as many records as the full sort did
+    loose, st_loose = drv.render(ocam, loose_cull=True)
+    assert (loose == full).all() and st_loose["d_fetched"] == st["d_fetched"]
+    # (6) background linearity: frame(bg) = frame(black) + (1 - coverage) * bg, coverage from the depth/coverage output
+    if background:
+        from sage_gs import Camera, RenderConfig
+        c = Camera(W, H, ocam.fx, ocam.fy, ocam.cx, ocam.cy, np.asarray(ocam.view, np.float64))
+        bg = (0.25, 0.5, 0.75)
+        over = drv.r.render(c, drv.scene, config=RenderConfig(background=bg)).cpu().numpy()
+        _, aux = drv.r.render(c, drv.scene, return_aux=True)
+        t_final = 1.0 - aux.cpu().numpy()[..., 1:2]
+        assert np.abs(over - (full + t_final * np.asarray(bg, np.float32))).max() < 2e-6
+        assert (t_final >= 0).all() and (t_final <= 1).all()
+    return full, st_prod
+
+
+def _ocam(cam, sc):
+    view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
+    return onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
+
+
+BANDS_1080_8 = ((0, 9), (9, 18), (18, 27), (27, 36), (36, 44), (44, 52), (52, 60), (60, 68))      # BASELINE.md config 4
+BANDS_4K_8 = tuple((17 * i, min(135, 17 * (i + 1))) for i in range(8))                             # 17 x 7 + 16
+
+
 def test_3m_scene_properties(drv, big_scene):
+    """BASELINE configs[2] at its real size."""
     sc, cams = big_scene
     drv.upload(*sc.as_tuple())
     for cam in (cams[0], cams[5]):
-        view = (np.asarray(cam.view) @ sc.model_to_world).astype(np.float32)
-        ocam = onp.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, view)
-        prod, st_prod = drv.render(ocam, full_sort=True)                    # production binning (tight rects)
-        full, st = drv.render(ocam, full_sort=True, loose_cull=True)          # reference binning: the structures checked below
-        assert (prod == full).all() and st_prod["d_total"] <= st["d_total"] and st_prod["d_fetched"] <= st["d_fetched"]
-        assert np.isfinite(full).all() and full.min() >= 0.0
-        assert 0 < st["n_visible"] <= 3_000_000 and st["d_total"] >= st["n_visible"] and st["d_fetched"] <= st["d_total"]
-        off, ids, slot_ids, splats = drv.intermediates()
-        # (1) every queue is sorted by (depth bits, index); the offsets are a partition of D
-        assert off[-1] == st["d_total"] and (np.diff(off) >= 0).all()
-        key_of = np.zeros(3_000_000, np.uint64); key_of[slot_ids] = splats[:, 9].astype(np.uint64)
-        comp = (key_of[ids] << np.uint64(32)) | ids.astype(np.uint64)
-        tile_of = np.repeat(np.arange(len(off) - 1), np.diff(off))
-        same = tile_of[1:] == tile_of[:-1]
-        assert (comp[1:][same] > comp[:-1][same]).all(), "a queue is not strictly ordered by (depth, index)"
-        # (2) D == sum of rect areas of the visible splats (a checksum of the binning)
-        x0, y0 = splats[:, 10] & 0xffff, splats[:, 10] >> 16
-        x1, y1 = splats[:, 11] & 0xffff, splats[:, 11] >> 16
-        assert int(((x1 - x0).astype(np.int64) * (y1 - y0)).sum()) == st["d_total"]
-        # (3) tile-row bands reproduce the full frame bit-exactly (the multi-GPU sharding property)
-        union = np.zeros_like(full)
-        for r0, r1 in ((0, 9), (9, 18), (18, 27), (27, 36), (36, 44), (44, 52), (52, 60), (60, 68)):
-            band, _ = drv.render(ocam, None, (r0, r1))
-            union[r0 * 16:min(r1 * 16, 1080)] = band[r0 * 16:min(r1 * 16, 1080)]
-        assert (union == full).all()
-        # (3b) so do interleaved rows (rank p of 8 owns rows p, p+8, ...), and their queues add up to the frame's
-        union = np.zeros_like(full); d_sum = 0
-        for phase in range(8):
-            comp_img, st_p = drv.render(ocam, interleave=(8, phase))
-            for k, row in enumerate(range(phase, 68, 8)):
-                y0, y1 = 16 * row, min(16 * row + 16, 1080)
-                union[y0:y1] = comp_img[16 * k: 16 * k + (y1 - y0)]
-            d_sum += st_p["d_total"]
-        assert (union == full).all() and d_sum == st_prod["d_total"]
-        # (4) idempotence / determinism
-        again, _ = drv.render(ocam)
-        assert (again == full).all()
-        # (6) background linearity: frame(bg) = frame(black) + (1 - coverage) * bg, coverage from the depth/coverage output
-        if cam is cams[0]:
-            from sage_gs import Camera, RenderConfig
-            c = Camera(ocam.width, ocam.height, ocam.fx, ocam.fy, ocam.cx, ocam.cy, np.asarray(ocam.view, np.float64))
-            bg = (0.25, 0.5, 0.75)
-            over = drv.r.render(c, drv.scene, config=RenderConfig(background=bg)).cpu().numpy()
-            _, aux = drv.r.render(c, drv.scene, return_aux=True)
-            t_final = 1.0 - aux.cpu().numpy()[..., 1:2]
-            assert np.abs(over - (full + t_final * np.asarray(bg, np.float32))).max() < 2e-6
-            assert (t_final >= 0).all() and (t_final <= 1).all()
-        # (5) lazy sort under reference binning consumes exactly as many records as the full sort did
-        loose, st_loose = drv.render(ocam, loose_cull=True)
-        assert (loose == full).all() and st_loose["d_fetched"] == st["d_fetched"]
+        _check_frame_properties(drv, _ocam(cam, sc), 3_000_000, BANDS_1080_8, background=cam is cams[0])
+
+
+def test_room_500k_1080p_config2(drv):
+    """BASELINE configs[1]: make_room(500 000, seed 1) at 1920x1080, SH degree 3.  Two poses: the full comparison with the
+    oracle (counts, offsets, queue order, splat attributes, pixels) on two bands of tile rows each — the oracle finishes a
+    band in seconds — and the size-independent properties on the full frame."""
+    from sage_gs import scenes
+    sc = scenes.make_room(500_000, seed=1)
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=2, n_yaw=8, seed=1)
+    for ci, bands in ((2, ((30, 34), (50, 53))), (13, ((0, 3), (36, 40)))):
+        ocam = _ocam(cams[ci], sc)
+        for rows in bands:
+            pc.check_against_oracle(drv, sc.as_tuple(), ocam, rows=rows, what=f"config2 500k cam {ci} rows {rows}")
+        _check_frame_properties(drv, ocam, 500_000, BANDS_1080_8, background=(ci == 2))
+
+
+def test_3m_scene_4k_config5_geometry(drv, big_scene):
+    """BASELINE configs[4] geometry at its real size: the 3 M-Gaussian scene at 3840x2160 (240 x 135 tiles = four binning
+    windows), a pose of the 1-degree yaw sweep.  Size-independent properties on the full frame, bands = the 8-rank
+    partition (17 x 7 + 16); oracle check of a band that straddles a binning-window boundary (tile row 34)."""
+    from sage_gs import scenes
+    sc, _ = big_scene
+    cam = scenes.sweep_cameras(sc, 3840, 2160, n=360)[77]
+    ocam = _ocam(cam, sc)
+    drv.upload(*sc.as_tuple())
+    _check_frame_properties(drv, ocam, 3_000_000, BANDS_4K_8)
+    r0, r1 = 33, 36
+    img, st_b = drv.render(ocam, None, (r0, r1))
+    img_ref, st_bref = drv.render(ocam, None, (r0, r1), loose_cull=True)
+    ref, aux = oracle_c.render(*sc.as_tuple(), ocam, None, r0, r1, want="image")
+    assert (img_ref == img).all() and st_bref["d_total"] == aux["D"] and st_b["n_visible"] == aux["n_visible"]
+    sl = slice(r0 * 16, r1 * 16)
+    assert_frame_close(img[sl], ref[sl], aux["margin"][sl], aux["recheck"], what="3M @ 4K band", y0=sl.start)
 
 
 def test_3m_scene_crop_vs_oracle(drv, big_scene):

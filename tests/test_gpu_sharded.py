@@ -1,0 +1,99 @@
+"""BASELINE configs[3] logic on ONE GPU: `ShardedRenderer` for real — 2 and 3 ranks (one process each, as deployed)
+sharing cuda:0 under gloo, every rank rendering ITS band of tile rows with the HIP library, rank 0 receiving the
+gatherv.  The gathered frame must be bit-identical to the frame the same library renders un-sharded.  (On the 8-GPU
+node the only difference is the backend string: "nccl" = RCCL over xGMI, one GPU per rank.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, mode, n_gauss, res, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sage-3d_official_amd"))
+    import torch
+    import torch.distributed as dist
+    from sage_gs import Renderer, scenes
+    from sage_gs.dist import ShardedRenderer, row_partition
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert torch.cuda.is_available()
+        w, h = res
+        sc = scenes.make_room(n_gauss, seed=1)
+        cams = scenes.room_cameras(sc, w, h, n_positions=1, n_yaw=10, seed=1)
+        r = Renderer("cuda:0")
+        scene = r.upload(scenes.to_gaussians(sc, "cuda:0"))
+        sr = ShardedRenderer(r, h, w, batch=4, interleave=(mode == "interleave"), balance=(mode == "balance"))
+        ok, notes = True, []
+        whole = [r.render(c, scene).clone() for c in cams] if rank == 0 else None      # the un-sharded HIP frames
+        # one frame at a time (the latency mode)
+        for i in (0, 3):
+            f = sr.render(cams[i], scene)
+            if rank == 0:
+                same = bool((f == whole[i]).all())
+                ok = ok and same and tuple(f.shape) == (h, w, 3)
+                if not same:
+                    notes.append(f"render cam {i}: {(f != whole[i]).sum().item()} values differ")
+        # a sweep: batches of 4 (last partial), two exchanges in flight
+        r.row_records((h + 15) // 16, reset=True)
+        done, bands_seen = [], []
+        for c0 in range(0, len(cams), 4):
+            ids = list(range(c0, min(len(cams), c0 + 4)))
+            g = sr.render_batch([cams[i] for i in ids], scene)
+            bands_seen.append(tuple(g.bands))
+            done.append((g, ids, sr._turn ^ 1))
+            if len(done) == 2:
+                g0, ids0, k0 = done.pop(0)
+                if sr._pending[k0] is not None:
+                    sr._pending[k0].wait(); sr._pending[k0] = None
+                if rank == 0:
+                    for j, i in enumerate(ids0):
+                        same = bool((g0.frame(j) == whole[i]).all())
+                        ok = ok and same
+                        if not same:
+                            notes.append(f"batch cam {i}: {(g0.frame(j) != whole[i]).sum().item()} values differ")
+        sr.finish()
+        for g0, ids0, _ in done:
+            if rank == 0:
+                for j, i in enumerate(ids0):
+                    same = bool((g0.frame(j) == whole[i]).all())
+                    ok = ok and same
+                    if not same:
+                        notes.append(f"batch(tail) cam {i}: {(g0.frame(j) != whole[i]).sum().item()} values differ")
+        if mode == "balance":
+            even = tuple(row_partition((h + 15) // 16, world))
+            ok = ok and bands_seen[0] == even and any(b != even for b in bands_seen[1:])
+            notes.append(f"bands {bands_seen}")
+        st = sr.last_stats
+        ok = ok and st is not None and st["n_visible"] > 0
+        if rank == 0:
+            q.put((ok, notes))
+        dist.barrier()
+        scene.free(); r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "balance"), (2, "interleave"), (3, "interleave")])
+def test_sharded_renderer_on_one_gpu(world, mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, mode, 500_000, (1920, 1080), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
+    ok, notes = q.get(timeout=10)
+    assert ok, notes
