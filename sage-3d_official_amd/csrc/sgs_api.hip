@@ -413,7 +413,7 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     stats->retries = ctx->last_retries;
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
-    stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 48 + 4) * nv;
+    stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 64 + 16) * nv;   // rows read; splat + binning record written
     stats->bytes[SGS_STAGE_COUNT] = 16 * nv + 16 * ((int64_t)ctx->last_T + 1);   // rect re-read + counters
     stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
     stats->bytes[SGS_STAGE_RENDER] = 8 * D + 36 * Df + 12 * pixels;               // every record seen once, D_f splats blended
@@ -804,7 +804,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_TILE_OFFSETS: have = ((int64_t)ctx->last_T + 1) * 4; break;       // every 8th sub-queue offset
         case SGS_BUF_SORTED_SLOTS: src = L.sorted_out; have = (s.overflow || !L.sorted_out) ? 0 : (int64_t)s.d_total * 4; break;
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
-        case SGS_BUF_SPLATS: src = L.splats; elem = (int64_t)sizeof(Splat); have = n_slots * elem; break;
+        case SGS_BUF_SPLATS: elem = 48; have = n_slots * elem; break;          // the 12-word view documented in sage_gs.h
         case SGS_BUF_CHUNK_SKIPPED: have = n_chunks; break;
         case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
@@ -831,6 +831,22 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         if (e == hipSuccess) e = hipMemcpy(bm.data(), L.bigmask, (size_t)n_chunks * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
         for (int64_t i = 0; i < n; ++i) ((unsigned char*)host_dst)[i] = vm[(size_t)i] == 0ull && bm[(size_t)i] == ~0ull;
+    }
+    if (what == SGS_BUF_SPLATS) {
+        // device records (sgs_common.h: 64 B, conic pre-scaled for the composite) -> x,y,conic a,b | c,opacity,r,g | b,depth,rect01,rect23
+        const int64_t cnt = n / elem;
+        std::vector<Splat> tmp((size_t)std::max<int64_t>(1, cnt));
+        hipError_t e = hipMemcpy(tmp.data(), L.splats, (size_t)cnt * sizeof(Splat), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+        const double l2e = 1.4426950408889634;
+        for (int64_t i = 0; i < cnt; ++i) {
+            const Splat& sp = tmp[(size_t)i];
+            float* o = (float*)((char*)host_dst + i * elem);
+            o[0] = sp.x; o[1] = sp.y;
+            o[2] = (float)((double)sp.A / (0.5 * l2e)); o[3] = (float)((double)sp.B / l2e); o[4] = (float)((double)sp.C / (0.5 * l2e));
+            o[5] = sp.o; o[6] = sp.r; o[7] = sp.g; o[8] = sp.b;
+            memcpy(o + 9, &sp.key, 4); memcpy(o + 10, &sp.rect01, 4); memcpy(o + 11, &sp.rect23, 4);
+        }
     }
     if (elem) {
         // a splat lives at its Gaussian's index; the per-chunk visibility masks say which are live.

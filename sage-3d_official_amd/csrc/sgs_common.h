@@ -77,11 +77,17 @@ struct FrameStatus {
     uint32_t pad_[4];
 };
 
-// One projected Gaussian ("splat"), 48 B, three aligned 16-B words.
-//   a = (x, y, conic_a, conic_b)   b = (conic_c, opacity, r, g)
-//   c = (b, depth bits, rect x0|y0<<16, rect x1|y1<<16)          (last three are bit patterns)
-struct Splat {
-    float ax, ay, aca, acb;
-    float bcc, bo, br, bg;
-    float cb; uint32_t key; uint32_t rect01; uint32_t rect23;
+// One projected Gaussian ("splat"): 64 B, 64-B aligned — exactly one HBM access sector, written once per frame by
+// k_preprocess (at the Gaussian's ORIGINAL index: with the scene in Z-order that is a scatter, and a 48-B record
+// straddling sectors made every such write a read-modify-write) and gathered by k_tile_render.  Everything the composite
+// needs per (splat, tile) that does not depend on the tile is computed here once, per splat:
+//   word 0..3   x, y, A, B            q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e):  A = conic_a log2(e)/2, B = conic_b log2(e)
+//   word 4..7   C, opacity, qcut, r   qcut = bits(log2(opacity / alpha_min)) + 1 (0 when below alpha_min)
+//   word 8..11  g, b, depth bits, hx  hx, hy = half extents of the ellipse {alpha >= alpha_min}, padded outward
+//   word 12..15 hy, qmax, rect x0|y0<<16, rect x1|y1<<16     qmax = log2(opacity / alpha_min); rect = S3's reference rect (tests)
+struct alignas(64) Splat {
+    float x, y, A, B;
+    float C, o; uint32_t qcut; float r;
+    float g, b; uint32_t key; float hx;
+    float hy, qmax; uint32_t rect01; uint32_t rect23;
 };

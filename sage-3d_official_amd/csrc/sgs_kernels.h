@@ -18,6 +18,8 @@
 
 namespace sgs {
 
+#define SGS_LOG2E 1.44269504088896341f
+
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
@@ -109,7 +111,11 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
     if (i >= 0) {
         g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
         g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
+#ifdef SGS_EXPERIMENT_SLOT_POS   // timing experiment only: splats stored at the layout position (breaks depth-tie order)
+        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)p));
+#else
         g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)i));
+#endif
     }
     geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
     geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
@@ -281,6 +287,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     unsigned brect01 = 0, brect23 = 0;                 // the rect the binning kernels walk (see below)
     int bnt = 0;
     float sx = 0.f, sy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f;
+    float ext_x = 3.0e38f, ext_y = 3.0e38f, qmax = -1.0f;   // extents of {alpha >= alpha_min} for the composite; log2(o / alpha_min)
     // Cheap exclusion before the fp64 work (17-64 % of the chunks in front of the near plane end with no visible
     // lane, and visibility is dense inside a chunk, so whole waves skip): an fp32 UPPER bound of the 3-sigma radius,
     //     lambda_max(J W Sigma W^T J^T) <= |J|_F^2 s_max^2,  |J|_F^2 <= (f_max / tz)^2 (2 + limx^2 + limy^2),
@@ -373,6 +380,15 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                 // 16t .. 16t+15.  fp32 with outward padding; the reference rect stays in the splat record and is what
                 // SGS_FLAG_LOOSE_CULL (tests) bins.
                 brect01 = rect01; brect23 = rect23;
+                // what the composite needs to decide which 8x8 quadrants of a tile the splat can reach (k_tile_render):
+                // alpha >= alpha_min  <=>  q2 <= qmax = log2(o / alpha_min); the ellipse's axis-aligned half extents are
+                // sqrt(K a) x sqrt(K c), K = 2 ln(o / alpha_min) = 2 ln2 qmax, padded generously (the exact quadrant test follows)
+                qmax = __log2f(g0.w) - __log2f(P.alpha_min);
+                if (qmax > 0.0f) {
+                    const float Kq = 1.38629436112f * qmax;
+                    const float ex_ = sqrtf(Kq * (float)a) * 1.01f + 0.5f, ey_ = sqrtf(Kq * (float)c) * 1.01f + 0.5f;
+                    ext_x = ex_ < 3.0e38f ? ex_ : 3.0e38f; ext_y = ey_ < 3.0e38f ? ey_ : 3.0e38f;      // (inf / NaN -> everywhere)
+                }
                 if (!(P.flags & 32u)) {
                     const float Kc = 2.0f * __logf(g0.w / P.alpha_min) * 1.0001f + 1.0e-4f;
                     if (Kc > 0.0f) {
@@ -424,10 +440,13 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             default: eval_sh<3>(row0, ux, uy, uz, r, g, b); break;
         }
         const float depth = (float)tz;
+        // the record of the composite (sgs_common.h): constants folded per splat, not per (splat, tile) or per pixel
+        const unsigned qcut = qmax >= 0.0f ? __float_as_uint(qmax) + 1u : 0u;
         float4* sp = reinterpret_cast<float4*>(splats + slot);
-        sp[0] = make_float4(sx, sy, ca, cb);
-        sp[1] = make_float4(cc, g0.w, r, g);
-        sp[2] = make_float4(b, __uint_as_float(__float_as_uint(depth)), __uint_as_float(rect01), __uint_as_float(rect23));
+        sp[0] = make_float4(sx, sy, (0.5f * SGS_LOG2E) * ca, SGS_LOG2E * cb);
+        sp[1] = make_float4((0.5f * SGS_LOG2E) * cc, g0.w, __uint_as_float(qcut), r);
+        sp[2] = make_float4(g, b, depth, ext_x);
+        sp[3] = make_float4(ext_y, qmax, __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
         binrec[pos] = uint4{__float_as_uint(depth), brect01, brect23, slot};
     }
@@ -1130,7 +1149,6 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_RCP(x) __builtin_amdgcn_rcpf(x)         // 1 ulp; every use below is padded outward
 #define SGS_SQRT(x) __builtin_amdgcn_sqrtf(x)
 #endif
-#define SGS_LOG2E 1.44269504088896341f
 #ifdef SGS_TILE_PROF   // profiling build: how many (wave, splat) evaluations had no pixel inside the alpha cut-off
 #define SGS_PROF_EVAL(valid, J)                                                                        \
     if ((J) != (unsigned)SGS_BATCH) {                                                                  \
@@ -1227,13 +1245,13 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         (void)wave_done;                                                                               \
         used = T > 0.0f ? base + m : used;                                                             \
     }
-// staging: write splat J (registers A_ = x,y,ca,cb  B_ = cc,o,r,g  CBLUE = b, ZV = view depth); QMAX = log2(o / alpha_min)
-#define SGS_STAGE(J, A_, B_, CBLUE, ZV, QMAX)                                                          \
+// staging: write splat J from its record (A_ = x,y,A,B  B_ = C,o,qcut,r  C_ = g,b,depth,hx) — a plain copy: k_preprocess
+// has folded every constant into the record
+#define SGS_STAGE(J, A_, B_, C_)                                                                       \
     {                                                                                                  \
-        const unsigned qcut_ = (QMAX) >= 0.0f ? __float_as_uint(QMAX) + 1u : 0u;                       \
-        s_a[J] = make_float4(A_.x, A_.y, (0.5f * SGS_LOG2E) * A_.z, SGS_LOG2E * A_.w);                 \
-        s_b[J] = make_float4((0.5f * SGS_LOG2E) * B_.x, B_.y, __uint_as_float(qcut_), B_.z);           \
-        s_c[J] = make_col<ColT>(B_.w, CBLUE, ZV);                                                      \
+        s_a[J] = A_;                                                                                   \
+        s_b[J] = B_;                                                                                   \
+        s_c[J] = make_col<ColT>(C_.x, C_.y, C_.z);                                                     \
     }
 #define SGS_STAGE_DUMMY()                                                                              \
     {                                                                                                  \
@@ -1394,9 +1412,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     const float fpx = (float)px, fpy = (float)py;
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
-    const float amin = P.alpha_min, amax = P.alpha_max, tmin = P.t_min;
+    const float amax = P.alpha_max, tmin = P.t_min;
     const int tmin_bits = (int)__float_as_uint(tmin);
-    const float l2_inv_amin = -__log2f(amin);          // alpha >= amin  <=>  q2 <= log2(o) + l2_inv_amin
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
     const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
 
@@ -1554,8 +1571,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
             // compiler has to merge the loaded registers with their defaults at the end of the branch, i.e. wait for
             // the gather right here — instead of behind the ranking below, which is what hides its latency
             const float4* const sp = reinterpret_cast<const float4*>(splats + (have ? (unsigned)mine : 0u));
-            const float4 nA = sp[0], nB = sp[1];
-            const float nC = sp[2].x;
+            const float4 nA = sp[0], nB = sp[1], nC = sp[2];
+            const float2 nD = *reinterpret_cast<const float2*>(sp + 3);          // hy, qmax
             // Rank of my record inside the group.  The resident queue is bucket-contiguous (MSD partition) and the
             // buckets are disjoint depth ranges, so rank = (records of shallower buckets) + (rank inside MY bucket):
             // a lane walks only its own bucket's slice — typically a few dozen records instead of the group's ~256.
@@ -1593,24 +1610,16 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
             //  cleared when the batch before last was consumed)
             if (tid == 0) SGS_STAGE_DUMMY()
             if (have) {
-                const float qmax = __log2f(nB.y) + l2_inv_amin;
+                const float qmax = nD.y, hx = nC.w, hy = nD.x;      // log2(o / alpha_min); half extents of {alpha >= alpha_min}
                 SGS_PROF_STAGED_ALL()
-                SGS_STAGE(rank, nA, nB, nC, __uint_as_float((unsigned)(mine >> 32)), qmax)
-                const float K = 1.38629436112f * qmax;     // d^T Q d <= 2 ln(o / amin)
-                const float detq = nA.z * nB.x - nA.w * nA.w;
-                if (K > 0.0f) {
-                    float hx = 3.0e38f, hy = 3.0e38f;
-                    if (detq > 1.0e-12f * nA.z * nB.x) {
-                        const float inv = K * SGS_RCP(detq);
-                        hx = SGS_SQRT(inv * nB.x) * 1.01f + 0.5f;
-                        hy = SGS_SQRT(inv * nA.z) * 1.01f + 0.5f;
-                    }
+                SGS_STAGE(rank, nA, nB, nC)
+                if (qmax > 0.0f) {
                     const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
                     const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
                     const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
                     unsigned qb4 = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                    ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits(rx, ry, (0.5f * SGS_LOG2E) * nA.z, SGS_LOG2E * nA.w, (0.5f * SGS_LOG2E) * nB.x, qmax);
+                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits(rx, ry, nA.z, nA.w, nB.x, qmax);
                     SGS_PROF_STAGED(qb4)
                     unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
                     const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
@@ -1705,12 +1714,11 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
-            float4 nA, nB; float nC, nD;
+            float4 nA, nB, nC; float2 nD;
             {   // unconditional (see the single-batch path): lanes past the batch read the group's first splat
                 const float4* sp = reinterpret_cast<const float4*>(splats + gv[(unsigned)tid < min((unsigned)SGS_BATCH, cnt) ? tid : 0]);
-                nA = sp[0]; nB = sp[1];
-                const float4 c4 = sp[2];
-                nC = c4.x; nD = c4.y;                      // .y = fp32 view depth (the sort key's bits)
+                nA = sp[0]; nB = sp[1]; nC = sp[2];
+                nD = *reinterpret_cast<const float2*>(sp + 3);
             }
             for (unsigned gb = 0; gb < cnt && !tile_done; gb += SGS_BATCH, ++it) {
                 const unsigned par = it & 1u;
@@ -1721,24 +1729,15 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
                 unsigned qbits = 0;
                 if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
                 if (have) {
-                    const float qmax = __log2f(nB.y) + l2_inv_amin;
-                    SGS_STAGE((unsigned)tid, nA, nB, nC, nD, qmax)
-                    // extent of {alpha >= amin}: d^T Q d <= K, half-widths sqrt(K Sigma_xx), sqrt(K Sigma_yy)
-                    const float K = 1.38629436112f * qmax;     // 2 ln(o / amin)
-                    const float detq = nA.z * nB.x - nA.w * nA.w;
-                    if (K > 0.0f) {
-                        float hx = 3.0e38f, hy = 3.0e38f;
-                        if (detq > 1.0e-12f * nA.z * nB.x) {   // otherwise fp32 cannot bound it: keep everywhere
-                            const float inv = K * SGS_RCP(detq);
-                            hx = SGS_SQRT(inv * nB.x) * 1.01f + 0.5f;
-                            hy = SGS_SQRT(inv * nA.z) * 1.01f + 0.5f;
-                        }
+                    const float qmax = nD.y, hx = nC.w, hy = nD.x;
+                    SGS_STAGE((unsigned)tid, nA, nB, nC)
+                    if (qmax > 0.0f) {
                         const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
                         const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
                         const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
                         qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                 ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits(rx, ry, (0.5f * SGS_LOG2E) * nA.z, SGS_LOG2E * nA.w, (0.5f * SGS_LOG2E) * nB.x, qmax);
+                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits(rx, ry, nA.z, nA.w, nB.x, qmax);
                     }
                 }
 #pragma unroll
@@ -1750,9 +1749,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FramePar
                 const unsigned ngb = gb + SGS_BATCH;
                 if (ngb < cnt) {                 // (uniform) lanes past the next batch re-read its first splat
                     const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + ((unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb) ? tid : 0)]);
-                    nA = sp[0]; nB = sp[1];
-                    const float4 c4 = sp[2];
-                    nC = c4.x; nD = c4.y;
+                    nA = sp[0]; nB = sp[1]; nC = sp[2];
+                    nD = *reinterpret_cast<const float2*>(sp + 3);
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
