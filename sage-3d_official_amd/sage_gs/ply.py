@@ -12,8 +12,9 @@ reads the two PLY flavours directly so that real InteriorGS scenes can replace t
   * `load_compressed_ply` / `save_compressed_ply` — the PlayCanvas "compressed.ply" layout (per-256-splat
                    chunk bounds + 11/10/11-bit position and log-scale, 2+10+10+10-bit "smallest three"
                    rotation, 8-bit colour/opacity, optional 8-bit SH).  Written from the published format
-                   description; NOT verified against files produced by splat-transform (the tool is not
-                   available offline), so treat it as experimental until checked on a real scene.
+                   description and checked against a file assembled by hand from that layout
+                   (tests/test_next_rows.py); files produced by splat-transform itself could not be tried — the
+                   tool is not available offline.
 Pure NumPy, host side; the arrays go to `Renderer.upload` like any other scene.
 """
 from __future__ import annotations

@@ -53,7 +53,10 @@ def cameras_for(points, resolution=CAMERA_RESOLUTION):
 
 
 def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESOLUTION, force=False, quality=95,
-        chunk=64):
+        chunk=64, on_frame=None):
+    """Renders every trajectory (one GPU batch per `chunk` poses) and writes the reference's output layout.
+    on_frame(trajectory_id, index, rgb uint8 [H,W,3]) — optional — sees each frame as it is handed to the JPEG encoder
+    (the array `cam.get_rgba()[:, :, :3]` would be in generate_images.py:428-432)."""
     from PIL import Image
     os.makedirs(out_dir, exist_ok=True)
     sequences, total = [], 0
@@ -68,6 +71,8 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
                 frames = renderer.render_batch(cams[c0:c0 + chunk], scene)            # [B,H,W,3] on the GPU
                 for k in range(frames.shape[0]):
                     rgba = renderer.pack_rgba8(frames[k]).cpu().numpy()
+                    if on_frame is not None:
+                        on_frame(tr["trajectory_id"], c0 + k, rgba[:, :, :3])
                     Image.fromarray(rgba[:, :, :3]).save(os.path.join(tdir, names[c0 + k]), quality=quality)
         total += len(names)
         sequences.append({"scene_id": scene_id, "trajectory_id": tr["trajectory_id"],

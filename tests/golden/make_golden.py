@@ -7,6 +7,8 @@
                         Code/data_pipeline/training_data_construction/generate_actions.py:
                         BatchActionGenerator.yaw_from_quaternion :117).  The reference holds no tests, so these
                        are the only results of the reference itself that can be pinned for this path.
+  usda_golden.json   — the shape of a scene stage built by the reference's own builder from Data/template.usda, as
+                       (type, name, value) triples of the two prims the render path reads (see usda_fixture)
   config1_golden.npz — a small BASELINE config-1 frame from the fp64 NumPy oracle (image, tile offsets,
                        queue order, per-splat rects): pins the oracle against regressions and gives the GPU
                        tests a fixture that does not depend on running the oracle.
@@ -54,6 +56,47 @@ def pose_fixture():
     print("pose_golden.json:", len(cases), "cases")
 
 
+def usda_fixture():
+    """usda_golden.json — the SHAPE of a scene stage as the reference builds it, as data.  The reference's own
+    `sage3d_usda_builder.build_usda_content` (Code/benchmark/scene_data/sage3d_usda_builder.py:93-149) is run here on
+    Data/template.usda for one scene id; from its output only the two prims the render path reads are tokenised —
+    /World/gauss (template.usda:115-124) and /World/scene_collision (:156-165) — into (type, name, value) triples and
+    composition arcs, plus the stage's upAxis / metersPerUnit.  No template text is stored: the test re-serialises the
+    triples itself and checks `sage_gs.adapter.parse_scene_usda` on the result."""
+    import re
+    sys.path.insert(0, os.path.join(REF, "benchmark", "scene_data"))
+    import sage3d_usda_builder as b
+    template = open("/root/reference/Data/template.usda", "r", encoding="utf-8").read()
+    scene_id = "0042"
+    usdz_t = "@/data/InteriorGS_usdz/{scene_id}.usdz[gauss.usda]@"
+    coll_t = "@/data/InteriorGS_Collision/Collision/{scene_id}/{scene_id}_collision.usd@"
+    text = b.build_usda_content(template, scene_id, "839920", "@usdz_root[gauss.usda]@", usdz_t, "@collision_root@", coll_t)
+
+    def prim(header_re):
+        m = re.search(header_re, text, re.S)
+        meta = re.search(r"\((.*?)\)", text[m.start():], re.S).group(1)
+        arcs = [[a.strip(), v.strip()] for a, v in re.findall(r"(prepend\s+\w+)\s*=\s*(@[^@]*@)", meta)]
+        i = text.find("{", m.end())
+        j = text.find("}", i)
+        attrs = []
+        for line in text[i + 1:j].splitlines():
+            line = line.strip()
+            mm = re.match(r"((?:uniform\s+)?[\w\[\]]+)\s+([\w:]+)\s*=\s*(.+)$", line)
+            if mm:
+                attrs.append([mm.group(1), mm.group(2), mm.group(3)])
+        return {"arcs": arcs, "attrs": attrs}
+
+    out = {"source": "sage3d_usda_builder.build_usda_content on Data/template.usda (reference), tokenised by make_golden.py",
+           "scene_id": scene_id, "usdz_path_template": usdz_t, "collision_path_template": coll_t,
+           "stage": {"upAxis": re.search(r'upAxis\s*=\s*"(\w)"', text).group(1),
+                     "metersPerUnit": float(re.search(r"metersPerUnit\s*=\s*([\d.]+)", text).group(1))},
+           "gauss": dict(prim(r'over\s+"gauss"'), specifier='over "gauss"'),
+           "scene_collision": dict(prim(r'def\s+"scene_collision"'), specifier='def "scene_collision"'),
+           "authoring_layer": re.search(r'authoring_layer\s*=\s*"([^"]+)"', text).group(1)}
+    json.dump(out, open(os.path.join(HERE, "usda_golden.json"), "w"), indent=1)
+    print("usda_golden.json:", out["gauss"]["arcs"], len(out["gauss"]["attrs"]), "attrs;", out["scene_collision"]["arcs"])
+
+
 def config1_fixture():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_np as onp
@@ -80,6 +123,8 @@ def config1_fixture():
 
 
 if __name__ == "__main__":
-    if "--frames-only" not in sys.argv:          # (the pose fixture imports the reference; the frame fixture does not)
+    if "--frames-only" not in sys.argv:          # (the pose / usda fixtures import the reference; the frame fixture does not)
         pose_fixture()
-    config1_fixture()
+        usda_fixture()
+    if "--reference-only" not in sys.argv:
+        config1_fixture()

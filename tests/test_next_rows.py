@@ -67,19 +67,113 @@ def test_compressed_ply_round_trip(tmp_path):
     assert np.abs(col2 - col).max() <= 0.5 / 255 + 1e-6
 
 
+def _serialise_prim(spec, indent="    "):
+    """A prim stanza from (type, name, value) triples and composition arcs — this test's own writer."""
+    arcs = "".join(f"{indent}    {a} = {v}\n" for a, v in spec["arcs"])
+    attrs = "".join(f"{indent}    {t} {n} = {v}\n" for t, n, v in spec["attrs"])
+    return f"{indent}{spec['specifier']} (\n{arcs}{indent})\n{indent}{{\n{attrs}{indent}}}\n\n"
+
+
 def test_usda_resolver_on_the_reference_template_shape():
-    text = '''
-    def Xform "World" {
-        over "gauss" (
-            prepend references = @/data/scenes/0042.usdz[gauss.usda]@
-        ) {
-            float3 xformOp:rotateXYZ = (-90, 0, 0)
-        }
-        def "scene_collision" ( prepend payload = @/data/collision/0042_collision.usd@ ) {}
-    }'''
+    """f-3: `parse_scene_usda` on the stanzas a real scene stage holds.  tests/golden/usda_golden.json is the output of the
+    reference's OWN builder (sage3d_usda_builder.build_usda_content on Data/template.usda, run by make_golden.py) reduced
+    to data: the attributes of /World/gauss and /World/scene_collision as (type, name, value) triples — `double3
+    xformOp:rotateXYZ`, `prepend references = @...usdz[gauss.usda]@`, `prepend payload = @..._collision.usd@`.  The stage
+    text is re-serialised here and parsed by the product."""
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "usda_golden.json")))
+    text = ('#usda 1.0\n(\n    customLayerData = {\n        dictionary omni_layer = {\n'
+            f'            string authoring_layer = "{g["authoring_layer"]}"\n        }}\n    }}\n'
+            f'    defaultPrim = "World"\n    metersPerUnit = {g["stage"]["metersPerUnit"]:g}\n    upAxis = "{g["stage"]["upAxis"]}"\n)\n\n'
+            'def Xform "World"\n{\n' + _serialise_prim(g["gauss"]) +
+            '    def Camera "MySensorCamera"\n    {\n        float focalLength = 12\n        double3 xformOp:scale = (2, 2, 2)\n    }\n\n' +
+            _serialise_prim(g["scene_collision"]) + '}\n')
     got = adapter.parse_scene_usda(text)
-    assert got == {"usdz": "/data/scenes/0042.usdz", "collision": "/data/collision/0042_collision.usd",
-                   "rotate_xyz": (-90.0, 0.0, 0.0)}
+    sid = g["scene_id"]
+    assert got["usdz"] == g["usdz_path_template"].format(scene_id=sid).strip("@").replace("[gauss.usda]", "")
+    assert got["collision"] == g["collision_path_template"].format(scene_id=sid).strip("@")
+    assert g["authoring_layer"] == f"./{sid}.usda"
+    want = {n: v for _, n, v in g["gauss"]["attrs"]}
+    vec = lambda s_: tuple(float(v) for v in s_.strip("()").split(","))
+    assert got["rotate_xyz"] == vec(want["xformOp:rotateXYZ"]) == (-90.0, 0.0, 0.0)
+    assert got["scale"] == vec(want["xformOp:scale"]) and got["translate"] == vec(want["xformOp:translate"])   # the gauss prim's, not the camera's
+    assert list(got["xform_op_order"]) == json.loads(want["xformOpOrder"])
+    assert got["up_axis"] == g["stage"]["upAxis"] == "Z" and got["meters_per_unit"] == g["stage"]["metersPerUnit"] == 1.0
+    # the ops compose to the asset transform the renderer folds into the view (template.usda:119-123)
+    from sage_gs import scenes
+    assert np.abs(adapter.asset_model_to_world(got) - scenes.MODEL_TO_WORLD).max() < 1e-15
+    # a scaled asset is refused, not silently mis-rendered; other rotations compose as Rz Ry Rx
+    with pytest.raises(ValueError, match="rigid"):
+        adapter.asset_model_to_world(dict(got, scale=(2.0, 2.0, 2.0)))
+    M = adapter.asset_model_to_world(dict(got, rotate_xyz=(0.0, 0.0, 90.0), translate=(1.0, 2.0, 3.0)))
+    assert np.allclose(M @ [1, 0, 0, 1], [1, 3, 3, 1])
+
+
+def test_compressed_ply_decoder_on_hand_assembled_bytes(tmp_path):
+    """f-1: `load_compressed_ply` against a file assembled BY HAND from the published PlayCanvas layout — chunk rows of
+    min/max floats, vertex rows of four packed uint32 words (position 11-10-11, rotation 2-10-10-10 with the index of
+    the dropped largest component, log-scale 11-10-11, colour 8-8-8-8), an `sh` element of bytes — independent of this
+    repo's encoder.  Expected values are worked out here from the bit fields."""
+    import struct
+    # one chunk: position box [0,10] x [-1,1] x [2,4]; log-scale box [-4,-2] x [-3,-3] x [0,1]; colour box [0,1] (rgb) explicit
+    chunk = [0.0, -1.0, 2.0, 10.0, 1.0, 4.0, -4.0, -3.0, 0.0, -2.0, -3.0, 1.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0]
+    chunk_names = ["min_x", "min_y", "min_z", "max_x", "max_y", "max_z", "min_scale_x", "min_scale_y", "min_scale_z",
+                   "max_scale_x", "max_scale_y", "max_scale_z", "min_r", "min_g", "min_b", "max_r", "max_g", "max_b"]
+    pos = lambda x, y, z: (x << 21) | (y << 11) | z               # 11 | 10 | 11 bits
+    rot = lambda largest, a, b, c: (largest << 30) | (a << 20) | (b << 10) | c
+    col = lambda r, g, b, a: (r << 24) | (g << 16) | (b << 8) | a
+    h = 512                                                       # 10-bit code of ~0: (512/1023 - 0.5) sqrt2 = 6.9e-4
+    verts = [
+        # x = max, y = min, z = mid-code 1024/2047;   identity-ish: largest = w (index 0), others ~0;   scale codes 0 / any / 2047;  red, opaque
+        (pos(2047, 0, 1024), rot(0, h, h, h), pos(0, 777, 2047), col(255, 0, 0, 255)),
+        # x = min, y = max, z = min;                  largest = x (index 1): (w,y,z) = (a,b,c) with a = 1023 -> +0.7071;     grey 128, alpha 51 = 0.2
+        (pos(0, 1023, 0), rot(1, 1023, h, h), pos(2047, 0, 0), col(128, 128, 128, 51)),
+        # largest = z (index 3): stored (w,x,y) = (0, 1023, h) -> w = -0.7071, x = +0.7071
+        (pos(1, 1, 1), rot(3, 0, 1023, h), pos(1024, 512, 1024), col(0, 255, 64, 0)),
+    ]
+    sh_bytes = [[(7 * i + 40 * v) % 256 for i in range(45)] for v in range(3)]          # degree 3: 45 bytes per vertex
+    path = str(tmp_path / "hand.compressed.ply")
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement chunk 1\n")
+        for n_ in chunk_names:
+            f.write(f"property float {n_}\n".encode())
+        f.write(b"element vertex 3\nproperty uint packed_position\nproperty uint packed_rotation\nproperty uint packed_scale\nproperty uint packed_color\n")
+        f.write(b"element sh 3\n")
+        for i in range(45):
+            f.write(f"property uchar f_rest_{i}\n".encode())
+        f.write(b"end_header\n")
+        f.write(struct.pack("<18f", *chunk))
+        for v in verts:
+            f.write(struct.pack("<4I", *v))
+        for row in sh_bytes:
+            f.write(bytes(row))
+    m, s, q, o, sh, deg = ply.load_compressed_ply(path)
+    assert deg == 3 and sh.shape == (3, 16, 3) and m.dtype == np.float32
+    # positions: lerp(min, max, code / (2^bits - 1))
+    assert np.allclose(m[0], [10.0, -1.0, 2.0 + 2.0 * 1024 / 2047], atol=1e-6)
+    assert np.allclose(m[1], [0.0, 1.0, 2.0], atol=1e-6)
+    assert np.allclose(m[2], [10.0 / 2047, -1.0 + 2.0 / 1023, 2.0 + 2.0 / 2047], atol=1e-6)
+    # scales: exp(lerp(min_scale, max_scale, code))
+    assert np.allclose(s[0], np.exp([-4.0, -3.0, 1.0]), rtol=1e-6)
+    assert np.allclose(s[1], np.exp([-2.0, -3.0, 0.0]), rtol=1e-6)
+    assert np.allclose(s[2], np.exp([-4.0 + 2.0 * 1024 / 2047, -3.0, 1024 / 2047]), rtol=1e-6)
+    # rotations (w, x, y, z): three components stored as (code/1023 - 0.5) sqrt2, the dropped one = sqrt(1 - sum^2) >= 0
+    e = (h / 1023 - 0.5) * np.sqrt(2.0)
+    big = np.sqrt(1 - 3 * e * e)
+    assert np.allclose(q[0], [big, e, e, e], atol=1e-6)
+    r2 = np.sqrt(0.5)
+    assert np.allclose(q[1], [r2, np.sqrt(1 - 0.5 - 2 * e * e), e, e], atol=1e-6)               # largest = x
+    assert np.allclose(q[2], [-r2, r2, e, np.sqrt(1 - 1.0 - e * e if 1 - 1.0 - e * e > 0 else 0.0)], atol=1e-3)   # largest = z (~0 here)
+    assert np.allclose(np.linalg.norm(q[:2], axis=1), 1.0, atol=1e-6)
+    # colour -> SH DC = (lerp(min, max, code/255) - 0.5) / C0; alpha -> opacity (already activated)
+    C0 = 0.28209479177387814
+    assert np.allclose(sh[0, 0], [(1.0 - 0.5) / C0, (0.0 - 0.5) / C0, (0.0 - 0.5) / C0], atol=1e-5)
+    assert np.allclose(sh[1, 0], [(128 / 255 - 0.5) / C0] * 3, atol=1e-5)
+    assert np.allclose(o, [1.0, 51 / 255, 0.0], atol=1e-7)
+    # higher SH bands: bytes, channel-major in the file (15 R, 15 G, 15 B), value = ((byte + 0.5) / 256 - 0.5) * 8
+    for v in range(3):
+        for k in range(15):
+            for c in range(3):
+                assert abs(sh[v, 1 + k, c] - (((sh_bytes[v][c * 15 + k] + 0.5) / 256.0 - 0.5) * 8.0)) < 1e-6
 
 
 def test_sweep_input_and_cameras(tmp_path):
