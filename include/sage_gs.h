@@ -168,6 +168,15 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
                      const sgs_config* cfg, int tile_row_begin, int tile_row_end, float* out_rgb,
                      sgs_stats* stats, void* hip_stream);
 
+/* As sgs_render_batch, with the frames' outputs `frame_stride` FLOATS apart: frame i is stored as if out_rgb + i *
+ * frame_stride were the address of its pixel (0,0).  This is what a rank of a tile-row-sharded sweep uses — every
+ * frame's band of rows goes to its own slab (sage_gs/dist.py) — and what keeps the host out of the way there: the whole
+ * batch is one call, and the library forks its internal streams, clears and collects the frames' status words and waits
+ * for completion once per batch instead of once per frame. */
+int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
+                             const sgs_config* cfg, int tile_row_begin, int tile_row_end, float* out_rgb,
+                             int64_t frame_stride, sgs_stats* stats, void* hip_stream);
+
 /* Completes frames issued with SGS_FLAG_ASYNC: waits for the stream of the MOST RECENT frame and for every
  * pipelined frame in flight, checks the status of every frame issued since the previous synchronisation and
  * reports the statistics of the most recent one.  A caller that spreads asynchronous, non-pipelined frames over

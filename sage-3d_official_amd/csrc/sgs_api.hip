@@ -76,7 +76,7 @@ struct Lane {
     bool busy = false;                       // has pipelined work that no synchronisation has collected yet
 };
 
-constexpr int kMaxLanes = 4;
+constexpr int kMaxLanes = 8;
 
 struct sgs_ctx {
     int device = 0;
@@ -292,9 +292,13 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
 
 // Enqueue one frame; its status lands in ring slot `slot`.  Ordinary frames run on `stream` with lane 0's
 // buffers; a pipelined frame runs on the next lane's own stream, forked from `stream`.
+// in_batch (sgs_render_batch*): the caller forks the lanes from its stream, zeroes and collects the status slots and
+// waits for the lanes ONCE per batch, so a frame costs its five launches and nothing else on the host (the runtime
+// calls around them — event record/wait, memset, status copy, event record — were ~40 us per frame: the whole time a
+// light band of tile rows takes on the GPU).
 int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg,
                   int row_begin, int row_end, float* out_rgb, int slot, hipStream_t caller_stream, bool timed,
-                  float* out_aux = nullptr, bool pipelined = false) {
+                  float* out_aux = nullptr, bool pipelined = false, bool in_batch = false) {
     int rc;
     const int lane = pipelined ? ctx->next_lane : 0;
     Lane& L = ctx->lanes[lane];
@@ -319,16 +323,16 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     }
     fill_params(P, ctx, L, scene, cam, cfg, row_begin, row_end);
     if ((P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, L)) != SGS_OK) return rc;
-    if (pipelined) {
+    if (pipelined && !in_batch) {
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
         SGS_HIP(ctx, hipEventRecord(L.fork, caller_stream));
         SGS_HIP(ctx, hipStreamWaitEvent(L.stream, L.fork, 0));
-    } else if (L.busy) {
+    } else if (!pipelined && L.busy) {
         // lane 0's buffers may still be in use by a pipelined frame
         SGS_HIP(ctx, hipStreamWaitEvent(caller_stream, L.done, 0));
     }
     FrameStatus* st = ctx->d_status + slot;
-    SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
+    if (!in_batch) SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
     hipEvent_t* ev = nullptr;
     if (timed) {
         if (!ctx->ev) {
@@ -376,10 +380,12 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
-    SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
-    if (pipelined) {
-        SGS_HIP(ctx, hipEventRecord(L.done, L.stream));
-        L.busy = true;
+    if (!in_batch) {
+        SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
+        if (pipelined) {
+            SGS_HIP(ctx, hipEventRecord(L.done, L.stream));
+            L.busy = true;
+        }
     }
 
     ctx->last_slot = slot; ctx->last_timed = timed; ctx->last_stream = caller_stream; ctx->last_lane = lane;
@@ -716,9 +722,9 @@ int sgs_render(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
     return sgs_render_rgbd(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, nullptr, stats, hip_stream);
 }
 
-int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
-                     const sgs_config* cfg_in, int tile_row_begin, int tile_row_end, float* out_rgb,
-                     sgs_stats* stats, void* hip_stream) {
+int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
+                             const sgs_config* cfg_in, int tile_row_begin, int tile_row_end, float* out_rgb,
+                             int64_t frame_stride, sgs_stats* stats, void* hip_stream) {
     if (!ctx) return SGS_ERR_INVALID;
     if (n_cams < 0 || (n_cams > 0 && !cams)) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad camera array");
     sgs_config cfg;
@@ -729,19 +735,33 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
     ctx->last_retries = 0;
     int rc;
     if (ctx->pending_count > 0 && (rc = sgs_frame_sync(ctx, nullptr)) != SGS_OK) return rc;
+    const bool lanes = ctx->n_lanes > 1 && !(cfg.flags & SGS_FLAG_FULL_SORT);
     for (int c0 = 0; c0 < n_cams; c0 += kStatusRing) {
         const int cn = std::min(kStatusRing, n_cams - c0);
         int64_t px[kStatusRing]; int tl[kStatusRing];
+        // once per chunk of frames, not once per frame: zero the status slots, fork the lanes from the caller's stream
+        SGS_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(FrameStatus) * (size_t)cn, stream));
+        if (lanes) {
+            if ((rc = ensure_lane_stream(ctx, ctx->lanes[0])) != SGS_OK) return rc;
+            SGS_HIP(ctx, hipEventRecord(ctx->lanes[0].fork, stream));
+            for (int l = 0; l < ctx->n_lanes; ++l) {
+                if ((rc = ensure_lane_stream(ctx, ctx->lanes[l])) != SGS_OK) return rc;
+                SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lanes[0].fork, 0));
+            }
+        }
         for (int i = 0; i < cn; ++i) {
             int rb = tile_row_begin, re = tile_row_end;
-            float* out = out_rgb + (size_t)(c0 + i) * cams[c0 + i].width * cams[c0 + i].height * 3;
+            float* out = out_rgb + (size_t)(c0 + i) * (size_t)frame_stride;
             if ((rc = validate(ctx, scene, &cams[c0 + i], &cfg, rb, re, out)) != SGS_OK) return rc;
-            if ((rc = enqueue_frame(ctx, scene, &cams[c0 + i], cfg, rb, re, out, i, stream, false, nullptr,
-                                    ctx->n_lanes > 1)) != SGS_OK) return rc;
+            if ((rc = enqueue_frame(ctx, scene, &cams[c0 + i], cfg, rb, re, out, i, stream, false, nullptr, lanes, true)) != SGS_OK)
+                return rc;
             px[i] = ctx->last_pixels; tl[i] = ctx->last_tiles;
         }
+        // ... wait for the lanes and fetch every frame's status in one copy
+        if (lanes) for (int l = 0; l < ctx->n_lanes; ++l) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
         SGS_HIP(ctx, hipStreamSynchronize(stream));
-        if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;
+        if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;           // (frames issued outside this call)
+        SGS_HIP(ctx, hipMemcpy(ctx->h_status, ctx->d_status, sizeof(FrameStatus) * (size_t)cn, hipMemcpyDeviceToHost));
         // The redo below goes through sgs_render, which takes ring slots of its own (from next_slot, two or more per
         // grow-and-retry) — i.e. slots of frames of THIS chunk that have not been looked at yet.  So every frame's
         // verdict and statistics are taken out of the ring before anything is re-rendered.
@@ -755,8 +775,8 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
             if (over[i]) {
                 // redo this one frame synchronously (grows the queues), then carry on
                 int rb = tile_row_begin, re = tile_row_end;
-                float* out = out_rgb + (size_t)(c0 + i) * cams[c0 + i].width * cams[c0 + i].height * 3;
-                sgs_config c1 = cfg; c1.flags &= ~(uint32_t)SGS_FLAG_ASYNC;
+                float* out = out_rgb + (size_t)(c0 + i) * (size_t)frame_stride;
+                sgs_config c1 = cfg; c1.flags &= ~(uint32_t)(SGS_FLAG_ASYNC | SGS_FLAG_PIPELINED);
                 if ((rc = sgs_render(ctx, scene, &cams[c0 + i], &c1, rb, re, out, stats ? stats + c0 + i : nullptr, hip_stream)) != SGS_OK)
                     return rc;
             }
@@ -764,6 +784,18 @@ int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam
         ctx->next_slot = 0; ctx->pending_begin = 0; ctx->pending_count = 0;
     }
     return SGS_OK;
+}
+
+int sgs_render_batch(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int n_cams,
+                     const sgs_config* cfg_in, int tile_row_begin, int tile_row_end, float* out_rgb,
+                     sgs_stats* stats, void* hip_stream) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (n_cams < 0 || (n_cams > 0 && !cams)) SGS_FAIL(ctx, SGS_ERR_INVALID, "bad camera array");
+    for (int i = 1; i < n_cams; ++i)
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height)
+            SGS_FAIL(ctx, SGS_ERR_INVALID, "the cameras of a batch must share a resolution");
+    const int64_t stride = n_cams > 0 ? (int64_t)cams[0].width * cams[0].height * 3 : 0;
+    return sgs_render_batch_strided(ctx, scene, cams, n_cams, cfg_in, tile_row_begin, tile_row_end, out_rgb, stride, stats, hip_stream);
 }
 
 int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset) {

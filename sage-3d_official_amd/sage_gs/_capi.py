@@ -25,7 +25,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 # every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
 EXPORTS = ("sgs_version", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
            "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_free", "sgs_render",
-           "sgs_render_rgbd", "sgs_render_batch", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
+           "sgs_render_rgbd", "sgs_render_batch", "sgs_render_batch_strided", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
 
 
 class SgsError(RuntimeError):
@@ -91,6 +91,8 @@ class Lib:
                                         C.POINTER(SgsStats), vp]
         lib.sgs_render_batch.argtypes = [vp, vp, C.POINTER(SgsCamera), i32, C.POINTER(SgsConfig), i32,
                                          i32, vp, C.POINTER(SgsStats), vp]
+        lib.sgs_render_batch_strided.argtypes = [vp, vp, C.POINTER(SgsCamera), i32, C.POINTER(SgsConfig), i32,
+                                                 i32, vp, i64, C.POINTER(SgsStats), vp]
         lib.sgs_frame_sync.argtypes = [vp, C.POINTER(SgsStats)]
         lib.sgs_row_records.argtypes = [vp, vp, i32, i32]
         lib.sgs_pack_rgba8.argtypes = [vp, vp, vp, i32, i32, vp]

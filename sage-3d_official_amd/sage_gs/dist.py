@@ -230,6 +230,15 @@ class FrameGather:
             return {"out": self._frames[b], "tile_rows": self.band}
         return {"out_band": self._slab[b], "tile_rows": self.band}
 
+    def batch_target(self) -> dict:
+        """Keyword arguments for Renderer.render_batch: this rank's rows of every frame of the batch, in place."""
+        if self.interleave and self.world > 1:
+            buf = self._compact[self.rank] if self.rank == self.dst else self._slab
+            return {"out_bands": buf, "interleave": (self.world, self.rank)}
+        if self.rank == self.dst:
+            return {"out": self._frames, "tile_rows": self.band}
+        return {"out_bands": self._slab, "tile_rows": self.band}
+
     @property
     def render_rows(self) -> dict:
         """The row selection alone (for callers that manage their own output buffers)."""
@@ -410,9 +419,13 @@ class ShardedRenderer:
             g.set_bands(self.bands)
         r0, r1 = g.band
         if r1 > r0:
-            for b, cam in enumerate(cameras):
-                self.r.render(cam, scene, config=config, sync=False, pipelined=True, timing=timing, **g.render_target(b))
-            self.last_stats = self.r.sync()        # bands complete (all lanes) before the exchange reads them
+            if timing:                             # per-stage events: one call per frame
+                for b, cam in enumerate(cameras):
+                    self.r.render(cam, scene, config=config, sync=False, pipelined=True, timing=True, **g.render_target(b))
+                self.last_stats = self.r.sync()    # bands complete (all lanes) before the exchange reads them
+            else:                                  # ONE call into the library for the whole batch (complete on return)
+                _, st = self.r.render_batch(cameras, scene, config=config, want_stats=True, **g.batch_target())
+                self.last_stats = st[-1]
         if self.balance:
             self._post_costs(n)
         self._pending[k] = g.exchange(n, async_op=True)

@@ -269,8 +269,15 @@ class Renderer:
         return out
 
     def render_batch(self, cameras: Sequence[Camera], gaussians, *, config: Optional[RenderConfig] = None,
-                     out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False):
-        """B frames of one scene back to back with a single synchronisation (camera-sweep batch)."""
+                     out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False,
+                     out_bands: Optional[torch.Tensor] = None, interleave=None):
+        """B frames of one scene in ONE call into the library (camera-sweep batch): the frames go through the pipelined
+        lanes, and the per-frame host work (stream fork, status clear / copy, completion) is paid once per batch.
+
+        out: [B,H,W,3] (allocated when omitted).  tile_rows=(r0,r1) renders only that band of every frame.  With
+        `out_bands` — a [B, >= band rows, W, 3] tensor whose frames may be strided views, e.g. the slabs of a sharded
+        sweep — only the band is stored, at the top of each slab.  interleave=(stride, phase) with out_bands renders the
+        owned tile rows of every frame into compact images (see render())."""
         scene = self._scene_of(gaussians)
         b = len(cameras)
         if b == 0:
@@ -278,17 +285,48 @@ class Renderer:
         h, w = cameras[0].height, cameras[0].width
         if any(c.height != h or c.width != w for c in cameras):
             raise ValueError("all cameras of a batch must share a resolution")
-        if out is None:
-            out = torch.zeros((b, h, w, 3), dtype=torch.float32, device=self.device)
-        arr = (_capi.SgsCamera * b)(*[self._c_camera(c, scene) for c in cameras])
-        stats = (_capi.SgsStats * b)() if want_stats else None
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
         cfg = self._c_config(config)
-        self._lib.check(self._lib.sgs_render_batch(self._ctx, scene.handle, arr, b, C.byref(cfg), r0, r1,
-                                                   out.data_ptr(), stats, self._stream()), self._ctx)
+        if out_bands is not None:
+            if out is not None:
+                raise ValueError("give out or out_bands, not both")
+            stride, phase = (1, 0) if interleave is None else (int(interleave[0]), int(interleave[1]))
+            if stride > 1:
+                if not 0 <= phase < stride:
+                    raise ValueError(f"interleave phase {phase} outside [0, {stride})")
+                owned = len(range(phase, cameras[0].tile_rows, stride))
+                need, y0 = 16 * (owned if r1 < 0 else min(r1, owned)), 0
+                cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
+            else:
+                if tile_rows is None:
+                    raise ValueError("out_bands needs tile_rows (or interleave)")
+                if r1 < 0 or r1 > cameras[0].tile_rows:
+                    r1 = cameras[0].tile_rows
+                if not 0 <= r0 <= r1:
+                    raise ValueError(f"tile_rows {tile_rows} is not a band of the frame's {cameras[0].tile_rows} tile rows")
+                y0 = r0 * 16
+                need = min(r1 * 16, h) - y0
+            t = out_bands
+            if (t.device != self.device or t.dtype != torch.float32 or t.dim() != 4 or t.shape[0] < b or t.shape[1] < need
+                    or tuple(t.shape[2:]) != (w, 3) or t.stride(3) != 1 or t.stride(2) != 3 or t.stride(1) != 3 * w):
+                raise ValueError("out_bands must be float32 [>= B, >= band rows, W, 3] on the device with contiguous frames")
+            ptr, frame_stride, ret = t.data_ptr() - y0 * w * 3 * 4, int(t.stride(0)), t
+        else:
+            if interleave is not None:
+                raise ValueError("interleave renders into out_bands only")
+            if out is None:
+                out = torch.zeros((b, h, w, 3), dtype=torch.float32, device=self.device)
+            elif (out.device != self.device or out.dtype != torch.float32 or out.dim() != 4 or out.shape[0] < b
+                  or tuple(out.shape[1:]) != (h, w, 3) or not out[0].is_contiguous()):
+                raise ValueError("out must be float32 [>= B, H, W, 3] on the renderer's device")
+            ptr, frame_stride, ret = out.data_ptr(), int(out.stride(0)), out
+        arr = (_capi.SgsCamera * b)(*[self._c_camera(c, scene) for c in cameras])
+        stats = (_capi.SgsStats * b)() if want_stats else None
+        self._lib.check(self._lib.sgs_render_batch_strided(self._ctx, scene.handle, arr, b, C.byref(cfg), r0, r1,
+                                                           ptr, frame_stride, stats, self._stream()), self._ctx)
         if want_stats:
-            return out, [s.as_dict() for s in stats]
-        return out
+            return ret, [s.as_dict() for s in stats]
+        return ret
 
     def pack_rgba8(self, rgb: torch.Tensor, tonemap: Optional[str] = None) -> torch.Tensor:
         """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns.

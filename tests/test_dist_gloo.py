@@ -234,6 +234,16 @@ class _RowCopyRenderer:
         self.calls.append((cam, r0, r1))
         return out if out is not None else out_band
 
+    def render_batch(self, cameras, scene, *, config=None, out=None, tile_rows=None, want_stats=False, out_bands=None,
+                     interleave=None):
+        for b, cam in enumerate(cameras):
+            if out is not None:
+                self.render(cam, scene, out=out[b], tile_rows=tile_rows)
+            else:
+                self.render(cam, scene, out_band=out_bands[b], tile_rows=tile_rows, interleave=interleave)
+        ret = out if out is not None else out_bands
+        return (ret, [{"ms": {}, "ms_total": 0.0, "n_visible": 1}] * len(cameras)) if want_stats else ret
+
     def sync(self):
         return {"ms": {}, "ms_total": 0.0}
 

@@ -155,6 +155,14 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
     lib.check(lib.sgs_render_batch(ctx, drv.scene, arr, len(cams), C.byref(cfg2), 0, -1, batch.ctypes.data, stats, None), ctx)
     for i in range(len(cams)):
         assert (batch[i] == seq[i]).all() and stats[i].d_total > 0
+    # frames a stride apart, one band of tile rows each, stored at the top of a slab (what a rank of a sharded sweep does):
+    # frame i's "pixel (0,0)" is slab i's start minus the rows above the band
+    r0, r1, slab_rows = 1, 3, 48                                     # tile rows [1,3) = pixel rows 16..47 of the 80
+    slabs = np.full((len(cams), slab_rows, 96, 3), -1.0, np.float32)
+    base = slabs.ctypes.data - r0 * 16 * 96 * 3 * 4
+    lib.check(lib.sgs_render_batch_strided(ctx, drv.scene, arr, len(cams), C.byref(cfg2), r0, r1, base, slab_rows * 96 * 3, None, None), ctx)
+    for i in range(len(cams)):
+        assert (slabs[i, :32] == seq[i][16:48]).all() and (slabs[i, 32:] == -1.0).all()
 
 
 def test_batch_on_a_fresh_context_survives_overflowing_frames():
