@@ -54,6 +54,7 @@ struct Lane {
     unsigned long long* bigmask = nullptr;   //   ... and which of those went to the big-rect list
     unsigned* big_list = nullptr;
     uint4* binrec = nullptr;                 // per slot: depth bits, rect01, rect23 (dense copy for the binning kernels)
+    unsigned* live_list = nullptr;           // chunks that passed the per-chunk bounds this frame (k_chunk_cull)
     // per-tile scratch
     int tile_cap = 0;
     unsigned *tile_count = nullptr, *tile_offset = nullptr;
@@ -82,7 +83,9 @@ struct sgs_ctx {
     int device = 0;
     std::string err;
     Lane lanes[kMaxLanes];
-    int n_lanes = 3, next_lane = 0;          // SGS_LANES=1..4
+    int n_lanes = 3, next_lane = 0;          // SGS_LANES: lanes that SGS_FLAG_PIPELINED single frames rotate over
+    int group = 4, group_lanes = 2;          // SGS_GROUP x SGS_GROUP_LANES <= kMaxLanes: sgs_render_batch* issues `group` frames per
+                                             // set of launches (blockIdx.y = frame), groups rotating over `group_lanes` streams
     int last_lane = 0;
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
     int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
@@ -149,6 +152,7 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     if ((rc = grow(ctx, L.vismask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.bigmask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.binrec, (size_t)cap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.live_list, (size_t)chunks)) != SGS_OK) return rc;
     if (!L.big_list && (rc = grow(ctx, L.big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS * 2)) != SGS_OK) return rc;    // list lengths | XCD ids
     if ((rc = grow(ctx, L.bin_prof, (size_t)SGS_BIN_BLOCKS * 8)) != SGS_OK) return rc;
@@ -174,6 +178,9 @@ int ensure_tiles(sgs_ctx* ctx, Lane& L, int tiles) {
     if ((rc = grow(ctx, L.tile_order, (size_t)tiles)) != SGS_OK) return rc;
     // k_bin_emit zeroes every count k_tile_scan has consumed, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
+    // (hipMemset of device memory runs on the NULL stream and may return before it has run; the frames use non-blocking
+    //  streams that do not order with it — an unfinished clear would land in the middle of a frame's counting)
+    SGS_HIP(ctx, hipStreamSynchronize(nullptr));
     L.tile_cap = tiles;
     return SGS_OK;
 }
@@ -288,51 +295,70 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.n_windows = (row_end - row_begin + P.win_rows - 1) / P.win_rows;
     P.rec_capacity = L.rec_cap;
     P.flags = cfg.flags | SGS_FLAG_STATS;
+    {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
+        const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
+        P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
+        const double c0 = 1.001 * (3.0 * std::sqrt(2.0 * (double)P.dilation + 0.3163) + 1.0) + 0.5 + 1.0;      // + one pixel of slack
+        P.cull_off[0] = (double)P.cx - 0.5 + c0;                                     // px + rb >= 0
+        P.cull_off[1] = (double)(SGS_TILE * P.gx) - (double)P.cx + 0.5 + c0;         // px - rb <  16 gx
+        P.cull_off[2] = (double)P.cy - 0.5 - (double)P.cull_y0 + c0;                 // py + rb >= cull_y0
+        P.cull_off[3] = (double)P.cull_y1 - (double)P.cy + 0.5 + c0;                 // py - rb <  cull_y1
+        const double f[4] = {(double)P.fx, (double)P.fx, (double)P.fy, (double)P.fy};
+        for (int k = 0; k < 4; ++k) P.cull_nrm[k] = std::sqrt(f[k] * f[k] + P.cull_off[k] * P.cull_off[k]);
+    }
 }
 
-// Enqueue one frame; its status lands in ring slot `slot`.  Ordinary frames run on `stream` with lane 0's
-// buffers; a pipelined frame runs on the next lane's own stream, forked from `stream`.
-// in_batch (sgs_render_batch*): the caller forks the lanes from its stream, zeroes and collects the status slots and
-// waits for the lanes ONCE per batch, so a frame costs its five launches and nothing else on the host (the runtime
-// calls around them — event record/wait, memset, status copy, event record — were ~40 us per frame: the whole time a
-// light band of tile rows takes on the GPU).
-int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg,
-                  int row_begin, int row_end, float* out_rgb, int slot, hipStream_t caller_stream, bool timed,
-                  float* out_aux = nullptr, bool pipelined = false, bool in_batch = false) {
+// Enqueue a GROUP of nf <= SGS_MAX_GROUP frames of one scene — same resolution, same tile rows, one camera each — as
+// ONE set of five launches (blockIdx.y = frame; sgs_common.h FrameGroup).  Frame f uses the intermediates of lane
+// set0 + f and status slot slot0 + f; the launches go to `stream`.
+//   * ordinary frames: nf = 1, set0 = 0, stream = the caller's;
+//   * SGS_FLAG_PIPELINED frames: nf = 1, the next lane and its own stream, forked from the caller's stream;
+//   * sgs_render_batch*: groups of ctx->group frames rotating over ctx->group_lanes streams (in_batch: the caller forks
+//     the streams, zeroes and collects the status slots and waits ONCE per batch — the per-frame runtime calls around the
+//     launches were ~40 us, as long as a light band of tile rows takes on the GPU).
+int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
+                  int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
+                  float* out_aux, bool pipelined, bool in_batch, int set0) {
     int rc;
-    const int lane = pipelined ? ctx->next_lane : 0;
-    Lane& L = ctx->lanes[lane];
+    const sgs_camera* cam = cams;                 // resolution / rows are the group's
+    Lane& L = ctx->lanes[set0];                   // the group's stream is its first lane's
     hipStream_t stream = caller_stream;
     if (pipelined) {
-        ctx->next_lane = (ctx->next_lane + 1) % ctx->n_lanes;
         if ((rc = ensure_lane_stream(ctx, L)) != SGS_OK) return rc;
         stream = L.stream;
     }
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE, gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
-    FrameParams P;
-    // a pipelined frame sizes the intermediates of ALL lanes (once: the ensure_* are no-ops afterwards), so that no
-    // later frame of the sweep stops to allocate
-    for (int l = pipelined ? 0 : lane; l < (pipelined ? ctx->n_lanes : lane + 1); ++l) {
-        Lane& A = ctx->lanes[l];
+    FrameGroup G;
+    memset(&G, 0, sizeof G);
+    G.geom = scene->geom; G.shq = scene->shq; G.cbound = scene->cbound; G.row_acc = ctx->row_acc;
+    for (int f = 0; f < nf; ++f) {
+        Lane& A = ctx->lanes[set0 + f];
         if ((rc = ensure_splats(ctx, A, scene->n)) != SGS_OK) return rc;
         if ((rc = ensure_tiles(ctx, A, gx * gy)) != SGS_OK) return rc;
         if ((rc = ensure_records(ctx, A)) != SGS_OK) return rc;
-        fill_params(P, ctx, A, scene, cam, cfg, row_begin, row_end);
-        if ((rc = ensure_blk_list(ctx, A, std::max(1, P.n_windows), P.win_tiles)) != SGS_OK) return rc;
-        if (pipelined && (rc = ensure_lane_stream(ctx, A)) != SGS_OK) return rc;
+        FrameSlot& S = G.s[f];
+        fill_params(S.P, ctx, A, scene, &cams[f], cfg, row_begin, row_end);
+        if ((rc = ensure_blk_list(ctx, A, std::max(1, S.P.n_windows), S.P.win_tiles)) != SGS_OK) return rc;
+        if ((S.P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, A)) != SGS_OK) return rc;
+        S.splats = A.splats; S.vismask = A.vismask; S.bigmask = A.bigmask; S.big_list = A.big_list; S.binrec = A.binrec;
+        S.live_list = A.live_list;
+        S.tile_count = A.tile_count; S.tile_offset = A.tile_offset; S.tile_order = A.tile_order;
+        S.blk_list = A.blk_list; S.blk_len = A.blk_len;
+        S.rec = A.rec; S.alt = A.alt; S.part = A.part; S.sorted_out = A.sorted_out;
+        S.tile_prof = A.tile_prof; S.bin_prof = A.bin_prof;
+        S.out_rgb = outs[f]; S.out_aux = out_aux; S.st = ctx->d_status + slot0 + f;
     }
-    fill_params(P, ctx, L, scene, cam, cfg, row_begin, row_end);
-    if ((P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, L)) != SGS_OK) return rc;
+    const FrameParams& P = G.s[0].P;
     if (pipelined && !in_batch) {
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
         SGS_HIP(ctx, hipEventRecord(L.fork, caller_stream));
         SGS_HIP(ctx, hipStreamWaitEvent(L.stream, L.fork, 0));
-    } else if (!pipelined && L.busy) {
-        // lane 0's buffers may still be in use by a pipelined frame
-        SGS_HIP(ctx, hipStreamWaitEvent(caller_stream, L.done, 0));
+    } else if (!pipelined) {
+        for (int f = 0; f < nf; ++f)               // these lanes' buffers may still be in use by a pipelined frame
+            if (ctx->lanes[set0 + f].busy) SGS_HIP(ctx, hipStreamWaitEvent(caller_stream, ctx->lanes[set0 + f].done, 0));
     }
-    FrameStatus* st = ctx->d_status + slot;
-    if (!in_batch) SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus), stream));
+    FrameStatus* st = ctx->d_status + slot0;
+    if (!in_batch) SGS_HIP(ctx, hipMemsetAsync(st, 0, sizeof(FrameStatus) * (size_t)nf, stream));
     hipEvent_t* ev = nullptr;
     if (timed) {
         if (!ctx->ev) {
@@ -341,53 +367,51 @@ int enqueue_frame(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, c
             for (int i = 0; i < kStatusRing; ++i)
                 for (int j = 0; j <= SGS_NUM_STAGES; ++j) SGS_HIP(ctx, hipEventCreate(&ctx->ev[i][j]));
         }
-        ev = ctx->ev[slot];
+        ev = ctx->ev[slot0];
     }
-    ctx->slot_timed[slot] = timed;
+    for (int f = 0; f < nf; ++f) ctx->slot_timed[slot0 + f] = timed && f == 0;
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
+    const unsigned F = (unsigned)nf;
     const unsigned bin_blocks = (unsigned)std::min<int64_t>(ctx->bin_grid, P.n_ranges);
-    if (P.n_chunks > 0)
-        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4)), dim3(256), 0, stream, P,
-                           scene->geom, scene->shq, L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, scene->cbound, st);
+    if (P.n_chunks > 0) {
+        hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), F),
+                           dim3(SGS_CULL_THREADS), 0, stream, G);
+        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4), F), dim3(256), 0, stream, G);
+    }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
-                           L.vismask, L.bigmask, L.big_list, L.tile_count, L.blk_list, L.blk_len, st,
-                           L.bin_prof);
+        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks * (unsigned)P.n_windows, F), dim3(SGS_BIN_THREADS),
+                           (size_t)P.win_tiles * sizeof(unsigned), stream, G);
     // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
     const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
-    hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups), dim3(SGS_SCAN_THREADS), 0, stream, P, L.tile_count,
-                       L.tile_offset, L.tile_order, ctx->row_acc, st);
+    hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups, F), dim3(SGS_SCAN_THREADS), 0, stream, G);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks * (unsigned)P.n_windows), dim3(SGS_BIN_THREADS), (size_t)P.win_tiles * sizeof(unsigned), stream, P, L.binrec,
-                           L.vismask, L.bigmask, L.big_list, L.tile_offset, L.blk_list, L.blk_len,
-                           L.rec, L.tile_count, st);
+        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks * (unsigned)P.n_windows, F), dim3(SGS_BIN_THREADS),
+                           (size_t)P.win_tiles * sizeof(unsigned), stream, G);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        if (out_aux)
-            hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid), dim3(256), 0, stream, P, L.tile_order,
-                               L.rec, L.alt, L.part, L.sorted_out, L.splats, out_rgb, out_aux, st, L.tile_prof);
-        else
-            hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid), dim3(256), 0, stream, P, L.tile_order,
-                               L.rec, L.alt, L.part, L.sorted_out, L.splats, out_rgb, out_aux, st, L.tile_prof);
+        if (out_aux) hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid, F), dim3(256), 0, stream, G);
+        else hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid, F), dim3(256), 0, stream, G);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());
     if (!in_batch) {
-        SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot, st, sizeof(FrameStatus), hipMemcpyDeviceToHost, stream));
+        SGS_HIP(ctx, hipMemcpyAsync(ctx->h_status + slot0, st, sizeof(FrameStatus) * (size_t)nf, hipMemcpyDeviceToHost, stream));
         if (pipelined) {
             SGS_HIP(ctx, hipEventRecord(L.done, L.stream));
             L.busy = true;
         }
     }
 
+    const int slot = slot0 + nf - 1, lane = set0 + nf - 1;         // "the last frame" = the group's last
+    cam = &cams[nf - 1];
     ctx->last_slot = slot; ctx->last_timed = timed; ctx->last_stream = caller_stream; ctx->last_lane = lane;
     ctx->last_n = scene->n; ctx->last_tiles = (int)ntiles; ctx->last_sh_rows = scene->sh_rows;
     ctx->last_T = gx * gy;
@@ -478,10 +502,14 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_status), sizeof(FrameStatus) * kStatusRing, 0)) != hipSuccess) return fail("hipHostMalloc", e);
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->row_acc), sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMemset", e);
+    if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("hipStreamSynchronize", e);
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
     if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
+    if (const char* env = getenv("SGS_GROUP")) ctx->group = std::min(std::min(kMaxLanes, SGS_MAX_GROUP), std::max(1, atoi(env)));
+    if (const char* env = getenv("SGS_GROUP_LANES")) ctx->group_lanes = std::max(1, atoi(env));
+    ctx->group_lanes = std::max(1, std::min(ctx->group_lanes, kMaxLanes / ctx->group));
     if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
         const long long v = atoll(env);
         if (v > 0) ctx->rec_cap_wanted = v;
@@ -495,7 +523,7 @@ int sgs_destroy(sgs_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (Lane& L : ctx->lanes) {
-        void* bufs[] = {L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, L.tile_count, L.tile_offset, L.tile_order,
+        void* bufs[] = {L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, L.live_list, L.tile_count, L.tile_offset, L.tile_order,
                         L.tile_prof, L.bin_prof, L.blk_list, L.blk_len, L.rec, L.alt, L.part, L.sorted_out};
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -702,8 +730,11 @@ int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
         ctx->pending_count++;
         const bool pipelined = (cfg.flags & SGS_FLAG_PIPELINED) && (cfg.flags & SGS_FLAG_ASYNC) && ctx->n_lanes > 1 &&
                                !(cfg.flags & SGS_FLAG_FULL_SORT);
-        if ((rc = enqueue_frame(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, timed, out_aux,
-                                pipelined)) != SGS_OK)
+        int lane = 0;
+        if (pipelined) { lane = ctx->next_lane; ctx->next_lane = (ctx->next_lane + 1) % ctx->n_lanes; }
+        float* outs[1] = {out_rgb};
+        if ((rc = enqueue_group(ctx, scene, cam, 1, cfg, tile_row_begin, tile_row_end, outs, slot, stream, timed, out_aux,
+                                pipelined, false, lane)) != SGS_OK)
             return rc;
         if (cfg.flags & SGS_FLAG_ASYNC) return SGS_OK;
         rc = sgs_frame_sync(ctx, stats);
@@ -735,30 +766,39 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
     ctx->last_retries = 0;
     int rc;
     if (ctx->pending_count > 0 && (rc = sgs_frame_sync(ctx, nullptr)) != SGS_OK) return rc;
-    const bool lanes = ctx->n_lanes > 1 && !(cfg.flags & SGS_FLAG_FULL_SORT);
+    const bool lanes = !(cfg.flags & SGS_FLAG_FULL_SORT);           // own streams (the FULL_SORT test hook stays on the caller's)
+    const int F = ctx->group, GL = lanes ? ctx->group_lanes : 1;
     for (int c0 = 0; c0 < n_cams; c0 += kStatusRing) {
         const int cn = std::min(kStatusRing, n_cams - c0);
         int64_t px[kStatusRing]; int tl[kStatusRing];
-        // once per chunk of frames, not once per frame: zero the status slots, fork the lanes from the caller's stream
+        // once per chunk of frames, not once per frame: zero the status slots, fork the group streams from the caller's
         SGS_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(FrameStatus) * (size_t)cn, stream));
         if (lanes) {
             if ((rc = ensure_lane_stream(ctx, ctx->lanes[0])) != SGS_OK) return rc;
             SGS_HIP(ctx, hipEventRecord(ctx->lanes[0].fork, stream));
-            for (int l = 0; l < ctx->n_lanes; ++l) {
-                if ((rc = ensure_lane_stream(ctx, ctx->lanes[l])) != SGS_OK) return rc;
-                SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[l].stream, ctx->lanes[0].fork, 0));
+            for (int gl = 0; gl < GL; ++gl) {
+                if ((rc = ensure_lane_stream(ctx, ctx->lanes[gl * F])) != SGS_OK) return rc;
+                SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[gl * F].stream, ctx->lanes[0].fork, 0));
             }
         }
-        for (int i = 0; i < cn; ++i) {
+        for (int i = 0, g = 0; i < cn; i += F, ++g) {
+            const int nf = std::min(F, cn - i);
+            float* outs[SGS_MAX_GROUP];
             int rb = tile_row_begin, re = tile_row_end;
-            float* out = out_rgb + (size_t)(c0 + i) * (size_t)frame_stride;
-            if ((rc = validate(ctx, scene, &cams[c0 + i], &cfg, rb, re, out)) != SGS_OK) return rc;
-            if ((rc = enqueue_frame(ctx, scene, &cams[c0 + i], cfg, rb, re, out, i, stream, false, nullptr, lanes, true)) != SGS_OK)
+            for (int f = 0; f < nf; ++f) {
+                rb = tile_row_begin; re = tile_row_end;
+                outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
+                if ((rc = validate(ctx, scene, &cams[c0 + i + f], &cfg, rb, re, outs[f])) != SGS_OK) return rc;
+                if (cams[c0 + i + f].width != cams[c0].width || cams[c0 + i + f].height != cams[c0].height)
+                    SGS_FAIL(ctx, SGS_ERR_INVALID, "the cameras of a batch must share a resolution");
+            }
+            if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
+                                    (g % GL) * F)) != SGS_OK)
                 return rc;
-            px[i] = ctx->last_pixels; tl[i] = ctx->last_tiles;
+            for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
         }
         // ... wait for the lanes and fetch every frame's status in one copy
-        if (lanes) for (int l = 0; l < ctx->n_lanes; ++l) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[l].stream));
+        if (lanes) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl * F].stream));
         SGS_HIP(ctx, hipStreamSynchronize(stream));
         if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;           // (frames issued outside this call)
         SGS_HIP(ctx, hipMemcpy(ctx->h_status, ctx->d_status, sizeof(FrameStatus) * (size_t)cn, hipMemcpyDeviceToHost));
@@ -806,7 +846,10 @@ int sgs_row_records(sgs_ctx* ctx, int64_t* out, int n_rows, int reset) {
     //  be waited for here; the frames the caller has synchronised are complete, and that is the contract)
     static_assert(sizeof(unsigned long long) == sizeof(int64_t), "row counters");
     if (n_rows > 0) SGS_HIP(ctx, hipMemcpy(out, ctx->row_acc, sizeof(int64_t) * (size_t)n_rows, hipMemcpyDeviceToHost));
-    if (reset) SGS_HIP(ctx, hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS));
+    if (reset) {
+        SGS_HIP(ctx, hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS));
+        SGS_HIP(ctx, hipStreamSynchronize(nullptr));      // (see ensure_tiles: the clear must not race later frames)
+    }
     return SGS_OK;
 }
 

@@ -61,6 +61,11 @@ struct FrameParams {
     int32_t row_stride, row_phase;  // interleaved tile rows: local row k of this call is frame row k * row_stride + row_phase
     int32_t cull_y0, cull_y1;       // pixel rows outside [cull_y0, cull_y1) cannot matter to this call (conservative)
     uint32_t pad_;
+    // k_chunk_cull's four planes (left, right, top, bottom), constants of the frame (filled on the host, fill_params):
+    // a chunk is outside when  f u + off tz + nrm R + A s_max < 0  for one of them (chunk_outside, sgs_kernels.h)
+    double cull_A;                  // 1.001 * 3 sqrt(2 (2 + lx^2 + ly^2)) max(fx, fy): radius bound = A s_max / tz + c0
+    double cull_off[4];             // the plane's tz coefficient (image edge, principal point, c0)
+    double cull_nrm[4];             // sqrt(f^2 + off^2)
 };
 
 // Device-resident per-frame status; zeroed by a memset node at frame start, copied to pinned host
@@ -74,7 +79,34 @@ struct FrameStatus {
     unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
     uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
     uint32_t n_big;                 // splats in the big-rect list (may exceed SGS_BIG_CAP; consumers clamp)
-    uint32_t pad_[4];
+    uint32_t n_live;                // chunks that passed the per-chunk bounds (k_chunk_cull): length of the frame's live list
+    uint32_t pad_[3];
+};
+
+struct Splat;
+
+// Frame groups.  A launch of any per-frame kernel covers up to SGS_MAX_GROUP frames of one scene: blockIdx.y selects the
+// frame, and everything that differs between the frames of a group — parameters, intermediates, output — is one FrameSlot
+// of the FrameGroup passed BY VALUE (kernarg segment, scalar-loaded; no device copy to keep alive).  Why: a light frame
+// (a rank's band of tile rows) is five launches of ~25 us each, and an MI355X retires small kernels from several streams
+// barely faster than from one (scripts/launch_floor.hip: 1.6-2x at best) — so a sweep's frames ride the same five
+// launches instead of five launches each.
+#define SGS_MAX_GROUP 8
+struct FrameSlot {
+    FrameParams P;
+    // the frame's intermediates (one "lane" of the context)
+    Splat* splats; unsigned long long* vismask; unsigned long long* bigmask; unsigned* big_list; uint4* binrec;
+    unsigned* live_list;            // chunks (layout order) that passed k_chunk_cull; FrameStatus.n_live of them
+    unsigned* tile_count; unsigned* tile_offset; uint4* tile_order; uint2* blk_list; unsigned* blk_len;
+    unsigned long long* rec; unsigned long long* alt; unsigned long long* part; unsigned* sorted_out;
+    unsigned long long* tile_prof; unsigned long long* bin_prof;
+    // the frame's output and status word
+    float* out_rgb; float* out_aux; FrameStatus* st;
+};
+struct FrameGroup {
+    const float4* geom; const float4* shq; const float4* cbound;      // the scene (shared by the group's frames)
+    unsigned long long* row_acc;                                       // per-row record counters of the context
+    FrameSlot s[SGS_MAX_GROUP];
 };
 
 // One projected Gaussian ("splat"): 64 B, 64-B aligned — exactly one HBM access sector, written once per frame by

@@ -184,26 +184,45 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
     const double tz = (double)P.view[8] * mx + (double)P.view[9] * my + (double)P.view[10] * mz + (double)P.view[11];
     const double Rp = R * 1.0001 + 1.0e-6 * (fabs(tx) + fabs(ty) + fabs(tz));      // the view transform of the centre rounds too
     if (tz + Rp < (double)P.near_z || tz - Rp > (double)P.far_z) return true;
-    const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
-    const double fmx = fmax((double)P.fx, (double)P.fy);
-    const double A = 1.001 * 3.0 * sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * fmx * 1.0001;
-    const double c0 = 1.001 * (3.0 * sqrt(2.0 * (double)P.dilation + 0.3163) + 1.0) + 0.5 + 1.0;      // + one pixel of slack
-    const double d = A * sm;
-    // form(u, f, off) = f u + off tz + d, maximised over the sphere; negative => the condition fails for every member
-    const double zmag = fabs(tz) + Rp;
-#define SGS_PLANE_NEG(U, F, OFF)                                                                         \
-    (((F) * (U) + (OFF) * tz + sqrt((F) * (F) + (OFF) * (OFF)) * Rp + d) <                               \
-     -1.0e-4 * (fabs((F) * (U)) + fabs(OFF) * zmag + sqrt((F) * (F) + (OFF) * (OFF)) * Rp + d))
-    const double ox0 = (double)P.cx - 0.5 + c0;                                     // px + rb >= 0     (weaker than >= 1)
-    const double ox1 = (double)(SGS_TILE_PX * P.gx) - (double)P.cx + 0.5 + c0;      // px - rb <  16 gx
-    const double oy0 = (double)P.cy - 0.5 - (double)P.cull_y0 + c0;                 // py + rb >= cull_y0
-    const double oy1 = (double)P.cull_y1 - (double)P.cy + 0.5 + c0;                 // py - rb <  cull_y1
-    if (SGS_PLANE_NEG(tx, (double)P.fx, ox0)) return true;
-    if (SGS_PLANE_NEG(tx, -(double)P.fx, ox1)) return true;
-    if (SGS_PLANE_NEG(ty, (double)P.fy, oy0)) return true;
-    if (SGS_PLANE_NEG(ty, -(double)P.fy, oy1)) return true;
+    // the four planes: form(u) = f u + off tz + nrm Rp + A s_max (f = +-fx for left/right with u = tx, +-fy for top/bottom
+    // with u = ty; off, nrm, A: constants of the frame, fill_params); negative => the condition fails for every member
+    const double d = P.cull_A * sm, zmag = fabs(tz) + Rp;
+    const double fx = (double)P.fx, fy = (double)P.fy;
+#define SGS_PLANE_NEG(U, F, K)                                                                           \
+    (((F) * (U) + P.cull_off[K] * tz + P.cull_nrm[K] * Rp + d) <                                         \
+     -1.0e-4 * (fabs((F) * (U)) + fabs(P.cull_off[K]) * zmag + P.cull_nrm[K] * Rp + d))
+    const bool out = SGS_PLANE_NEG(tx, fx, 0) || SGS_PLANE_NEG(tx, -fx, 1) || SGS_PLANE_NEG(ty, fy, 2) || SGS_PLANE_NEG(ty, -fy, 3);
 #undef SGS_PLANE_NEG
-    return false;
+    return out;
+}
+
+// The frame's LIVE LIST: one lane per 64-Gaussian chunk tests the chunk's bounds against the frame / the band of tile
+// rows (chunk_outside) and the survivors' indices are compacted into live_list (ballot + one atomic per workgroup; order
+// inside a workgroup preserved).  k_preprocess and both binning kernels then walk that list — 47 k chunks at 3 M
+// Gaussians, of which a rank's band of a sharded frame keeps a few per cent — instead of sweeping the scene.  Skipped
+// chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
+#define SGS_CULL_THREADS 1024
+__global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    __shared__ unsigned s_wcnt[SGS_CULL_THREADS / SGS_WAVE];
+    __shared__ unsigned s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long chunk = (long long)blockIdx.x * SGS_CULL_THREADS + tid;
+    bool live = false;
+    if (chunk < P.n_chunks) {
+        live = (P.flags & 64u) != 0u || !chunk_outside(P, G.cbound[2 * chunk], G.cbound[2 * chunk + 1]);
+        if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; }
+    }
+    const unsigned long long m = __ballot(live);
+    if (lane == 0) s_wcnt[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    unsigned before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < SGS_CULL_THREADS / SGS_WAVE; ++w) { before += w < wave ? s_wcnt[w] : 0u; total += s_wcnt[w]; }
+    if (tid == 0) s_base = total ? atomicAdd(&S.st->n_live, total) : 0u;
+    __syncthreads();
+    if (live) S.live_list[s_base + before + (unsigned)__popcll(m & lanemask_lt(lane))] = (unsigned)chunk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -458,24 +477,21 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
 // HBM-bound), which makes every integer decision (cull, radius, rect, tile counts) agree with the
 // fp64 oracle.  A pure map kernel: no LDS, no atomics; vismask[chunk] (the wave's ballot) tells the
 // consumers which of the chunk's 64 splat slots are live this frame.
-__global__ __launch_bounds__(256) void k_preprocess(const FrameParams P,
-                                                    const float4* __restrict__ geom,
-                                                    const float4* __restrict__ shq,
-                                                    Splat* __restrict__ splats,
-                                                    unsigned long long* __restrict__ vismask,
-                                                    unsigned long long* __restrict__ bigmask,
-                                                    unsigned* __restrict__ big_list,
-                                                    uint4* __restrict__ binrec,
-                                                    const float4* __restrict__ cbound,
-                                                    FrameStatus* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];                  // this workgroup's frame of the group
+    const FrameParams& P = S.P;
+    const float4* __restrict__ geom = G.geom; const float4* __restrict__ shq = G.shq; const float4* __restrict__ cbound = G.cbound;
+    Splat* __restrict__ splats = S.splats;
+    unsigned long long* __restrict__ vismask = S.vismask; unsigned long long* __restrict__ bigmask = S.bigmask;
+    unsigned* __restrict__ big_list = S.big_list; uint4* __restrict__ binrec = S.binrec;
+    FrameStatus* __restrict__ st = S.st;
     const int lane = threadIdx.x & 63;
-    const long long chunk = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (chunk >= P.n_chunks) return;                       // wave-uniform
-    // chunks that cannot reach this frame / this rank's band of tile rows cost 32 bytes, not a sweep of their rows
-    if (!(P.flags & 64u) && chunk_outside(P, cbound[2 * chunk], cbound[2 * chunk + 1])) {
-        if (lane == 0) { vismask[chunk] = 0ull; bigmask[chunk] = ~0ull; }   // (bigmask is only read under a non-zero
-        return;                                                             //  vismask: all-ones marks "skipped" for tests)
-    }
+    // wave k of the launch takes entry k of the frame's live list (k_chunk_cull): the chunks that cannot reach this frame
+    // / this rank's band of tile rows are never touched
+    const unsigned k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= st->n_live) return;                           // wave-uniform
+    const long long chunk = (long long)S.live_list[k];
+    (void)cbound;
     preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, chunk, lane);
 }
 
@@ -513,12 +529,12 @@ __device__ __forceinline__ unsigned class_take(unsigned* s_cls, unsigned cls, bo
 }
 __device__ __forceinline__ unsigned queue_class(unsigned c) { return c ? 32u - (unsigned)__clz((int)c) : 0u; }
 
-__global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameParams P,
-                                                                const unsigned* __restrict__ tile_count,
-                                                                unsigned* __restrict__ tile_offset,
-                                                                uint4* __restrict__ tile_order,
-                                                                unsigned long long* __restrict__ row_acc,
-                                                                FrameStatus* __restrict__ st) {
+__global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const unsigned* __restrict__ tile_count = S.tile_count; unsigned* __restrict__ tile_offset = S.tile_offset;
+    uint4* __restrict__ tile_order = S.tile_order; unsigned long long* __restrict__ row_acc = G.row_acc;
+    FrameStatus* __restrict__ st = S.st;
     constexpr int NW = SGS_SCAN_THREADS / SGS_WAVE;
     __shared__ unsigned s_row[SGS_SCAN_THREADS + 2];  // records per tile row among my 1024 tiles (-> row_acc, see the end)
     __shared__ unsigned s_all[33], s_before[33];      // tiles per log2(queue length) class: whole band / before my tiles
@@ -655,29 +671,26 @@ __device__ __forceinline__ unsigned bin_b(const FrameParams& P) { return blockId
 __device__ __forceinline__ int bin_w(const FrameParams& P) { return (int)(blockIdx.x / bin_B(P)); }
 #define SGS_RANGES_PER_SWEEP (SGS_BIN_THREADS / SGS_RANGE_CHUNKS)
 #define SGS_SWEEPS_PER_PASS (SGS_MAX_LIVE / SGS_BIN_THREADS)
-#ifndef SGS_RANGE_BLOCK
-#define SGS_RANGE_BLOCK 1            // consecutive ranges a workgroup takes at a time (experiment)
-#endif
-// the j-th range of workgroup b: blocks of SGS_RANGE_BLOCK consecutive ranges, dealt round-robin to the workgroups
-__device__ __forceinline__ long long bin_range(const FrameParams& P, int j) {
-    return ((long long)(j / SGS_RANGE_BLOCK) * bin_B(P) + bin_b(P)) * SGS_RANGE_BLOCK + (j % SGS_RANGE_BLOCK);
-}
-__device__ __forceinline__ int bin_sweeps(const FrameParams& P) {
-    const int n_blocks = (P.n_ranges + SGS_RANGE_BLOCK - 1) / SGS_RANGE_BLOCK;
-    const int mine = ((n_blocks - (int)bin_b(P) + (int)bin_B(P) - 1) / (int)bin_B(P)) * SGS_RANGE_BLOCK;
-    return (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP;
+// The binning kernels deal RANGES of SGS_RANGE_CHUNKS consecutive entries of the frame's live list round-robin to the
+// workgroups: range j of workgroup b is range j * B + b of the list.
+__device__ __forceinline__ int bin_sweeps(const FrameParams& P, unsigned n_live) {
+    const int n_ranges = (int)((n_live + SGS_RANGE_CHUNKS - 1) / SGS_RANGE_CHUNKS);
+    const int mine = (n_ranges - (int)bin_b(P) + (int)bin_B(P) - 1) / (int)bin_B(P);
+    return mine > 0 ? (mine + SGS_RANGES_PER_SWEEP - 1) / SGS_RANGES_PER_SWEEP : 0;
 }
 __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const unsigned long long* __restrict__ vismask,
                                                  const unsigned long long* __restrict__ bigmask,
+                                                 const unsigned* __restrict__ live_list, unsigned n_live,
                                                  LiveChunks& lc, int sweep0, int sweep1) {
     if (threadIdx.x == 0) { lc.n = 0; lc.n_vis = 0; }
     __syncthreads();
     unsigned vis = 0;
     for (int sw = sweep0; sw < sweep1; ++sw) {
         const int j = sw * SGS_RANGES_PER_SWEEP + (int)(threadIdx.x / SGS_RANGE_CHUNKS);     // j-th range of this workgroup
-        const long long r = bin_range(P, j);
-        const long long chunk = r * SGS_RANGE_CHUNKS + (threadIdx.x % SGS_RANGE_CHUNKS);
-        if (r < P.n_ranges && chunk < P.n_chunks) {
+        const long long r = (long long)j * bin_B(P) + bin_b(P);
+        const long long e = r * SGS_RANGE_CHUNKS + (threadIdx.x % SGS_RANGE_CHUNKS);         // entry of the live list
+        if (e < (long long)n_live) {
+            const long long chunk = (long long)live_list[e];
             const unsigned long long vm = vismask[chunk];
             if (vm != 0ull) {
                 vis += (unsigned)__popcll(vm);
@@ -815,15 +828,15 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
 
 // (~39 KB of LDS per workgroup: what a binning workgroup takes from a CU is what the composite workgroups of the
 // frames in flight cannot use)
-__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams P,
-                                                               const uint4* __restrict__ binrec,
-                                                               const unsigned long long* __restrict__ vismask,
-                                                               const unsigned long long* __restrict__ bigmask,
-                                                               const unsigned* __restrict__ big_list,
-                                                               unsigned* __restrict__ tile_count,
-                                                               uint2* __restrict__ blk_list,
-                                                               unsigned* __restrict__ blk_len,
-                                                               FrameStatus* __restrict__ st, unsigned long long* prof) {
+__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const uint4* __restrict__ binrec = S.binrec;
+    const unsigned long long* __restrict__ vismask = S.vismask; const unsigned long long* __restrict__ bigmask = S.bigmask;
+    const unsigned* __restrict__ big_list = S.big_list; unsigned* __restrict__ tile_count = S.tile_count;
+    uint2* __restrict__ blk_list = S.blk_list; unsigned* __restrict__ blk_len = S.blk_len;
+    FrameStatus* __restrict__ st = S.st; unsigned long long* prof = S.bin_prof;
+    (void)prof;
 #ifdef SGS_TILE_PROF
     unsigned long long bt0 = clock64(), bt_find = 0, bt_walk = 0, bt_flush = 0, bt_big = 0, btm = bt0;
 #define SGS_BPROF(acc) do { unsigned long long now_ = clock64(); acc += now_ - btm; btm = now_; } while (0)
@@ -835,7 +848,9 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
     const unsigned xcd = xcc_id();
-    const int n_sweeps = bin_sweeps(P);
+    const unsigned n_live = st->n_live;
+    const unsigned* __restrict__ live_list = S.live_list;
+    const int n_sweeps = bin_sweeps(P, n_live);
     unsigned n_vis = 0;
     const unsigned b = bin_b(P);
     {
@@ -848,7 +863,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
         if (tid == 0) s_nlist = 0;
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
-            find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            find_live_chunks(P, vismask, bigmask, live_list, n_live, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             SGS_BPROF(bt_find);
             if (w == 0) n_vis += lc.n_vis;
             bin_walk<false>(P, binrec, lc, wr0, wr1, s_cnt, nullptr);
@@ -914,17 +929,15 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameParams
 #endif
 }
 
-__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams P,
-                                                              const uint4* __restrict__ binrec,
-                                                              const unsigned long long* __restrict__ vismask,
-                                                              const unsigned long long* __restrict__ bigmask,
-                                                              const unsigned* __restrict__ big_list,
-                                                              const unsigned* __restrict__ tile_offset,
-                                                              const uint2* __restrict__ blk_list,
-                                                              const unsigned* __restrict__ blk_len,
-                                                              unsigned long long* __restrict__ rec,
-                                                              unsigned* __restrict__ tile_count,
-                                                              const FrameStatus* __restrict__ st) {
+__global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const uint4* __restrict__ binrec = S.binrec;
+    const unsigned long long* __restrict__ vismask = S.vismask; const unsigned long long* __restrict__ bigmask = S.bigmask;
+    const unsigned* __restrict__ big_list = S.big_list; const unsigned* __restrict__ tile_offset = S.tile_offset;
+    const uint2* __restrict__ blk_list = S.blk_list; const unsigned* __restrict__ blk_len = S.blk_len;
+    unsigned long long* __restrict__ rec = S.rec; unsigned* __restrict__ tile_count = S.tile_count;
+    const FrameStatus* __restrict__ st = S.st;
     SGS_DYNAMIC_LDS(unsigned, s_next);               // P.win_tiles write cursors
     __shared__ LiveChunks lc;
     const int tid = threadIdx.x;
@@ -936,7 +949,9 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
     }
     if (st->overflow) return;
     const unsigned b = bin_b(P);
-    const int n_sweeps = bin_sweeps(P);
+    const unsigned n_live = st->n_live;
+    const unsigned* __restrict__ live_list = S.live_list;
+    const int n_sweeps = bin_sweeps(P, n_live);
     {
         const int w = bin_w(P);
         const unsigned xcd = blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + b * SGS_MAX_WINDOWS + w];   // the XCD k_bin_count ran (b, w) on
@@ -949,7 +964,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameParams 
         }
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
-            find_live_chunks(P, vismask, bigmask, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
+            find_live_chunks(P, vismask, bigmask, live_list, n_live, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             bin_walk<true>(P, binrec, lc, wr0, wr1, s_next, rec);
             __syncthreads();
         }
@@ -1351,15 +1366,15 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 }
 
 template <bool AUX>
-__global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameParams P,
-                                                     const uint4* __restrict__ tile_order,
-                                                     const unsigned long long* __restrict__ rec,
-                                                     unsigned long long* alt, unsigned long long* part,
-                                                     unsigned* sorted_out,
-                                                     const Splat* __restrict__ splats,
-                                                     float* __restrict__ out_rgb,
-                                                     float* __restrict__ out_aux,
-                                                     FrameStatus* st, unsigned long long* prof) {
+__global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const uint4* __restrict__ tile_order = S.tile_order; const unsigned long long* __restrict__ rec = S.rec;
+    unsigned long long* alt = S.alt; unsigned long long* part = S.part; unsigned* sorted_out = S.sorted_out;
+    const Splat* __restrict__ splats = S.splats;
+    float* __restrict__ out_rgb = S.out_rgb; float* __restrict__ out_aux = S.out_aux;
+    FrameStatus* st = S.st; unsigned long long* prof = S.tile_prof;
+    (void)prof; (void)out_aux;
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8 + SGS_RANK_BUCKET_MAX];  // records: depth bits << 32 | slot (+8 sentinels, + slack
                                                                           // for the masked reads past a short bucket)

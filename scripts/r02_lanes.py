@@ -37,13 +37,15 @@ def rate_batch(r, gs, rows=None, n=96):
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) / n * 1e3)
     return best
-for lanes in (3, 4, 6, 8):
-    os.environ["SGS_LANES"] = str(lanes)
-    r = Renderer(dev, record_capacity=24 << 20)
-    gs = r.upload(g)
-    bands = row_partition(68, 8)
-    per = [rate(r, gs, b) for b in bands]
-    print(f"lanes {lanes} (GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}): full {rate(r, gs):.4f}  bands max {max(per):.4f} mean {np.mean(per):.4f} {np.round(per, 3).tolist()}", flush=True)
+bands = row_partition(68, 8)
+os.environ["SGS_LANES"] = "3"
+r = Renderer(dev, record_capacity=24 << 20); gs = r.upload(g)
+per = [rate(r, gs, b) for b in bands]
+print(f"one frame per launch set, 3 lanes (python loop): full {rate(r, gs):.4f}  bands max {max(per):.4f} mean {np.mean(per):.4f} {np.round(per, 3).tolist()}", flush=True)
+gs.free(); r.close()
+for group, gl in ((1, 3), (2, 2), (2, 4), (4, 1), (4, 2), (8, 1)):
+    os.environ["SGS_GROUP"], os.environ["SGS_GROUP_LANES"] = str(group), str(gl)
+    r = Renderer(dev, record_capacity=24 << 20); gs = r.upload(g)
     per = [rate_batch(r, gs, b) for b in bands]
-    print(f"   one call per batch: full {rate_batch(r, gs):.4f}  bands max {max(per):.4f} mean {np.mean(per):.4f} {np.round(per, 3).tolist()}", flush=True)
+    print(f"group {group} x {gl} streams: full {rate_batch(r, gs):.4f}  bands max {max(per):.4f} mean {np.mean(per):.4f} {np.round(per, 3).tolist()}", flush=True)
     gs.free(); r.close()

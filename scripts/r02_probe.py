@@ -63,6 +63,21 @@ if what in ("full", "all"):
             print(f"   chunks skipped by bounds at pose {poses[0]}: {sk.mean():.3f}")
         gs.free(); r.close()
 
+def rate_batch(r, gs, rows, per_call=8, n=64):
+    """ms per frame of a band when the sweep goes through Renderer.render_batch (frame groups), `per_call` frames per call
+    — what a rank of ShardedRenderer.render_batch does"""
+    cl = [cams[poses[i % len(poses)]] for i in range(n)]
+    buf = torch.zeros((per_call, (rows[1] - rows[0]) * 16, W, 3), dtype=torch.float32, device=dev)
+    best = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for c0 in range(0, n, per_call):
+            r.render_batch(cl[c0:c0 + per_call], gs, out_bands=buf, tile_rows=rows)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
+
+
 if what in ("bands", "all"):
     r, gs = make(True)
     gy = (H + 15) // 16
@@ -74,12 +89,12 @@ if what in ("bands", "all"):
         for p in poses[:24]:
             r.render(cams[p], gs, out=ring[0])
         rec = r.row_records(gy, reset=True) / 24.0
-        for name, bands in (("even", even),) + tuple((f"balanced(tile_cost={tc})", balanced_partition(rec + tc * gx, world, 4 * -(-gy // world))) for tc in (0.0, 48.0, 200.0)):
-            per = []
-            for (r0, r1) in bands:
-                per.append(rate(r, gs, True, (r0, r1), n=60))
-            per = np.array(per)
-            print(f"world {world} {name}: slowest {per.max():.4f} mean {per.mean():.4f} ms/frame/rank  rows {[b - a for a, b in bands]}  {np.round(per, 3).tolist()}", flush=True)
+        for name, bands in (("even", even),) + tuple((f"balanced(tile_cost={tc})", balanced_partition(rec + tc * gx, world, 4 * -(-gy // world))) for tc in (48.0,)):
+            per = np.array([rate(r, gs, True, b, n=60) for b in bands])
+            print(f"world {world} {name}: one frame per launch set: slowest {per.max():.4f} mean {per.mean():.4f} ms/frame/rank  rows {[b - a for a, b in bands]}  {np.round(per, 3).tolist()}", flush=True)
+            for pc in (8, 16, 32):
+                per = np.array([rate_batch(r, gs, b, pc) for b in bands])
+                print(f"world {world} {name}: render_batch x{pc}: slowest {per.max():.4f} mean {per.mean():.4f}  {np.round(per, 3).tolist()}", flush=True)
         if world == 8:
             for k, (r0, r1) in enumerate(even):
                 a = alone(r, gs, True, (r0, r1), n=12)
