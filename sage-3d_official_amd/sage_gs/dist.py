@@ -28,7 +28,10 @@ its frame buffer, every peer one send per frame, all in ONE group (`torch.distri
 the seven peers on seven distinct xGMI links of rank 0 concurrently; "gloo" in the CPU tests).  Bands may therefore be
 of any height and there is no padding and no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.1 MB per rank at 8
 ranks): latency-, not bandwidth-bound — so a sweep ships the bands of B frames per group, asynchronously, double-
-buffered against the rendering of the next batch (`ShardedRenderer.render_batch`).
+buffered against the rendering of the next batch (`ShardedRenderer.render_batch`; 32 frames by default: the library
+renders a batch in groups of four frames per launch on two streams, and the pipeline drains at the end of every call —
+measured on one GPU with every rank's band replayed, slowest of 8 ranks: 0.084 ms/frame at 8 frames per call, 0.077 at
+16, 0.070 at 32).
 
 `shard_cameras` is the other natural partition (frames of a sweep are independent units): no
 data-path collective at all.
@@ -347,7 +350,7 @@ class ShardedRenderer:
     # writing a tile costs about as much as blending a few dozen records; scripts/band_balance2.py)
     TILE_COST = 48.0
 
-    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 8,
+    def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 32,
                  interleave: bool = False, balance: bool = False):
         if balance and interleave:
             raise ValueError("interleaved rows are balanced by construction; balance=True is for contiguous bands")

@@ -51,6 +51,14 @@ def rate(r, gs, chunk_cull=True, rows=None, n=100):
     return best
 
 
+if what == "quick":
+    r, gs = make(True)
+    a = alone(r, gs, True)
+    print(f"{os.environ.get('SAGE_GS_LIB', 'default lib')}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]} | pipelined {rate(r, gs, True):.4f} ms/frame", flush=True)
+    a = alone(r, gs, True)
+    print(f"   again: alone us {a[0]} total {a[1]} | pipelined {rate(r, gs, True):.4f} ms/frame", flush=True)
+    gs.free(); r.close()
+
 if what in ("full", "all"):
     for morton in (True, False):
         r, gs = make(morton)
