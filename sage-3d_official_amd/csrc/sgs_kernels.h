@@ -201,7 +201,7 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
 // inside a workgroup preserved).  k_preprocess and both binning kernels then walk that list — 47 k chunks at 3 M
 // Gaussians, of which a rank's band of a sharded frame keeps a few per cent — instead of sweeping the scene.  Skipped
 // chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
-#define SGS_CULL_THREADS 1024
+#define SGS_CULL_THREADS 256
 __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
