@@ -7,7 +7,8 @@ os.environ["SAGE_GS_LIB"] = os.path.join(ROOT, "sage-3d_official_amd", "lib", "l
 import numpy as np, torch
 from sage_gs import Renderer, scenes
 sc = scenes.cached_room(int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, seed=2)
-cams = scenes.room_cameras(sc, 1920, 1080, 4, 64, seed=2)
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+cams = scenes.room_cameras(sc, W, H, 4, 64, seed=2)
 r = Renderer("cuda:0", record_capacity=96 << 20)
 gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
 out = {}
