@@ -185,8 +185,10 @@ def main():
             batch_cams = [cams[pose(first + i + j)] for j in range(nb)]
             sharded.last_stats = None
             if pipelined:
-                sharded.render_batch(batch_cams, gs, timing=timed)
-                st = sharded.last_stats
+                # (no per-stage events inside the timed region: they would force one call per frame instead of one call per
+                #  batch; the stage times of rank 0's band come from the one-at-a-time post-pass)
+                sharded.render_batch(batch_cams, gs)
+                st = None
             else:
                 sharded.render(batch_cams[0], gs)
                 st = r.last_stats

@@ -15,9 +15,11 @@ Which rows a rank owns:
   * `balance=True` — contiguous bands of equal COST.  An indoor view puts most of its depth complexity into a few
     rows around the horizon, so equal bands leave the slowest of 8 ranks at ~1.5x the mean.  Every rank reports the
     records its rows queued (`Renderer.row_records`, from the frames it just rendered), one tiny all-reduce makes the
-    per-row profile of the whole frame known everywhere, and the next batch's bands are cut from it
-    (`balanced_partition`: minimal largest band cost) — a sweep's views change slowly, so the previous batch predicts
-    the next;
+    per-row profile of the whole frame known everywhere — together with the time each rank's band just took, which is
+    spread over the band's rows by their records (`timed_row_cost`: records alone mispredict, a ceiling row of a few huge
+    splats queues as many as a horizon row of thousands of small ones and costs a third) — and the next batch's bands are
+    cut from that (`balanced_partition`: minimal largest band cost); a sweep's views change slowly, so the previous batch
+    predicts the next;
   * `interleave=True` — every R-th row (rank r owns rows r, r+R, ...): balanced whatever the camera looks at, but a
     splat covers 2-3 tile rows, so every rank then projects and bins ~1.7x the splats of a contiguous band, and rank 0
     has to re-interleave the rows (one copy).  Opt-in; measured slower than balanced bands.
@@ -119,6 +121,29 @@ def balanced_partition(cost: Sequence[float], world: int, max_rows: Optional[int
         bands[k:k + 1] = [(a, m), (m, b)]
     bands += [(n, n)] * (world - len(bands))
     return bands
+
+
+def timed_row_cost(bands: Sequence[Tuple[int, int]], band_ms: Sequence[float], row_records: Sequence[float],
+                   prev_cost: Optional[Sequence[float]] = None, smooth: float = 0.5) -> np.ndarray:
+    """Per-tile-row cost from what the ranks just MEASURED: rank r took band_ms[r] for its band, and that time is spread
+    over the band's rows in proportion to the records each row queued (rows of an empty band, or without records, share
+    evenly).  Records alone mispredict — a ceiling row of a few huge splats queues as many records as a horizon row
+    of thousands of small ones and costs a third — while the measured time carries everything, including the fixed cost of
+    a rank's launches.  `prev_cost` (the cost the current bands were cut from) is blended in (`smooth`) to damp the
+    iteration.  Deterministic; every rank computes the same vector from the same all-reduced inputs."""
+    rec = np.maximum(np.nan_to_num(np.asarray(row_records, np.float64)), 0.0)
+    cost = np.zeros(len(rec))
+    for (a, b), t in zip(bands, band_ms):
+        if b <= a:
+            continue
+        t = max(float(t), 0.0)
+        w = rec[a:b] + 1.0                                   # (+1: rows without records still share the band's fixed cost)
+        cost[a:b] = t * w / w.sum()
+    if prev_cost is not None and len(prev_cost) == len(cost) and smooth > 0.0:
+        p = np.asarray(prev_cost, np.float64)
+        if p.sum() > 0 and cost.sum() > 0:
+            cost = (1.0 - smooth) * cost + smooth * p * (cost.sum() / p.sum())
+    return cost
 
 
 def shard_cameras(n_cameras: int, rank: int, world: int) -> range:
@@ -346,8 +371,7 @@ class ShardedRenderer:
     """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows, the
     bands are gathered to rank `dst`.  balance=True re-cuts the bands of a sweep by cost (see the module docstring)."""
 
-    # cost of a tile row = records queued in it + this many "records" per tile of fixed work (clearing, scanning and
-    # writing a tile costs about as much as blending a few dozen records; scripts/band_balance2.py)
+    # first re-cut (no timing yet): cost of a tile row = records queued in it + this many "records" per tile of fixed work
     TILE_COST = 48.0
 
     def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 32,
@@ -362,8 +386,10 @@ class ShardedRenderer:
         self._ring = None            # two batched buffers: one travels while the other is rendered into
         self._pending = [None, None]
         self._turn = 0
-        self._cost_work = None       # the all-reduce of the previous batch's per-row records
+        self._cost_work = None       # the all-reduce of the previous batch's per-row records and per-rank band times
         self._cost = None
+        self._cost_bands = None      # the bands those measurements were taken with
+        self._row_cost = None        # the per-row cost the current bands were cut from
         self.bands = list(self.g.bands)
         self.last_stats = None       # statistics of the last batch this rank rendered (per-frame averages)
 
@@ -381,13 +407,17 @@ class ShardedRenderer:
         return self.g.gather()
 
     # -- cost-balanced bands ---------------------------------------------------------------------------------------------
-    def _post_costs(self, n_frames: int):
-        """After a batch: every rank contributes the records its rows queued; one small all-reduce, posted BEFORE the
-        batch's exchange so that it does not queue behind 25 MB per frame on the communicator."""
+    def _post_costs(self, n_frames: int, band_ms: float, bands):
+        """After a batch: every rank contributes the records its rows queued and the time its band took per frame; one
+        small all-reduce (rows + ranks elements), posted BEFORE the batch's exchange so that it does not queue behind
+        25 MB per frame on the communicator."""
         g = self.g
         rec = self.r.row_records(g.n_tile_rows, reset=True).astype(np.float64) / max(1, n_frames)
+        times = np.zeros(self.world)
+        times[g.rank] = band_ms
         dev = "cpu" if dist.get_backend(self.group) == "gloo" else self.r.device
-        self._cost = torch.from_numpy(rec).to(dev)
+        self._cost = torch.from_numpy(np.concatenate([rec, times])).to(dev)
+        self._cost_bands = list(bands)
         self._cost_work = dist.all_reduce(self._cost, group=self.group, async_op=True) if self.world > 1 else None
 
     def _rebalance(self):
@@ -396,9 +426,15 @@ class ShardedRenderer:
         if self._cost_work is not None:
             self._cost_work.wait()
             self._cost_work = None
-        cost = self._cost.cpu().numpy() + self.TILE_COST * ((self.w + TILE - 1) // TILE)
+        v = self._cost.cpu().numpy()
         self._cost = None
-        self.bands = balanced_partition(cost, self.world, self.g.max_band_rows)
+        n = self.g.n_tile_rows
+        rec, times = v[:n], v[n:]
+        if times.sum() > 0:          # measured band times, spread over the rows by their records (timed_row_cost)
+            self._row_cost = timed_row_cost(self._cost_bands, times, rec, self._row_cost)
+        else:
+            self._row_cost = rec + self.TILE_COST * ((self.w + TILE - 1) // TILE)
+        self.bands = balanced_partition(self._row_cost, self.world, self.g.max_band_rows)
 
     def render_batch(self, cameras, scene, *, config=None, timing=False):
         """Up to `batch` independent frames (a sweep): the bands are rendered through the renderer's pipelined lanes
@@ -420,6 +456,8 @@ class ShardedRenderer:
         if self.balance:
             self._rebalance()                      # bands cut from the previous batch's per-row records (same on all ranks)
             g.set_bands(self.bands)
+        import time
+        t0 = time.perf_counter()
         r0, r1 = g.band
         if r1 > r0:
             if timing:                             # per-stage events: one call per frame
@@ -429,8 +467,8 @@ class ShardedRenderer:
             else:                                  # ONE call into the library for the whole batch (complete on return)
                 _, st = self.r.render_batch(cameras, scene, config=config, want_stats=True, **g.batch_target())
                 self.last_stats = st[-1]
-        if self.balance:
-            self._post_costs(n)
+        if self.balance:                           # (render_batch is complete on return: the band's wall time per frame)
+            self._post_costs(n, 1e3 * (time.perf_counter() - t0) / n, g.bands)
         self._pending[k] = g.exchange(n, async_op=True)
         return g
 

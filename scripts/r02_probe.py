@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
 import numpy as np, torch
 from sage_gs import Renderer, scenes
-from sage_gs.dist import row_partition, balanced_partition, ShardedRenderer
+from sage_gs.dist import row_partition, balanced_partition, timed_row_cost, ShardedRenderer
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 W, H = (3840, 2160) if "4k" in sys.argv else (1920, 1080)
@@ -109,3 +109,20 @@ if what in ("bands", "all"):
                 print(f"   rank {k} rows {(r0, r1)} alone us {a[0]} total {a[1]} N_v={a[2]} D={a[3]}")
     full = rate(r, gs)
     print(f"full frame pipelined: {full:.4f} ms/frame")
+
+if what in ("iterate", "all"):
+    # what ShardedRenderer(balance=True) does over the batches of a sweep: bands re-cut from the MEASURED band times
+    r, gs = make(True)
+    gy = (H + 15) // 16
+    r.row_records(gy, reset=True)
+    for p in poses[:24]:
+        r.render(cams[p], gs, out=ring[0])
+    rec = r.row_records(gy, reset=True) / 24.0
+    full = rate(r, gs)
+    for world in (8, 4, 2):
+        bands, cost = row_partition(gy, world), None
+        for it in range(6):
+            per = np.array([rate_batch(r, gs, b, 32) if b[1] > b[0] else 0.0 for b in bands])
+            print(f"world {world} iteration {it}: slowest {per.max():.4f} mean {per.mean():.4f} (x{full / per.max():.2f} of {full:.4f})  rows {[b - a for a, b in bands]}  {np.round(per, 3).tolist()}", flush=True)
+            cost = timed_row_cost(bands, per, rec, cost)
+            bands = balanced_partition(cost, world, 4 * -(-gy // world))
