@@ -34,30 +34,10 @@ __device__ __forceinline__ unsigned xcc_id() {
     return (unsigned)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & (SGS_XCDS - 1);
 }
 
-// Wave-wide scan / reductions.  On the GPU they are DPP sequences (row shifts inside the 16-lane rows, then the two
-// row broadcasts): pure VALU, where __shfl_* would be ds_bpermute — six DEPENDENT round-trips through the LDS
-// pipe per call, and these sit in the partition of every tile and in the binning walk of every chunk.
-#ifdef SGS_HIPEMU
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned x, int lane) {
-    for (int d = 1; d < SGS_WAVE; d <<= 1) {
-        unsigned v = __shfl_up(x, d);
-        if (lane >= d) x += v;
-    }
-    return x;
-}
-__device__ __forceinline__ unsigned wave_max(unsigned x) {
-    for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v > x ? v : x; }
-    return x;
-}
-__device__ __forceinline__ unsigned wave_min(unsigned x) {
-    for (int d = 32; d >= 1; d >>= 1) { unsigned v = __shfl_xor(x, d); x = v < x ? v : x; }
-    return x;
-}
-__device__ __forceinline__ unsigned wave_sum(unsigned x) {
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d);
-    return x;
-}
-#else
+// Wave-wide scan / reductions: DPP sequences (row shifts inside the 16-lane rows, then the two row broadcasts): pure
+// VALU, where __shfl_* would be ds_bpermute — six DEPENDENT round-trips through the LDS pipe per call, and these sit in
+// the partition of every tile and in the binning walk of every chunk.  (The CPU test harness emulates update_dpp /
+// readlane lane for lane, so this is the one and only code path.)
 // one step: combine x with the value `ctrl` selects; lanes whose source does not exist (or whose row is masked
 // off) combine with the identity
 #define SGS_DPP_STEP(OP, ID, CTRL, ROWMASK)                                                            \
@@ -83,7 +63,6 @@ __device__ __forceinline__ unsigned wave_sum(unsigned x) {
     SGS_DPP_SCAN(sgs_op_add, 0u)
     return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
 }
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
@@ -1155,15 +1134,9 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
 // is applied in depth order.  Predicates stay on the VALU (compare -> select).  A short tail reads the inert
 // dummy splat at index SGS_BATCH.
-#ifdef SGS_HIPEMU
-#define SGS_EXP2(x) exp2f(x)
-#define SGS_RCP(x) (1.0f / (x))
-#define SGS_SQRT(x) sqrtf(x)
-#else
 #define SGS_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define SGS_RCP(x) __builtin_amdgcn_rcpf(x)         // 1 ulp; every use below is padded outward
 #define SGS_SQRT(x) __builtin_amdgcn_sqrtf(x)
-#endif
 #ifdef SGS_TILE_PROF   // profiling build: how many (wave, splat) evaluations had no pixel inside the alpha cut-off
 #define SGS_PROF_EVAL(valid, J)                                                                        \
     if ((J) != (unsigned)SGS_BATCH) {                                                                  \
@@ -1349,13 +1322,9 @@ template <> struct ColOf<true> { typedef float4 type; };
 
 // orders a wave's own LDS writes before its later LDS reads by OTHER lanes of the same wave
 __device__ __forceinline__ void wave_lds_sync() {
-#ifdef SGS_HIPEMU
-    (void)__ballot(true);                  // a wave collective synchronises the wave's fibers
-#else
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
 }
 
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {

@@ -25,7 +25,6 @@
 #include <functional>
 #include <vector>
 
-#define SGS_HIPEMU 1
 
 // ---- language surface ---------------------------------------------------------------------------
 #define __global__
@@ -236,6 +235,34 @@ static inline unsigned long long clock64() { return 0; }
 template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // callers pass wave-uniform values
+// v_exp_f32 / v_rcp_f32 / v_sqrt_f32 (1 ulp on the hardware; correctly rounded here — the kernels pad every use)
+static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+// Wave-scope fence / barrier: a rendezvous of the wave's fibers orders their LDS accesses.
+#define __builtin_amdgcn_fence(order_, scope_) ((void)0)
+static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(true); }
+// v_readlane_b32: the value of lane `src` (callers read an active lane).
+static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::shfl_from(v, src & 63); }
+// v_mov_b32 with a DPP modifier (the controls the kernels use): every lane of the wave takes part; a lane whose source
+// lane does not exist, or whose row is masked off, gets `old` (bound_ctrl = false: the destination is not written).
+//   0x101..0x10f row_shl:n   0x111..0x11f row_shr:n   0x142 row_bcast:15   0x143 row_bcast:31
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    hipemu::BlockExec* e = hipemu::exec();
+    const unsigned t = e->fibers[e->cur].tid.x;
+    const int lane = (int)(t & 63), row = lane >> 4, in_row = lane & 15;
+    const int p = hipemu::collective(hipemu::bits(src));
+    hipemu::WaveState& w = e->waves[t >> 6];
+    int from = -1;
+    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (in_row >= n) from = lane - n; }
+    else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; if (in_row + n <= 15) from = lane + n; }
+    else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }                  // last lane of the previous row
+    else if (ctrl == 0x143) { if (row >= 2) from = 31; }                            // last lane of row 1
+    else { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
+    if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
+    if (from < 0 || !((w.part[p] >> from) & 1ull)) return bound_ctrl ? 0 : old;
+    return hipemu::unbits<int>(w.vals[p][from]);
+}
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline unsigned min(unsigned a, unsigned b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
