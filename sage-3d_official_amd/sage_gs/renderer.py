@@ -166,6 +166,26 @@ class Renderer:
         return _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                                  view.astype(np.float32).tolist())
 
+    _CAM_DTYPE = np.dtype([("width", "<i4"), ("height", "<i4"), ("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"),
+                           ("view", "<f4", (16,))])
+
+    @classmethod
+    def _c_cameras(cls, cameras: Sequence[Camera], scene: Scene) -> np.ndarray:
+        """The sgs_camera array of a batch, marshalled in one go (a structured array with sgs_camera's layout): per-camera
+        ctypes marshalling costs ~30 us, as much as a light band of tile rows takes to render."""
+        assert cls._CAM_DTYPE.itemsize == C.sizeof(_capi.SgsCamera)
+        b = len(cameras)
+        views = np.stack([np.asarray(c.view.detach().cpu().numpy() if isinstance(c.view, torch.Tensor) else c.view,
+                                     np.float64).reshape(4, 4) for c in cameras])
+        if scene.model_to_world is not None:
+            views = views @ scene.model_to_world.reshape(4, 4)
+        arr = np.zeros(b, cls._CAM_DTYPE)
+        arr["width"] = [c.width for c in cameras]; arr["height"] = [c.height for c in cameras]
+        arr["fx"] = [c.fx for c in cameras]; arr["fy"] = [c.fy for c in cameras]
+        arr["cx"] = [c.cx for c in cameras]; arr["cy"] = [c.cy for c in cameras]
+        arr["view"] = views.reshape(b, 16).astype(np.float32)
+        return arr
+
     def _c_config(self, cfg: Optional[RenderConfig], flags=0) -> _capi.SgsConfig:
         k = self._lib.default_config()
         if cfg is not None:
@@ -320,10 +340,10 @@ class Renderer:
                   or tuple(out.shape[1:]) != (h, w, 3) or not out[0].is_contiguous()):
                 raise ValueError("out must be float32 [>= B, H, W, 3] on the renderer's device")
             ptr, frame_stride, ret = out.data_ptr(), int(out.stride(0)), out
-        arr = (_capi.SgsCamera * b)(*[self._c_camera(c, scene) for c in cameras])
+        arr = self._c_cameras(cameras, scene)
         stats = (_capi.SgsStats * b)() if want_stats else None
-        self._lib.check(self._lib.sgs_render_batch_strided(self._ctx, scene.handle, arr, b, C.byref(cfg), r0, r1,
-                                                           ptr, frame_stride, stats, self._stream()), self._ctx)
+        self._lib.check(self._lib.sgs_render_batch_strided(self._ctx, scene.handle, arr.ctypes.data_as(C.POINTER(_capi.SgsCamera)),
+                                                           b, C.byref(cfg), r0, r1, ptr, frame_stride, stats, self._stream()), self._ctx)
         if want_stats:
             return ret, [s.as_dict() for s in stats]
         return ret
