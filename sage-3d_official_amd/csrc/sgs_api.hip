@@ -277,7 +277,6 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.fx = cam->fx; P.fy = cam->fy; P.cx = cam->cx; P.cy = cam->cy;
     P.near_z = cfg.near_z; P.far_z = cfg.far_z; P.dilation = cfg.dilation; P.clamp = cfg.clamp;
     P.alpha_min = cfg.alpha_min; P.alpha_max = cfg.alpha_max; P.t_min = cfg.t_min;
-    P.log2_alpha_min = log2f(cfg.alpha_min);
     for (int c = 0; c < 3; ++c) P.bg[c] = cfg.bg[c];
     P.width = cam->width; P.height = cam->height;
     P.gx = (cam->width + SGS_TILE - 1) / SGS_TILE; P.gy = (cam->height + SGS_TILE - 1) / SGS_TILE;

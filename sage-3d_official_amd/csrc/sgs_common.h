@@ -45,7 +45,6 @@ struct FrameParams {
     float fx, fy, cx, cy;
     float near_z, far_z, dilation, clamp;
     float alpha_min, alpha_max, t_min;
-    float log2_alpha_min;           // log2(alpha_min): the composite's cut-off in the exponent domain
     float bg[3];
     int32_t width, height, gx, gy;
     int32_t row_begin, row_end;     // tile rows rendered by this call

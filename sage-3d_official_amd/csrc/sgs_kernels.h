@@ -381,7 +381,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                 // what the composite needs to decide which 8x8 quadrants of a tile the splat can reach (k_tile_render):
                 // alpha >= alpha_min  <=>  q2 <= qmax = log2(o / alpha_min); the ellipse's axis-aligned half extents are
                 // sqrt(K a) x sqrt(K c), K = 2 ln(o / alpha_min) = 2 ln2 qmax, padded generously (the exact quadrant test follows)
-                qmax = __log2f(g0.w) - P.log2_alpha_min;
+                qmax = __log2f(g0.w) - __log2f(P.alpha_min);
                 if (qmax > 0.0f) {
                     const float Kq = 1.38629436112f * qmax;
                     const float ex_ = sqrtf(Kq * (float)a) * 1.01f + 0.5f, ey_ = sqrtf(Kq * (float)c) * 1.01f + 0.5f;
@@ -1117,13 +1117,11 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // (v_pk_*) 1.8 — no gain over two plain ops —, v_cmp / v_min / v_max / v_cndmask and any SGPR operand 1.6,
 // v_exp_f32 3, a broadcast ds_read_b128 ~6 on the CU's shared LDS pipe.  The composite is issue-bound, so the
 // per-pixel work is written for the smallest issue count rather than the fewest flops:
-//   * every constant is folded into the splat (per splat, not per pixel):
+//   * staging folds every constant into the splat (per splat, not per pixel):
 //         A = ca * log2(e)/2,  B = cb * log2(e),  C = cc * log2(e)/2      q2 = A dx^2 + B dx dy + C dy^2 = -power * log2(e)
-//         L = log2(o)   (staged as qmax + log2(alpha_min), qmax = log2(o / alpha_min) from k_preprocess)
-//     and the opacity rides in the exponent: e = L - q2 comes out of the last two FMAs (their addend), so
-//         alpha = min(2^e, alpha_max)  needs no multiply,   alpha >= alpha_min  <=>  e >= log2(alpha_min)  (one compare
-//     against a kernel constant; no per-splat threshold).  S6's other skip test (power > 0) is vacuous: the conic of
-//     S2 is positive definite (Sigma' + 0.3 I inverted), q2 >= 0 up to rounding, where alpha = o either way;
+//         qcut = bits(log2(o / alpha_min)) + 1
+//     so alpha = o * 2^-q2 needs no scaling, and BOTH skip tests of S6 are one unsigned compare:
+//         power <= 0  and  alpha >= alpha_min   <=>   bits(q2) < qcut     (a negative q2 has the sign bit set);
 //   * a finished (or outside) pixel carries its transmittance NEGATED: T (1 - alpha) is then negative too, and one
 //     SIGNED integer compare bits(T (1 - alpha)) < bits(t_min) is true both for the splat that ends a pixel and for
 //     every later splat — their weight is forced to 0 by the same select, T keeps -|T|.  No live mask, and |T| at
@@ -1131,7 +1129,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 //   * D_f (how far into the queue the tile's pixels read) is not tracked per splat: when a trip leaves a wave with
 //     no live pixel — once per wave and tile — the trip is replayed from the saved T to find the splat that ended
 //     the last pixel.
-// s_a[j] = (x, y, A, B)   s_b[j] = (C, L, r, g)   s_c[j] = b [, view depth]
+// s_a[j] = (x, y, A, B)   s_b[j] = (C, o, qcut, r)   s_c[j] = (g, b[, view depth, 0])
 // A wave walks the splats of the batch that can touch ITS quadrant four per trip: the four alphas are
 // independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
 // is applied in depth order.  Predicates stay on the VALU (compare -> select).  A short tail reads the inert
@@ -1157,27 +1155,26 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 4; \
     mm &= mm - 1ull;
 // O = byte offset of the splat's slot in the staging arrays (16 B per splat in s_a and s_b)
-#define SGS_ALPHA(O, AL, RED, GRN)                                                                     \
-    float AL, RED, GRN;                                                                                \
+#define SGS_ALPHA(O, AL, RED)                                                                          \
+    float AL, RED;                                                                                     \
     {                                                                                                  \
         const float4 qa = SGS_AT(s_a, float4, O), qb = SGS_AT(s_b, float4, O);                         \
         const float dx = qa.x - fpx, dy = qa.y - fpy;                                                  \
-        /* e = log2(o) - q2 = log2(alpha): the opacity rides in the exponent (no multiply per pixel) */ \
-        const float e = __builtin_fmaf(-dx, __builtin_fmaf(qa.w, dy, qa.z * dx), __builtin_fmaf(-(qb.x * dy), dy, qb.y)); \
-        const bool valid = e >= lmin;                                          /* S6: alpha >= 1/255 */ \
-        const float a = __builtin_amdgcn_fmed3f(SGS_EXP2(e), 0.0f, amax);      /* min(alpha, 0.99); alpha >= 0 */ \
+        const float q2 = __builtin_fmaf(dx, __builtin_fmaf(qa.w, dy, qa.z * dx), (qb.x * dy) * dy);    \
+        const bool valid = __float_as_uint(q2) < __float_as_uint(qb.z);   /* S6: power <= 0 and alpha >= 1/255 */ \
+        const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
         AL = valid ? a : 0.0f;                                                                         \
-        RED = qb.z; GRN = qb.w;                                                                        \
+        RED = qb.w;                                                                                    \
         SGS_PROF_EVAL(valid, (O) >> 4)                                                                 \
     }
-#define SGS_APPLY(O, AL, RED, GRN)                                                                     \
+#define SGS_APPLY(O, AL, RED)                                                                          \
     {                                                                                                  \
-        const ColT qc = SGS_AT(s_c, ColT, AUX ? ((O) >> 1) : ((O) >> 2));                              \
+        const ColT qc = SGS_AT(s_c, ColT, AUX ? (O) : ((O) >> 1));                                     \
         const float testT = __builtin_fmaf(-(AL), T, T);                                               \
         const bool stop = (int)__float_as_uint(testT) < tmin_bits;   /* ends here, or ended before (negative) */ \
         float wgt = (AL) * T;                                                                          \
         wgt = stop ? 0.0f : wgt;                   /* the splat that would end the pixel is not blended */ \
-        C0 = __builtin_fmaf(wgt, RED, C0); C1 = __builtin_fmaf(wgt, GRN, C1); C2 = __builtin_fmaf(wgt, col_b(qc), C2); \
+        C0 = __builtin_fmaf(wgt, RED, C0); C1 = __builtin_fmaf(wgt, qc.x, C1); C2 = __builtin_fmaf(wgt, qc.y, C2); \
         if (AUX) Dz = __builtin_fmaf(wgt, col_z(qc), Dz);   /* expected depth (template instantiation only) */ \
         T = stop ? -__builtin_fabsf(T) : testT;                                                        \
     }
@@ -1189,8 +1186,8 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     }
 #define SGS_TRIP(o0, o1, o2, o3)                                                                       \
     const float Tb = T;                                                                                \
-    SGS_ALPHA(o0, al0, r0, g0) SGS_ALPHA(o1, al1, r1, g1) SGS_ALPHA(o2, al2, r2, g2) SGS_ALPHA(o3, al3, r3, g3) \
-    SGS_APPLY(o0, al0, r0, g0) SGS_APPLY(o1, al1, r1, g1) SGS_APPLY(o2, al2, r2, g2) SGS_APPLY(o3, al3, r3, g3) \
+    SGS_ALPHA(o0, al0, r0) SGS_ALPHA(o1, al1, r1) SGS_ALPHA(o2, al2, r2) SGS_ALPHA(o3, al3, r3)        \
+    SGS_APPLY(o0, al0, r0) SGS_APPLY(o1, al1, r1) SGS_APPLY(o2, al2, r2) SGS_APPLY(o3, al3, r3)        \
     if (__ballot(T > 0.0f) == 0ull) {                                                                  \
         /* the wave's last pixel ended in this trip: replay it to find the splat that did it */        \
         float Ts = Tb; unsigned last = 0u;                                                             \
@@ -1236,18 +1233,18 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         (void)wave_done;                                                                               \
         used = T > 0.0f ? base + m : used;                                                             \
     }
-// staging: write splat J from its record (A_ = x,y,A,B  B_ = C,o,qcut,r  C_ = g,b,depth,hx; QMAX = log2(o / alpha_min)):
-// a copy but for log2(o) — k_preprocess has folded every constant into the record
-#define SGS_STAGE(J, A_, B_, C_, QMAX)                                                                 \
+// staging: write splat J from its record (A_ = x,y,A,B  B_ = C,o,qcut,r  C_ = g,b,depth,hx) — a plain copy: k_preprocess
+// has folded every constant into the record
+#define SGS_STAGE(J, A_, B_, C_)                                                                       \
     {                                                                                                  \
         s_a[J] = A_;                                                                                   \
-        s_b[J] = make_float4(B_.x, (QMAX) + lmin, B_.w, C_.x);         /* C, log2(o), r, g */            \
-        s_c[J] = make_col<ColT>(C_.y, C_.z);                                                           \
+        s_b[J] = B_;                                                                                   \
+        s_c[J] = make_col<ColT>(C_.x, C_.y, C_.z);                                                     \
     }
 #define SGS_STAGE_DUMMY()                                                                              \
     {                                                                                                  \
-        s_a[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_b[SGS_BATCH] = make_float4(0.f, -3.0e38f, 0.f, 0.f); \
-        s_c[SGS_BATCH] = make_col<ColT>(0.f, 0.f);                                                     \
+        s_a[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_b[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); \
+        s_c[SGS_BATCH] = make_col<ColT>(0.f, 0.f, 0.f);                                                \
     }
 // ---- which 8x8 quadrants of the tile can a splat reach? -------------------------------------------------
 // The axis-aligned extent of {alpha >= alpha_min} is a loose test for elongated splats (measured: 27 % of the
@@ -1284,15 +1281,13 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
     }
     return bits;
 }
-template <class C> __device__ __forceinline__ C make_col(float b, float z);
-template <> __device__ __forceinline__ float make_col<float>(float b, float) { return b; }
-template <> __device__ __forceinline__ float2 make_col<float2>(float b, float z) { return make_float2(b, z); }
-__device__ __forceinline__ float col_b(float c) { return c; }
-__device__ __forceinline__ float col_b(const float2& c) { return c.x; }
-__device__ __forceinline__ float col_z(float) { return 0.f; }
-__device__ __forceinline__ float col_z(const float2& c) { return c.y; }
-template <bool AUX> struct ColOf { typedef float type; };
-template <> struct ColOf<true> { typedef float2 type; };
+template <class C> __device__ __forceinline__ C make_col(float g, float b, float z);
+template <> __device__ __forceinline__ float2 make_col<float2>(float g, float b, float) { return make_float2(g, b); }
+template <> __device__ __forceinline__ float4 make_col<float4>(float g, float b, float z) { return make_float4(g, b, z, 0.f); }
+__device__ __forceinline__ float col_z(const float2&) { return 0.f; }
+__device__ __forceinline__ float col_z(const float4& c) { return c.z; }
+template <bool AUX> struct ColOf { typedef float2 type; };
+template <> struct ColOf<true> { typedef float4 type; };
 
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.  One workgroup per 16x16 tile,
@@ -1384,12 +1379,12 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 #else
 #define SGS_PROF_MARK(acc) do { } while (0)
 #endif
+    if (st->overflow) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // blocks take the tiles longest queue first (k_tile_scan's order)
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
     if (blockIdx.x >= ntiles) return;    // workgroup-uniform
     const uint4 job = tile_order[blockIdx.x];        // (tile, first record, queue length) from k_tile_scan
-    if (st->overflow) return;            // (after the job load is issued: the two round trips overlap)
     const unsigned tile = job.x;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
@@ -1401,7 +1396,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     const float fpx = (float)px, fpy = (float)py;
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
-    const float amax = P.alpha_max, tmin = P.t_min, lmin = P.log2_alpha_min;
+    const float amax = P.alpha_max, tmin = P.t_min;
     const int tmin_bits = (int)__float_as_uint(tmin);
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
     const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
@@ -1601,7 +1596,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
             if (have) {
                 const float qmax = nD.y, hx = nC.w, hy = nD.x;      // log2(o / alpha_min); half extents of {alpha >= alpha_min}
                 SGS_PROF_STAGED_ALL()
-                SGS_STAGE(rank, nA, nB, nC, nD.y)
+                SGS_STAGE(rank, nA, nB, nC)
                 if (qmax > 0.0f) {
                     const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
                     const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
@@ -1719,7 +1714,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
                 if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
                 if (have) {
                     const float qmax = nD.y, hx = nC.w, hy = nD.x;
-                    SGS_STAGE((unsigned)tid, nA, nB, nC, nD.y)
+                    SGS_STAGE((unsigned)tid, nA, nB, nC)
                     if (qmax > 0.0f) {
                         const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
                         const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
