@@ -236,11 +236,14 @@ def main():
         own = sharded.g.render_target(0) if rows_primary else {"out": frame}      # (rows: rank 0's band of the even split)
         sel = [pose(W + i) for i in range(K)] if (rows_primary or world == 1) else [pose((W + i) * world) for i in range(K)]
         for p in sel:
-            r.render(cams[p], gs, timing=timing, **own)
+            r.render(cams[p], gs, timing=timing, **own)           # the kernels a sweep runs (no D_f bookkeeping): durations
             st = r.last_stats
             frame_ms.append(st["ms_total"])
             for n in STAGE_NAMES:
                 iso_ms[n].append(st["ms"][n])
+            r.render(cams[p], gs, stats=True, **own)              # the same frame once more, counting D_f: bytes and counts
+            st = r.last_stats
+            for n in STAGE_NAMES:
                 stage_bytes[n] += st["bytes"][n]
             for k in ("n_visible", "d_total", "d_fetched"):
                 counts[k] += st[k]

@@ -294,7 +294,7 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.win_rows = std::max(1, P.win_tiles / P.gx);
     P.n_windows = (row_end - row_begin + P.win_rows - 1) / P.win_rows;
     P.rec_capacity = L.rec_cap;
-    P.flags = cfg.flags | SGS_FLAG_STATS;
+    P.flags = cfg.flags;
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
         const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
         P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
@@ -397,8 +397,15 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
     if (ntiles > 0) {
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
-        if (out_aux) hipLaunchKernelGGL(sgs::k_tile_render<true>, dim3(grid, F), dim3(256), 0, stream, G);
-        else hipLaunchKernelGGL(sgs::k_tile_render<false>, dim3(grid, F), dim3(256), 0, stream, G);
+        // (D_f is counted only on request: the per-pixel bookkeeping and the end-of-tile reduction cost ~4 % of a sweep)
+        const bool count_df = (cfg.flags & SGS_FLAG_STATS) != 0;
+        if (out_aux) {
+            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<true, true>), dim3(grid, F), dim3(256), 0, stream, G);
+            else hipLaunchKernelGGL((sgs::k_tile_render<true, false>), dim3(grid, F), dim3(256), 0, stream, G);
+        } else {
+            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<false, true>), dim3(grid, F), dim3(256), 0, stream, G);
+            else hipLaunchKernelGGL((sgs::k_tile_render<false, false>), dim3(grid, F), dim3(256), 0, stream, G);
+        }
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
     SGS_HIP(ctx, hipGetLastError());

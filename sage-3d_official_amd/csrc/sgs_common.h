@@ -35,7 +35,7 @@
 #define SGS_RADIX_BITS 8
 #define SGS_RADIX (1 << SGS_RADIX_BITS)
 #define SGS_SORT_CLASSES 4
-#define SGS_PROF_WORDS 20            // profiling build: words per tile in the tile_prof buffer
+#define SGS_PROF_WORDS 24            // profiling build: words per tile in the tile_prof buffer
 #define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
 
 // Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).

@@ -1190,9 +1190,11 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     SGS_APPLY(o0, al0, r0) SGS_APPLY(o1, al1, r1) SGS_APPLY(o2, al2, r2) SGS_APPLY(o3, al3, r3)        \
     if (__ballot(T > 0.0f) == 0ull) {                                                                  \
         /* the wave's last pixel ended in this trip: replay it to find the splat that did it */        \
-        float Ts = Tb; unsigned last = 0u;                                                             \
-        SGS_REPLAY(o0, al0) SGS_REPLAY(o1, al1) SGS_REPLAY(o2, al2) SGS_REPLAY(o3, al3)                \
-        used = base + last;                                                                            \
+        if (STATS) {                                                                                   \
+            float Ts = Tb; unsigned last = 0u;                                                         \
+            SGS_REPLAY(o0, al0) SGS_REPLAY(o1, al1) SGS_REPLAY(o2, al2) SGS_REPLAY(o3, al3)            \
+            used = base + last;                                                                        \
+        }                                                                                              \
         wave_done = true; break;                                                                       \
     }
 // multi-batch groups: walk the quadrant's 64-bit masks with scalar bit scans
@@ -1207,7 +1209,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
                 SGS_TRIP(o0, o1, o2, o3)                                                               \
             }                                                                                          \
         }                                                                                              \
-        used = T > 0.0f ? base + m : used;       /* still live: the whole batch counts as examined */    \
+        if (STATS) used = T > 0.0f ? base + m : used;   /* still live: the whole batch counts as examined */ \
     }
 // single-batch groups (the common case): the wave first compacts ITS quadrant's splats into a private list of
 // staging offsets (in the idle s_sorted storage) — then the loop has no bit scans on the CU-shared scalar unit,
@@ -1231,7 +1233,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
             SGS_TRIP(o0, o1, o2, o3)                                                                   \
         }                                                                                              \
         (void)wave_done;                                                                               \
-        used = T > 0.0f ? base + m : used;                                                             \
+        if (STATS) used = T > 0.0f ? base + m : used;                                                  \
     }
 // staging: write splat J from its record (A_ = x,y,A,B  B_ = C,o,qcut,r  C_ = g,b,depth,hx) — a plain copy: k_preprocess
 // has folded every constant into the record
@@ -1334,7 +1336,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool AUX>
+template <bool AUX, bool STATS>
 __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
@@ -1370,7 +1372,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
-    unsigned long long pt_rank = 0, pt_bar1 = 0, pt_stage = 0;     // sub-phases of the single-batch path (pt_sort = the rest: barrier 2)
+    unsigned long long pt_rank = 0, pt_bar1 = 0, pt_stage = 0, pt_job = 0, pt_rec = 0;     // sub-phases of the single-batch path (pt_sort = the rest: barrier 2)
     unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
     const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
     __shared__ unsigned s_pe[6];
@@ -1385,6 +1387,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
     if (blockIdx.x >= ntiles) return;    // workgroup-uniform
     const uint4 job = tile_order[blockIdx.x];        // (tile, first record, queue length) from k_tile_scan
+#ifdef SGS_TILE_PROF
+    __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory");
+    pt_job = clock64() - pt0;      // kernel entry -> job (and the status word) arrived
+#endif
     const unsigned tile = job.x;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
@@ -1425,6 +1431,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
                 rq[r] = i < n ? rec[beg + i] : ~0ull;
             }
         }
+#ifdef SGS_TILE_PROF
+        __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory");
+        pt_rec = clock64() - pt0;  // ... -> the queue's records arrived (queues of <= SGS_QCAP)
+#endif
         if (!parted) {
             s_q[tid] = rq[0];                                              // n <= 256: one group, padded with ~0
             if (tid < 8) s_q[SGS_GROUP + tid] = ~0ull;
@@ -1760,7 +1770,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
         unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
-        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = 0;
+        o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = pt_job;
+        o[20] = pt_rec; o[21] = 0; o[22] = 0; o[23] = 0;
     }
 #endif
     if (inside) {
@@ -1772,7 +1783,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
             a[0] = Dz; a[1] = 1.0f - Tf;
         }
     }
-    if (P.flags & 4u) {                  // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
+    if (STATS) {                         // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
         const unsigned wu = wave_max(inside ? used : 0u);
         __syncthreads();
         if (lane == 0) s_used[wave] = wu;

@@ -204,8 +204,11 @@ class Renderer:
     def render(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None,
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
-               return_aux=False, pipelined=False, loose_cull=False, interleave=None, chunk_cull=True):
+               return_aux=False, pipelined=False, loose_cull=False, interleave=None, chunk_cull=True, stats=False):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
+
+        stats=True also counts D_f (records consumed by the composite; SGS_FLAG_STATS) — bookkeeping that costs a sweep ~4 %,
+        so it is opt-in; N_v, D and the stage times (timing=True) are always available.
 
         tile_rows=(r0,r1) renders only that band of 16-pixel tile rows (multi-GPU sharding); other rows
         of `out` are left untouched.  With `out_band` (a [>=band rows, W, 3] slab) only the band is
@@ -255,7 +258,7 @@ class Renderer:
         flags = (0 if sync else _capi.FLAG_ASYNC) | (_capi.FLAG_TIMING if timing else 0) | \
                 (_capi.FLAG_FULL_SORT if full_sort else 0) | \
                 (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
-                (0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL) | \
+                (0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL) | (_capi.FLAG_STATS if stats else 0) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
@@ -306,7 +309,7 @@ class Renderer:
         if any(c.height != h or c.width != w for c in cameras):
             raise ValueError("all cameras of a batch must share a resolution")
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
-        cfg = self._c_config(config)
+        cfg = self._c_config(config, _capi.FLAG_STATS if want_stats else 0)     # (D_f is counted on request only)
         if out_bands is not None:
             if out is not None:
                 raise ValueError("give out or out_bands, not both")

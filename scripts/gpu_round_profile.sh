@@ -54,7 +54,8 @@ for set_, log in (("default", "pmc_default_sq1.log"), ("k20", "pmc_k20_sq1.log")
     line = [l for l in open("$OUT/" + log) if l.startswith("{")][-1]
     tag = json.loads(line)["config"]["pose_set"]
     stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess"], "count": ["sgs::k_bin_count", "sgs::k_tile_scan"], "emit": ["sgs::k_bin_emit"],
-             "render": ["sgs::k_tile_render<false>"]}
+             # the instantiation a sweep runs (no aux output, no D_f bookkeeping), however the profiler spells it
+             "render": [k for k in d if k.startswith("sgs::k_tile_render<false") and not k.rstrip(">").endswith("true")]}
     t = {}
     for s, ks in stage.items():
         t[s] = sum((2.0 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024.0 for k in ks if k in d)

@@ -34,7 +34,9 @@ def alone(r, gs, chunk_cull=True, rows=None, n=24):
         st = r.last_stats
         for s in STAGES:
             acc[s] += st["ms"][s]
-        tot += st["ms_total"]; nv += st["n_visible"]; d += st["d_total"]; df += st["d_fetched"]
+        tot += st["ms_total"]; nv += st["n_visible"]; d += st["d_total"]
+        r.render(cams[p], gs, out=ring[0], chunk_cull=chunk_cull, stats=True, **kw)        # (D_f is counted on request only)
+        df += r.last_stats["d_fetched"]
     return {s: round(1e3 * acc[s] / n, 1) for s in STAGES}, round(1e3 * tot / n, 1), nv // n, d // n, df // n
 
 

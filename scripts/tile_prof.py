@@ -13,11 +13,12 @@ r = Renderer("cuda:0", record_capacity=96 << 20)
 gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
 out = {}
 for ci in (5, 20, 70, 140, 200):
+    r.render(cams[ci], gs, stats=True); d_f = r.last_stats["d_fetched"]      # (D_f is counted on request only)
     for _ in range(3):
-        r.render(cams[ci], gs, timing=True)
-    st = r.last_stats
-    p = r.debug_buffer(100, np.uint64).reshape(-1, 20).astype(np.float64)
-    n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, _ = p.T
+        r.render(cams[ci], gs, timing=True)                                   # the kernels a sweep runs
+    st = dict(r.last_stats); st["d_fetched"] = d_f
+    p = r.debug_buffer(100, np.uint64).reshape(-1, 24).astype(np.float64)
+    n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, pjob, prec = p.T[:21]
     clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
     print(f"cam {ci}: render {st['ms']['render']*1e3:.0f} us  D={st['d_total']} D_f={st['d_fetched']} | tile-cycles sum: part {part.sum()/1e6:.1f}M sort {sort.sum()/1e6:.1f}M blend {blend.sum()/1e6:.1f}M total {tot.sum()/1e6:.1f}M | "
           f"groups/tile {ng.mean():.2f} batches/tile {nb.mean():.2f} | max tile total {tot.max()/1e3:.0f}k cyc (n={int(n[tot.argmax()])}) | span {(t0+tot).max()-t0.min():.0f} cyc")
@@ -34,6 +35,7 @@ for ci in (5, 20, 70, 140, 200):
     q = np.quantile(rt1 - ev[0, 0], [0.5, 0.9, 0.99, 1.0]) / 100
     print(f"     tiles finished by: 50 % {q[0]:.0f} us, 90 % {q[1]:.0f} us, 99 % {q[2]:.0f} us, all {q[3]:.0f} us; tiles started after 50 % of the span: {100 * (rt0 - ev[0, 0] > 0.5 * span).mean():.1f} %")
     print(f"     single-batch path, cycle sums: rank (records resident -> ranked) {prank.sum()/1e6:.0f}M, barrier 1 {pbar1.sum()/1e6:.0f}M, stage (gather wait + extents + quadrant test) {pstage.sum()/1e6:.0f}M, barrier 2 {sort.sum()/1e6:.0f}M; partition {part.sum()/1e6:.0f}M; blend {blend.sum()/1e6:.0f}M; total {tot.sum()/1e6:.0f}M")
+    print(f"     start of a tile, mean cycles: entry -> job arrived {pjob.mean():.0f}, -> records arrived {prec.mean():.0f}, -> partitioned {part.mean():.0f}  (p90: {np.quantile(pjob,0.9):.0f}, {np.quantile(prec,0.9):.0f}, {np.quantile(part,0.9):.0f})")
     order = np.argsort(-tot)[:5]
     for o in order:
         print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])}")
@@ -41,4 +43,4 @@ for ci in (5, 20, 70, 140, 200):
     for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
         m = (n > lo) & (n <= hi)
         if m.any():
-            print(f"     n in ({lo},{hi}]: {m.sum()} tiles, mean cyc part {part[m].mean():.0f} sort {sort[m].mean():.0f} blend {blend[m].mean():.0f}")
+            print(f"     n in ({lo},{hi}]: {m.sum()} tiles, mean cyc job {pjob[m].mean():.0f} rec {prec[m].mean():.0f} part {part[m].mean():.0f} rank {prank[m].mean():.0f} stage {pstage[m].mean():.0f} sort {sort[m].mean():.0f} blend {blend[m].mean():.0f} total {tot[m].mean():.0f}")

@@ -68,8 +68,9 @@ class EmuRenderer:
         self.n = arrs[0].shape[0]
 
     def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
-               chunk_cull=True):
+               chunk_cull=True, stats=True):
         flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL
+        flags |= _capi.FLAG_STATS if stats else 0
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
         flags |= _capi.FLAG_LOOSE_CULL if loose_cull else 0
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,

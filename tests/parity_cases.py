@@ -45,6 +45,11 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     drv.upload(*scene)
     # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them
     img, st = drv.render(cam, cfg, rows)
+    # ... which counts D_f only on request (the drivers ask for it): the instantiation without the bookkeeping — the one
+    # a sweep runs — must produce the same frame from the same queues
+    img_plain, st_plain = drv.render(cam, cfg, rows, stats=False)
+    assert (img_plain == img).all() and st_plain["d_total"] == st["d_total"] and st_plain["n_visible"] == st["n_visible"] \
+        and st_plain["d_fetched"] == 0, f"{what}: the frame depends on whether D_f is counted"
     # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
     # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
     drv.row_records(0, reset=True)

@@ -31,7 +31,7 @@ class GpuDriver:
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
     def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False, interleave=None,
-               chunk_cull=True):
+               chunk_cull=True, stats=True):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
@@ -40,11 +40,11 @@ class GpuDriver:
             owned = len(range(interleave[1], (cam.height + 15) // 16, interleave[0]))
             band = self.torch.full((16 * owned, cam.width, 3), -1.0, dtype=self.torch.float32, device="cuda:0")
             img = self.r.render(c, self.scene, config=k, out_band=band, tile_rows=None if rows == (0, -1) else rows,
-                                full_sort=full_sort, loose_cull=loose_cull, interleave=interleave, chunk_cull=chunk_cull)
+                                full_sort=full_sort, loose_cull=loose_cull, interleave=interleave, chunk_cull=chunk_cull, stats=stats)
             return img.cpu().numpy(), self.r.last_stats
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
         img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
-                            full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull)
+                            full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull, stats=stats)
         return img.cpu().numpy(), self.r.last_stats
 
     def render_aux(self, cam, cfg=None):
@@ -225,8 +225,8 @@ def _check_frame_properties(drv, ocam, n_gauss, bands, stride=8, background=Fals
         d_sum += st_p["d_total"]
     assert (union == full).all() and d_sum == st_prod["d_total"]
     # (4) idempotence / determinism
-    again, _ = drv.render(ocam)
-    assert (again == full).all()
+    again, st_again = drv.render(ocam, stats=False)      # (and the instantiation that does not count D_f: what a sweep runs)
+    assert (again == full).all() and st_again["d_total"] == st_prod["d_total"] and st_again["d_fetched"] == 0
     # (5) lazy sort under reference binning consumes exactly as many records as the full sort did
     loose, st_loose = drv.render(ocam, loose_cull=True)
     assert (loose == full).all() and st_loose["d_fetched"] == st["d_fetched"]
