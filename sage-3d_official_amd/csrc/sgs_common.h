@@ -70,18 +70,23 @@ struct FrameParams {
 
 // Device-resident per-frame status; zeroed by a memset node at frame start, copied to pinned host
 // memory at frame end.
-struct FrameStatus {
-    uint32_t n_visible;             // N_v
+struct alignas(128) FrameStatus {
+    // line 0: written once by one kernel, read at the start of every workgroup of the kernels after it
+    uint32_t n_live;                // chunks that passed the per-chunk bounds (k_chunk_cull): length of the frame's live list
     uint32_t d_total;               // D
     uint32_t overflow;              // D > rec_capacity: emit/sort/composite did nothing
     uint32_t max_tile_len;
-    uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
-    unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
-    uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
+    uint32_t pad0_[12];
+    // line 1: counters that workgroups ADD to while others of the same kernel read line 0 (a device-scope atomic occupies
+    // its line in the fabric for ~12 ns: on one line the readers queued behind the adders)
+    uint32_t n_visible;             // N_v
     uint32_t n_big;                 // splats in the big-rect list (may exceed SGS_BIG_CAP; consumers clamp)
-    uint32_t n_live;                // chunks that passed the per-chunk bounds (k_chunk_cull): length of the frame's live list
-    uint32_t pad_[3];
+    unsigned long long d_fetched;   // D_f (SGS_FLAG_STATS)
+    uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
+    uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
+    uint32_t pad1_[7];
 };
+static_assert(sizeof(FrameStatus) == 128, "two cache lines");
 
 struct Splat;
 
