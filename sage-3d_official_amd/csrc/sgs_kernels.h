@@ -1315,7 +1315,7 @@ template <> struct ColOf<true> { typedef float4 type; };
 #define SGS_NB 256
 #define SGS_BUCKET_SHIFT 18
 #ifndef SGS_GROUP
-#define SGS_GROUP 256                 // soft cap of a group: buckets are added while the total stays below
+#define SGS_GROUP 192                 // soft cap of a group: buckets are added while the total stays below (192 vs 256: -1.3 % per frame, r02y)
 #endif
 #ifndef SGS_QCAP
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap

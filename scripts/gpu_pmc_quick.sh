@@ -1,23 +1,22 @@
 #!/bin/bash
-# two PMC passes (instruction mix + busy cycles) over the default frames, one frame at a time
+# quick PMC look at the frame's kernels (one frame at a time, 20 poses):  scripts/gpu_pmc_quick.sh <tag> COUNTER [COUNTER...]
+#   one rocprofv3 --pmc pass per counter argument (quote several names to put them into one pass)
 export TMPDIR=/tmp
-ROOT=$PWD
-OUT=$ROOT/gpurun_out/pmcq
-rm -rf $OUT; mkdir -p $OUT/pmc
+TAG=${1:-pq}; shift
+ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT/csv
 cd /tmp
-pmc() { local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/raw_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-events --no-pipeline --steps ${STEPS:-40} > $OUT/$name.log 2>&1
-  find $OUT/raw_$name -name "*counter_collection.csv" -exec cp {} $OUT/pmc/$name.csv \;
-  rm -rf $OUT/raw_$name; }
-pmc sq1 SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS
-pmc grbm GRBM_GUI_ACTIVE
-python $ROOT/scripts/pmc_summary.py $OUT/pmc 10 > $OUT/summary.json
+i=0
+for c in "$@"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/raw_$i -o p -- python $ROOT/bench.py --no-cpu-baseline --no-events --no-pipeline --steps 20 --warmup 2 > $OUT/pass_$i.log 2>&1
+  find $OUT/raw_$i -name "*counter_collection.csv" -exec cp {} $OUT/csv/p$i.csv \;
+  rm -rf $OUT/raw_$i
+done
+python $ROOT/scripts/pmc_summary.py $OUT/csv 4 > $OUT/pmc_summary.json
 python - <<PY
 import json
-d = json.load(open("$OUT/summary.json"))
+d = json.load(open("$OUT/pmc_summary.json"))
 for k, v in d.items():
-    if "sgs::" in k and "layout" not in k:
-        cyc = v["GRBM_GUI_ACTIVE"] / 8
-        print(f"{k.split('(')[0]:34s} {cyc/2.4e3:7.1f} us  VALU insts {v['SQ_INSTS_VALU']/1e6:6.1f}M  VALU busy {100*v['SQ_ACTIVE_INST_VALU']*4/1024/cyc:5.1f} %  "
-              f"SALU {v['SQ_INSTS_SALU']/1e6:5.1f}M  LDS {v['SQ_INSTS_LDS']/1e6:5.1f}M  waves/SIMD {v['SQ_WAVE_CYCLES']*4/1024/cyc:4.1f}  VALU-active cycles/SIMD {v['SQ_ACTIVE_INST_VALU']*4/1024/1e3:6.0f}k")
+    if "sgs::" in k and "layout" not in k and "bounds" not in k:
+        print(k, {c: round(x) for c, x in v.items()})
 PY
