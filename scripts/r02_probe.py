@@ -128,3 +128,11 @@ if what in ("iterate", "all"):
             print(f"world {world} iteration {it}: slowest {per.max():.4f} mean {per.mean():.4f} (x{full / per.max():.2f} of {full:.4f})  rows {[b - a for a, b in bands]}  {np.round(per, 3).tolist()}", flush=True)
             cost = timed_row_cost(bands, per, rec, cost)
             bands = balanced_partition(cost, world, 4 * -(-gy // world))
+
+if what == "batchfull":
+    # full frames through Renderer.render_batch (frame groups: SGS_GROUP frames per launch set on SGS_GROUP_LANES streams)
+    # against the per-frame pipelined path
+    r, gs = make(True)
+    gy = (H + 15) // 16
+    print(f"SGS_GROUP={os.environ.get('SGS_GROUP')} SGS_GROUP_LANES={os.environ.get('SGS_GROUP_LANES')}: per-frame pipelined {rate(r, gs):.4f} | "
+          f"render_batch x32 {rate_batch(r, gs, (0, gy), 32, 96):.4f} x20 {rate_batch(r, gs, (0, gy), 20, 100):.4f} ms/frame", flush=True)
