@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-events", action="store_true", help="do not bracket stages with HIP events")
-    ap.add_argument("--event-stride", type=int, default=4,
+    ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the stages of every n-th frame of the timed region with HIP events (recording them on "
                          "every frame costs ~4 %% of the sweep's throughput)")
     ap.add_argument("--no-pipeline", action="store_true",
