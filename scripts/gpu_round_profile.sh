@@ -18,10 +18,10 @@ trace() { # name args...
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1
   local db=$(find $OUT/raw_$name -name "*.db" | head -1)
   python $ROOT/scripts/rocpd_stats.py $db > $OUT/kernel_stats_$name.csv
-  python $ROOT/scripts/rocpd_timeline.py $db 0.04 0.34 > $OUT/timeline_$name.txt 2>/dev/null
+  python $ROOT/scripts/rocpd_timeline.py $db ${WIN:-0.04 0.34} > $OUT/timeline_$name.txt 2>/dev/null
   rm -rf $OUT/raw_$name
 }
-echo "== kernel trace (default command: frames in flight)"; trace pipelined
+echo "== kernel trace (default command: frames in flight)"; WIN="0.03 0.26" trace pipelined   # (warm-up 10 + 100 timed frames of ~410 frames launched)
 echo "== kernel trace (one frame at a time)"; trace alone --no-pipeline
 echo "== kernel trace (driver's command, one frame at a time)"; trace alone_k20 --no-pipeline --steps 20 --warmup 5
 echo "== kernel trace (config 5, one frame at a time)"; trace config5_alone --config 5 --no-pipeline --steps 40
