@@ -292,7 +292,7 @@ class Renderer:
         return out
 
     def render_batch(self, cameras: Sequence[Camera], gaussians, *, config: Optional[RenderConfig] = None,
-                     out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False,
+                     out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False, stats=False,
                      out_bands: Optional[torch.Tensor] = None, interleave=None):
         """B frames of one scene in ONE call into the library (camera-sweep batch): the frames go through the pipelined
         lanes, and the per-frame host work (stream fork, status clear / copy, completion) is paid once per batch.
@@ -300,7 +300,8 @@ class Renderer:
         out: [B,H,W,3] (allocated when omitted).  tile_rows=(r0,r1) renders only that band of every frame.  With
         `out_bands` — a [B, >= band rows, W, 3] tensor whose frames may be strided views, e.g. the slabs of a sharded
         sweep — only the band is stored, at the top of each slab.  interleave=(stride, phase) with out_bands renders the
-        owned tile rows of every frame into compact images (see render())."""
+        owned tile rows of every frame into compact images (see render()).  want_stats=True also returns every frame's
+        statistics (N_v, D, ...); D_f is in them only with stats=True (see render())."""
         scene = self._scene_of(gaussians)
         b = len(cameras)
         if b == 0:
@@ -309,7 +310,7 @@ class Renderer:
         if any(c.height != h or c.width != w for c in cameras):
             raise ValueError("all cameras of a batch must share a resolution")
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
-        cfg = self._c_config(config, _capi.FLAG_STATS if want_stats else 0)     # (D_f is counted on request only)
+        cfg = self._c_config(config, _capi.FLAG_STATS if stats else 0)     # (D_f is counted on request only: stats=True)
         if out_bands is not None:
             if out is not None:
                 raise ValueError("give out or out_bands, not both")

@@ -426,7 +426,13 @@ def test_batch_equals_single_frames(drv):
     for i, c in enumerate(cams):
         single = drv.r.render(c, scene)
         assert (batch[i] == single).all()
-        assert stats[i]["d_total"] == drv.r.last_stats["d_total"]
+        assert stats[i]["d_total"] == drv.r.last_stats["d_total"] and stats[i]["d_fetched"] == 0
+    # the same batch counting D_f (the other instantiation of the composite): same frames, D_f as one frame at a time
+    batch2, stats2 = drv.r.render_batch(cams, scene, want_stats=True, stats=True)
+    assert (batch2 == batch).all()
+    for i, c in enumerate(cams):
+        drv.r.render(c, scene, stats=True)
+        assert stats2[i]["d_fetched"] == drv.r.last_stats["d_fetched"] > 0
     scene.free()
 
 
