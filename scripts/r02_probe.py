@@ -136,3 +136,13 @@ if what == "batchfull":
     gy = (H + 15) // 16
     print(f"SGS_GROUP={os.environ.get('SGS_GROUP')} SGS_GROUP_LANES={os.environ.get('SGS_GROUP_LANES')}: per-frame pipelined {rate(r, gs):.4f} | "
           f"render_batch x32 {rate_batch(r, gs, (0, gy), 32, 96):.4f} x20 {rate_batch(r, gs, (0, gy), 20, 100):.4f} ms/frame", flush=True)
+
+if what == "bands8":
+    # the converged 8-rank bands of the sweep, every rank's band through render_batch x32 (env: SGS_GROUP, SGS_GROUP_LANES)
+    r, gs = make(True)
+    rows = [18, 8, 4, 4, 4, 4, 11, 15]
+    bands, a = [], 0
+    for n in rows:
+        bands.append((a, a + n)); a += n
+    per = np.array([rate_batch(r, gs, b, 32) for b in bands])
+    print(f"SGS_GROUP={os.environ.get('SGS_GROUP')} SGS_GROUP_LANES={os.environ.get('SGS_GROUP_LANES')} SGS_LANES={os.environ.get('SGS_LANES')}: slowest {per.max():.4f} mean {per.mean():.4f}  {np.round(per, 3).tolist()}", flush=True)
