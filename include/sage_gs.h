@@ -44,7 +44,8 @@ enum { SGS_BACKEND_CPU = 0, SGS_BACKEND_HIP = 1 };
 enum {
     SGS_FLAG_ASYNC  = 1u << 0,     /* do not synchronise the stream; collect with sgs_frame_sync() */
     SGS_FLAG_TIMING = 1u << 1,     /* bracket every stage with HIP events (fills sgs_stats.ms[]) */
-    SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite) */
+    SGS_FLAG_STATS  = 1u << 2,     /* also count D_f (records consumed by the composite): OFF by default — the per-pixel
+                                      bookkeeping costs a sweep ~6 %; sgs_stats.d_fetched and bytes[RENDER]'s D_f term are 0 without it */
     SGS_FLAG_FULL_SORT = 1u << 3,  /* tests: order every queue completely (the production path sorts
                                       lazily and stops once a tile's pixels have all terminated) */
     SGS_FLAG_LOOSE_CULL = 1u << 5, /* tests: bin every splat over S3's reference rect (the production path bins the part of it
