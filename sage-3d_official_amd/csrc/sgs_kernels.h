@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // (wave, splat) evaluations it let through had no pixel inside the cut-off).  This is the exact one: the minimum of
 //     q2(d) = A dx^2 + B dx dy + C dy^2        (the staged coefficients, q2 <= qmax  <=>  alpha >= alpha_min)
 // over the rectangle of a quadrant's pixel centres is 0 if the centre lies inside, else it is attained on one of
-// the four edges, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  The comparison carries a
+// the (at most two) edges facing the centre, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  The comparison carries a
 // bound on the rounding error of both this evaluation and the per-pixel one (a few ulps of the largest possible sum
 // of terms inside the quadrant), so a quadrant holding a pixel the blend would accept is never rejected (a NaN
 // anywhere accepts).
@@ -1271,15 +1271,21 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float xa = xs[2 * (q & 1)], xb = xs[2 * (q & 1) + 1], ya = ys[2 * (q >> 1)], yb = ys[2 * (q >> 1) + 1];
-        const bool inside = xa <= 0.0f && xb >= 0.0f && ya <= 0.0f && yb >= 0.0f;
-        const float m = fminf(fminf(sgs_edge_min(xa, ya, yb, A, B, C, kv), sgs_edge_min(xb, ya, yb, A, B, C, kv)),
-                              fminf(sgs_edge_min(ya, xa, xb, C, B, A, kh), sgs_edge_min(yb, xa, xb, C, B, A, kh)));
+        // (coordinates are relative to the centre: it lies between two edges when they straddle 0)
+        const bool in_x = xa <= 0.0f && xb >= 0.0f, in_y = ya <= 0.0f && yb >= 0.0f;
+        // q2 is convex with its minimum at the centre, so over a rectangle that does not hold the centre it is least on an
+        // edge that FACES the centre (at the minimiser -grad q2 is an outward normal, and q2 decreases towards the centre):
+        // the nearer vertical edge unless the centre is within the x range, the nearer horizontal one unless within the y range
+        const float ex = xa > 0.0f ? xa : xb, ey = ya > 0.0f ? ya : yb;
+        const float mv = in_x ? 3.0e38f : sgs_edge_min(ex, ya, yb, A, B, C, kv);
+        const float mh = in_y ? 3.0e38f : sgs_edge_min(ey, xa, xb, C, B, A, kh);
+        const float m = fminf(mv, mh);
         // every term of any evaluation inside this quadrant (edge minima here, per-pixel q2 in the blend) is bounded
         // by S: a few ulps of S cover the rounding of both sides of the comparison
         const float fx = fmaxf(fabsf(xa), fabsf(xb)), fy = fmaxf(fabsf(ya), fabsf(yb));      // farthest pixel of the quadrant
         const float S = A * fx * fx + aB * fx * fy + C * fy * fy;
         const float thr = qmax + 8.0e-6f * S + 1.0e-5f;
-        if (inside || !(m > thr)) bits |= 1u << q;
+        if ((in_x && in_y) || !(m > thr)) bits |= 1u << q;
     }
     return bits;
 }
