@@ -193,6 +193,217 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in) {
             double* d = reinterpret_cast<double*>(q);
 #pragma unroll
             for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) & 15]));
+        } else if (KIND == 40) {  // v_fma_f32 with a neg modifier
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c));
+        } else if (KIND == 41) {  // v_mul_f32 e64 with a neg modifier
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32_e64 %0, %1, -%0" : "+v"(a[i]) : "v"(b));
+        } else if (KIND == 42) {  // v_med3_f32 with an SGPR and an inline constant
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_med3_f32 %0, %0, s20, 0" : "+v"(a[i]) : : );
+        } else if (KIND == 43) {  // v_cmp_le_f32 vcc, sgpr, vgpr
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[i]) : "vcc");
+        } else if (KIND == 44) {  // v_exp_f32 e64 with neg
+#pragma unroll
+            for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32_e64 %0, -%0" : "+v"(a[i]));
+        } else if (KIND == 45) {  // the composite's alpha sequence (12 instructions per splat), four splats interleaved
+            for (int rep = 0; rep < 1; ++rep) {
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+2]) : "v"(a[4*0+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+2]) : "v"(a[4*1+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+2]) : "v"(a[4*2+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+2]) : "v"(a[4*3+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+2]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+2]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+2]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+2]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+3]) : "v"(a[4*0+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+3]) : "v"(a[4*1+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+3]) : "v"(a[4*2+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+3]) : "v"(a[4*3+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*0+3]) : "v"(a[4*0+1]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*1+3]) : "v"(a[4*1+1]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*2+3]) : "v"(a[4*2+1]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*3+3]) : "v"(a[4*3+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+3]) : "v"(a[4*0+0]), "v"(a[4*0+2]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+3]) : "v"(a[4*1+0]), "v"(a[4*1+2]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+3]) : "v"(a[4*2+0]), "v"(a[4*2+2]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+3]) : "v"(a[4*3+0]), "v"(a[4*3+2]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*0+0]) : "v"(a[4*0+3]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*1+0]) : "v"(a[4*1+3]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*2+0]) : "v"(a[4*2+3]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*3+0]) : "v"(a[4*3+3]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*0+0]) : "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*1+0]) : "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*2+0]) : "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*3+0]) : "v"(b));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*0+0]) : "v"(c));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*1+0]) : "v"(c));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*2+0]) : "v"(c));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*3+0]) : "v"(c));
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*0+3]) : "vcc");
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*1+3]) : "vcc");
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*2+3]) : "vcc");
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*3+3]) : "vcc");
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*3+0]) : : );
+            }
+        } else if (KIND == 46) {  // the exponent-domain alpha sequence (11 per splat), four splats interleaved
+            for (int rep = 0; rep < 1; ++rep) {
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+1]) : "v"(c), "v"(b));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+2]) : "v"(a[4*0+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+2]) : "v"(a[4*1+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+2]) : "v"(a[4*2+0]), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+2]) : "v"(a[4*3+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+2]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+2]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+2]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+2]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*0+3]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*1+3]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*2+3]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*3+3]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*0+3]) : "v"(a[4*0+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*1+3]) : "v"(a[4*1+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*2+3]) : "v"(a[4*2+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*3+3]) : "v"(a[4*3+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*0+3]) : "v"(a[4*0+0]), "v"(a[4*0+2]));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*1+3]) : "v"(a[4*1+0]), "v"(a[4*1+2]));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*2+3]) : "v"(a[4*2+0]), "v"(a[4*2+2]));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*3+3]) : "v"(a[4*3+0]), "v"(a[4*3+2]));
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*0+3]) : "vcc");
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*1+3]) : "vcc");
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*2+3]) : "vcc");
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*3+3]) : "vcc");
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*0+0]) : "v"(a[4*0+3]));
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*1+0]) : "v"(a[4*1+3]));
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*2+0]) : "v"(a[4*2+3]));
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*3+0]) : "v"(a[4*3+3]));
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*3+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*3+0]) : : );
+            }
+        } else if (KIND == 47) {  // alpha sequence, splat after splat
+            for (int rep = 0; rep < 1; ++rep) {
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+2]) : "v"(a[4*0+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+2]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+3]) : "v"(a[4*0+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*0+3]) : "v"(a[4*0+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+3]) : "v"(a[4*0+0]), "v"(a[4*0+2]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*0+0]) : "v"(a[4*0+3]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*0+0]) : "v"(b));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*0+0]) : "v"(c));
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*0+3]) : "vcc");
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+2]) : "v"(a[4*1+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+2]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+3]) : "v"(a[4*1+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*1+3]) : "v"(a[4*1+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+3]) : "v"(a[4*1+0]), "v"(a[4*1+2]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*1+0]) : "v"(a[4*1+3]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*1+0]) : "v"(b));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*1+0]) : "v"(c));
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*1+3]) : "vcc");
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+2]) : "v"(a[4*2+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+2]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+3]) : "v"(a[4*2+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*2+3]) : "v"(a[4*2+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+3]) : "v"(a[4*2+0]), "v"(a[4*2+2]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*2+0]) : "v"(a[4*2+3]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*2+0]) : "v"(b));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*2+0]) : "v"(c));
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*2+3]) : "vcc");
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+2]) : "v"(a[4*3+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+2]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+3]) : "v"(a[4*3+1]), "v"(c));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*3+3]) : "v"(a[4*3+1]));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+3]) : "v"(a[4*3+0]), "v"(a[4*3+2]));
+                asm volatile("v_exp_f32_e64 %0, -%1" : "=v"(a[4*3+0]) : "v"(a[4*3+3]));
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(a[4*3+0]) : "v"(b));
+                asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[4*3+0]) : "v"(c));
+                asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(a[4*3+3]) : "vcc");
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*3+0]) : : );
+            }
+        } else if (KIND == 48) {  // exponent-domain sequence, splat after splat
+            for (int rep = 0; rep < 1; ++rep) {
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*0+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*0+2]) : "v"(a[4*0+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*0+2]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*0+3]) : "v"(c), "v"(a[4*0+1]));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*0+3]) : "v"(a[4*0+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*0+3]) : "v"(a[4*0+0]), "v"(a[4*0+2]));
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*0+3]) : "vcc");
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*0+0]) : "v"(a[4*0+3]));
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*0+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*1+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*1+2]) : "v"(a[4*1+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*1+2]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*1+3]) : "v"(c), "v"(a[4*1+1]));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*1+3]) : "v"(a[4*1+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*1+3]) : "v"(a[4*1+0]), "v"(a[4*1+2]));
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*1+3]) : "vcc");
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*1+0]) : "v"(a[4*1+3]));
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*1+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*2+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*2+2]) : "v"(a[4*2+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*2+2]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*2+3]) : "v"(c), "v"(a[4*2+1]));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*2+3]) : "v"(a[4*2+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*2+3]) : "v"(a[4*2+0]), "v"(a[4*2+2]));
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*2+3]) : "vcc");
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*2+0]) : "v"(a[4*2+3]));
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*2+0]) : : );
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+0]) : "v"(b), "v"(c));
+                asm volatile("v_sub_f32 %0, %1, %2" : "=v"(a[4*3+1]) : "v"(c), "v"(b));
+                asm volatile("v_mul_f32 %0, %1, %2" : "=v"(a[4*3+2]) : "v"(a[4*3+0]), "v"(b));
+                asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[4*3+2]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_mul_f32_e64 %0, %1, -%2" : "=v"(a[4*3+3]) : "v"(c), "v"(a[4*3+1]));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[4*3+3]) : "v"(a[4*3+1]), "v"(b));
+                asm volatile("v_fma_f32 %0, -%1, %2, %0" : "+v"(a[4*3+3]) : "v"(a[4*3+0]), "v"(a[4*3+2]));
+                asm volatile("v_cmp_le_f32 vcc, s20, %0" : : "v"(a[4*3+3]) : "vcc");
+                asm volatile("v_exp_f32 %0, %1" : "=v"(a[4*3+0]) : "v"(a[4*3+3]));
+                asm volatile("v_med3_f32 %0, %0, s21, 0" : "+v"(a[4*3+0]) : : );
+                asm volatile("v_cndmask_b32 %0, 0, %0, vcc" : "+v"(a[4*3+0]) : : );
+            }
         }
     }
     float s = acc.x + cnt;
@@ -228,10 +439,12 @@ int main(int argc, char** argv) {
                            "s_and_b64 (dep)", "ds_read_b128 lane", "v_fma dep4", "v_fmac_f32", "cmp->sgpr+cndmask (x2)", "cmp vcc + s_and (x2)",
                            "v_cndmask e64 sgpr", "cmp vcc+cndmask e32 (x2)", "v_max_f32", "v_add_f32", "v_mov_b32", "v_and_b32", "v_log_f32", "v_rcp_f32",
                            "v_cmp e64 sgpr", "v_mad_u32_u24", "ds_read_b64 bcast", "ds_read_b32 bcast", "v_readfirstlane", "v_fma sgpr opnd", "v_sub_f32 sgpr e32",
-                           "v_mul literal", "s_ff1+s_bitset0 (x2)", "s_load_dwordx4", "exp|fma interleaved", "cmp,fma,fma,cndmask", "v_mov_dpp", "v_fma_f64"};
+                           "v_mul literal", "s_ff1+s_bitset0 (x2)", "s_load_dwordx4", "exp|fma interleaved", "cmp,fma,fma,cndmask", "v_mov_dpp", "v_fma_f64",
+                           "v_fma neg", "v_mul e64 neg", "v_med3 sgpr,0", "v_cmp_le vcc,sgpr", "v_exp e64 neg", "alpha x4 interleaved (48)", "alpha-exp x4 interleaved (44)", "alpha x4 sequential (48)", "alpha-exp x4 sequential (44)"};
     runfn fns[] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>,
                    run<13>, run<14>, run<15>, run<16>, run<17>, run<18>, run<19>, run<20>, run<21>, run<22>, run<23>, run<24>, run<25>,
-                   run<26>, run<27>, run<28>, run<29>, run<30>, run<31>, run<32>, run<33>, run<34>, run<35>, run<36>, run<37>, run<38>, run<39>};
+                   run<26>, run<27>, run<28>, run<29>, run<30>, run<31>, run<32>, run<33>, run<34>, run<35>, run<36>, run<37>, run<38>, run<39>,
+                   run<40>, run<41>, run<42>, run<43>, run<44>, run<45>, run<46>, run<47>, run<48>};
     printf("%-26s", names[kind]);
     for (int wps : {1, 6}) {
         const float base = run<0>(wps, out, in);
