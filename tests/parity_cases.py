@@ -127,6 +127,39 @@ def case_ragged(drv):
         check_against_oracle(drv, scene, cam, what=f"ragged n={n} {w}x{h}")
 
 
+def case_fuzz(drv, seeds, max_n=700):
+    """Seeded random small frames through the full comparison: scene size, resolution (ragged tiles), SH degree, splat
+    sizes from sub-pixel to screen-filling, opacities down to the cut-off, cameras inside and outside the cloud (Gaussians
+    behind the camera, across the near plane, off screen), non-default thresholds / dilation / background, and a band of
+    tile rows now and then."""
+    for seed in seeds:
+        rng = np.random.default_rng(10_000 + seed)
+        n = int(rng.integers(1, max_n))
+        w, h = int(rng.integers(17, 260)), int(rng.integers(17, 160))
+        deg = int(rng.integers(0, 4))
+        lo = float(10 ** rng.uniform(-2.7, -1.0)); hi = lo * float(10 ** rng.uniform(0.3, 2.0))
+        scene = random_scene(n, 20_000 + seed, deg, box=((-3, 3), (-2, 2), (-1, 9)), scale=(lo, min(hi, 3.0)),
+                             opac_mu=float(rng.uniform(-3.0, 2.0)))
+        eye = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(-3, 6)])
+        target = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(3, 8)])
+        if np.linalg.norm(target - eye) < 0.5:
+            target = eye + np.array([0.1, 0.0, 1.0])
+        down = np.array([rng.normal(0, 0.3), 1.0, rng.normal(0, 0.3)])
+        view = look_at_view(eye, target, down)
+        f = float(w * rng.uniform(0.35, 1.6))
+        cam = onp.Camera(w, h, f, f * float(rng.uniform(0.9, 1.1)), w / 2.0 + float(rng.uniform(-3, 3)),
+                         h / 2.0 + float(rng.uniform(-3, 3)), view)
+        cfg = onp.Config(near=float(rng.choice([0.2, 0.05, 0.5])), dilation=float(rng.choice([0.3, 0.1, 0.6])),
+                         alpha_min=float(rng.choice([1.0 / 255.0, 0.01, 0.002])), alpha_max=float(rng.choice([0.99, 0.9])),
+                         t_min=float(rng.choice([1.0e-4, 1.0e-3])), background=tuple(float(v) for v in rng.uniform(0, 1, 3)),
+                         sh_degree=int(rng.integers(0, deg + 1)) if rng.random() < 0.3 else -1)
+        gy = (h + 15) // 16
+        rows = (0, -1)
+        if gy >= 3 and rng.random() < 0.3:
+            r0 = int(rng.integers(0, gy - 1)); rows = (r0, int(rng.integers(r0 + 1, gy + 1)))
+        check_against_oracle(drv, scene, cam, cfg, rows, what=f"fuzz seed {seed} (n={n} {w}x{h} deg {deg} rows {rows})")
+
+
 def case_padding_lanes(drv):
     """N not a multiple of 64 with a camera looking down -z: the padding lanes of the last chunk must stay
     culled (their placeholder mean projects to a huge POSITIVE depth for such a view)."""

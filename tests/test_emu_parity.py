@@ -28,6 +28,10 @@ def test_ragged_sizes(drv):
     pc.case_ragged(drv)
 
 
+def test_seeded_random_frames(drv):
+    pc.case_fuzz(drv, range(8))
+
+
 def test_padding_lanes_stay_culled(drv):
     pc.case_padding_lanes(drv)
 
