@@ -157,7 +157,19 @@ def case_fuzz(drv, seeds, max_n=700):
         rows = (0, -1)
         if gy >= 3 and rng.random() < 0.3:
             r0 = int(rng.integers(0, gy - 1)); rows = (r0, int(rng.integers(r0 + 1, gy + 1)))
+        if seed % 4 == 0:            # default constants and the whole frame: also the depth / coverage outputs (f-4)
+            cfg, rows = None, (0, -1)
         check_against_oracle(drv, scene, cam, cfg, rows, what=f"fuzz seed {seed} (n={n} {w}x{h} deg {deg} rows {rows})")
+        if seed % 4 == 0:
+            rgb0, _ = drv.render(cam)
+            rgb, aux = drv.render_aux(cam)
+            assert (rgb == rgb0).all(), f"fuzz seed {seed}: the aux instantiation changed the colours"
+            ref, o = oracle_c.render(*scene, cam)
+            safe = o["margin"] >= 1e-4
+            zmax = max(1.0, float(np.max(o["depth_image"])))
+            if safe.any():
+                assert np.abs(aux[..., 0] - o["depth_image"])[safe].max() < 1e-3 * zmax, f"fuzz seed {seed}: depth"
+                assert np.abs(aux[..., 1] - (1.0 - o["final_T"]))[safe].max() < 1e-3, f"fuzz seed {seed}: coverage"
 
 
 def case_padding_lanes(drv):
