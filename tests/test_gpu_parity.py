@@ -440,6 +440,12 @@ def test_batch_equals_single_frames(drv):
     scene.free()
 
 
+def test_issue_paths_agree_on_random_scenes(drv):
+    """Synchronous, pipelined, batched and banded frames of random scenes at random resolutions: the same bits."""
+    from gpu_stress import stress_issue_paths
+    assert stress_issue_paths(drv.r, 6, 123) == 0
+
+
 def test_pipelined_frames_equal_sequential_frames(drv):
     """SGS_FLAG_PIPELINED: frames in flight on the library's lanes (own streams, own intermediates) must
     produce exactly the frames that one-at-a-time rendering produces, also when ordinary frames are mixed in."""
