@@ -7,7 +7,7 @@
 //   k_bin_count      S4: per-workgroup LDS tile histograms -> one global atomic per touched tile
 //   k_tile_scan      S4: exclusive scan of the per-tile counts, longest-queue-first render order
 //   k_bin_emit       S4: duplication of each splat into the queues of the tiles it can reach
-//   k_tile_render    S5+S6 fused: per-tile MSD bucket partition, lazy rank sort of ~256-record groups (ties -> index),
+//   k_tile_render    S5+S6 fused: per-tile MSD bucket partition, lazy rank sort of ~192-record groups (ties -> index),
 //                    front-to-back alpha composite of LDS-staged batches
 //   k_pack_rgba8     fp32 RGB -> uint8 RGBA (get_rgba()-shaped surface)
 //
