@@ -158,9 +158,9 @@ def main():
     # frames of the sweep are independent: up to four are in flight per GPU, each with its own output buffer
     frames = [torch.zeros((height, width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
     frame = frames[0]
-    sharded = None
+    sharded = sharded_f32 = None
     if world > 1:
-        sharded = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
+        sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
 
     def fence():
         torch.cuda.synchronize(device)
@@ -176,9 +176,10 @@ def main():
                      timing=timed and i % max(1, args.event_stride) == 0, pipelined=pipelined)
         return r.sync() if count else None                # completes the frames in flight (all lanes)
 
-    def run_rows(first, count, timed):
+    def run_rows(first, count, timed, sharded=None):
         """`count` frames, each sharded by tile row over all ranks and gathered to rank 0 (RCCL): the bands of `batch`
         frames are rendered through the pipelined lanes and travel in one asynchronous exchange, double-buffered."""
+        sharded = sharded or sharded_f32
         acc, n_acc, i = None, 0, 0
         while i < count:
             nb = min(sharded.batch, count - i) if pipelined else 1
@@ -374,6 +375,33 @@ def main():
         guard.cancel()
         if rank == 0:
             out["also_measured"] = pre_second
+        if args.bands != "interleave":
+            # the same sweep with the bands travelling as uint8 RGBA (what get_rgba() hands the reference's callers): a third
+            # of the bytes into rank 0.  Same watchdog rule: the line above is printed whatever happens here.
+            done8 = threading.Event()
+
+            def bail8():
+                if not done8.is_set():
+                    if rank == 0:
+                        out["also_measured"]["rows_rgba8"] = {"error": f"still running after {args.secondary_timeout:.0f} s; abandoned"}
+                        print(json.dumps(out), flush=True)
+                    os._exit(0)
+
+            t8 = threading.Timer(args.secondary_timeout, bail8)
+            t8.daemon = True
+            t8.start()
+            try:
+                sharded8 = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8")
+                dt8, _ = measure(lambda f, c, t: run_rows(f, c, t, sharded8), W, K, False)
+                third = {"value": K / dt8, "unit": "frames/s", "steps": K, "ms_per_step": 1e3 * dt8 / K, "scaling": "strong",
+                         "parallelism": f"tile-row shard x{world} ({bands_desc}), bands packed to uint8 RGBA on every rank, RCCL gatherv "
+                                        f"of 4-byte pixels to rank 0" if rank == 0 else ""}
+            except Exception as e:       # noqa: BLE001
+                third = {"error": f"{type(e).__name__}: {e}"[:300]}
+            done8.set()
+            t8.cancel()
+            if rank == 0:
+                out["also_measured"]["rows_rgba8"] = third
     elif world > 1 and not args.no_secondary:
         import threading
         finished = threading.Event()

@@ -352,8 +352,9 @@ class Renderer:
             return ret, [s.as_dict() for s in stats]
         return ret
 
-    def pack_rgba8(self, rgb: torch.Tensor, tonemap: Optional[str] = None) -> torch.Tensor:
-        """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns.
+    def pack_rgba8(self, rgb: torch.Tensor, tonemap: Optional[str] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """float32 [H,W,3] -> uint8 [H,W,4] (alpha 255): the array shape cam.get_rgba() returns.  `out`: a contiguous uint8
+        [H,W,4] tensor on the device to write into (e.g. a band of a frame buffer).
 
         tonemap="reinhard" applies x / (1 + x) first — the operator the reference's stage selects
         (Data/template.usda:102,196).  An optional host-side op, off by default and outside the
@@ -363,7 +364,10 @@ class Renderer:
                 raise ValueError("tonemap must be None or 'reinhard'")
             rgb = rgb / (1.0 + rgb.clamp_min(0.0))
         h, w = int(rgb.shape[0]), int(rgb.shape[1])
-        out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        if out is None:
+            out = torch.empty((h, w, 4), dtype=torch.uint8, device=self.device)
+        elif (out.device != self.device or out.dtype != torch.uint8 or not out.is_contiguous() or tuple(out.shape) != (h, w, 4)):
+            raise ValueError("out must be a contiguous uint8 [H,W,4] tensor on the renderer's device")
         self._lib.check(self._lib.sgs_pack_rgba8(self._ctx, rgb.contiguous().data_ptr(), out.data_ptr(), w, h,
                                                  self._stream()), self._ctx)
         return out

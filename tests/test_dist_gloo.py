@@ -267,6 +267,12 @@ class _RowCopyRenderer:
     def sync(self):
         return {"ms": {}, "ms_total": 0.0}
 
+    def pack_rgba8(self, rgb, tonemap=None, out=None):
+        """csrc k_pack_rgba8: clamp to [0,1], x * 255 + 0.5 in fp32, truncate; alpha 255."""
+        out[..., :3] = (rgb.clamp(0.0, 1.0) * 255.0 + 0.5).to(torch.uint8)
+        out[..., 3] = 255
+        return out
+
     def row_records(self, n_rows, reset=True):
         out = self.acc[:n_rows].copy()
         if reset:
@@ -284,7 +290,14 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
         # records per row: a moving "horizon" peak
         costs = np.array([[2000 + 60000 * np.exp(-0.5 * ((r - (2 + 0.4 * c)) / 1.0) ** 2) for r in range(gy)] for c in range(n_frames)]).astype(np.int64)
         rr = _RowCopyRenderer(frames, costs)
-        sr = ShardedRenderer(rr, h, w, batch=3, interleave=(mode == "interleave"), balance=(mode == "balance"))
+        rgba8 = mode.startswith("rgba8")
+        sr = ShardedRenderer(rr, h, w, batch=3, interleave=(mode == "interleave"), balance=mode.endswith("balance"),
+                             output="rgba8" if rgba8 else "float32")
+        if rgba8:            # what rank 0 must end up with: the un-sharded frames, packed
+            packed = torch.zeros((n_frames, h, w, 4), dtype=torch.uint8)
+            for c in range(n_frames):
+                rr.pack_rgba8(frames[c], out=packed[c])
+            frames = packed
         ok = True
         # single frames
         for c in (0, 4):
@@ -315,7 +328,7 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
         gathered = [None] * world
         dist.all_gather_object(gathered, bands_seen)
         ok = ok and all(b == gathered[0] for b in gathered)
-        if mode == "balance":
+        if mode.endswith("balance"):
             even = tuple(row_partition(gy, world))
             # first batch even, later ones re-cut from the measured band times spread over the rows by their records
             # (timed_row_cost: the times are wall-clock, so only the structure is checked — a valid partition, the same on
@@ -332,6 +345,7 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "interleave"), (2, "balance"), (3, "balance")])
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "interleave"), (2, "balance"), (3, "balance"),
+                                        (2, "rgba8"), (3, "rgba8-balance")])
 def test_sharded_renderer_host_logic_gloo(world, mode):
     assert _spawn(_sharded_worker, world, 150, 72, mode) is True

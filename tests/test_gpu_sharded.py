@@ -32,15 +32,20 @@ def _worker(rank, world, port, mode, n_gauss, res, q):
         cams = scenes.room_cameras(sc, w, h, n_positions=1, n_yaw=10, seed=1)
         r = Renderer("cuda:0")
         scene = r.upload(scenes.to_gaussians(sc, "cuda:0"))
-        sr = ShardedRenderer(r, h, w, batch=4, interleave=(mode == "interleave"), balance=(mode == "balance"))
+        rgba8 = mode.startswith("rgba8")
+        sr = ShardedRenderer(r, h, w, batch=4, interleave=(mode == "interleave"), balance=mode.endswith("balance"),
+                             output="rgba8" if rgba8 else "float32")
         ok, notes = True, []
         whole = [r.render(c, scene).clone() for c in cams] if rank == 0 else None      # the un-sharded HIP frames
+        if rgba8 and rank == 0:                     # bands travel as bytes: rank 0 must hold pack_rgba8 of the un-sharded frame
+            whole = [r.pack_rgba8(f) for f in whole]
+        chans = 4 if rgba8 else 3
         # one frame at a time (the latency mode)
         for i in (0, 3):
             f = sr.render(cams[i], scene)
             if rank == 0:
                 same = bool((f == whole[i]).all())
-                ok = ok and same and tuple(f.shape) == (h, w, 3)
+                ok = ok and same and tuple(f.shape) == (h, w, chans)
                 if not same:
                     notes.append(f"render cam {i}: {(f != whole[i]).sum().item()} values differ")
         # a sweep: batches of 4 (last partial), two exchanges in flight
@@ -69,7 +74,7 @@ def _worker(rank, world, port, mode, n_gauss, res, q):
                     ok = ok and same
                     if not same:
                         notes.append(f"batch(tail) cam {i}: {(g0.frame(j) != whole[i]).sum().item()} values differ")
-        if mode == "balance":
+        if mode.endswith("balance"):
             even = tuple(row_partition((h + 15) // 16, world))
             ok = ok and bands_seen[0] == even and any(b != even for b in bands_seen[1:])
             notes.append(f"bands {bands_seen}")
@@ -83,7 +88,8 @@ def _worker(rank, world, port, mode, n_gauss, res, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "balance"), (2, "interleave"), (3, "interleave")])
+@pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "balance"), (2, "interleave"), (3, "interleave"),
+                                        (3, "rgba8-balance")])
 def test_sharded_renderer_on_one_gpu(world, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
