@@ -162,6 +162,8 @@ def main():
     if world > 1:
         sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
 
+    warming = [False]
+
     def fence():
         torch.cuda.synchronize(device)
         if world > 1:
@@ -183,6 +185,8 @@ def main():
         acc, n_acc, i = None, 0, 0
         while i < count:
             nb = min(sharded.batch, count - i) if pipelined else 1
+            if warming[0] and nb > 2:          # warm-up: several short batches, so that the bands are re-cut a few times
+                nb = max(2, -(-count // 4))    # (every batch ends with one re-balancing step) before the timed sweep starts
             batch_cams = [cams[pose(first + i + j)] for j in range(nb)]
             sharded.last_stats = None
             if pipelined:
@@ -210,7 +214,9 @@ def main():
 
     def measure(runner, n_warm, n_steps, timed):
         """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize fences; max over ranks."""
+        warming[0] = True
         runner(0, n_warm, False)
+        warming[0] = False
         fence()
         t0 = time.perf_counter()
         st = runner(n_warm, n_steps, timed)
