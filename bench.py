@@ -187,6 +187,9 @@ def main():
             nb = min(sharded.batch, count - i) if pipelined else 1
             if warming[0] and nb > 2:          # warm-up: several short batches, so that the bands are re-cut a few times
                 nb = max(2, -(-count // 4))    # (every batch ends with one re-balancing step) before the timed sweep starts
+            elif pipelined and count <= sharded.batch:
+                nb = min(nb, max(8, -(-count // 2)))   # a short sweep in two batches: the first one's exchange travels while
+                                                       # the second is rendered (one batch would render, THEN send)
             batch_cams = [cams[pose(first + i + j)] for j in range(nb)]
             sharded.last_stats = None
             if pipelined:
