@@ -925,7 +925,9 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
             const Splat& sp = tmp[(size_t)i];
             float* o = (float*)((char*)host_dst + i * elem);
             o[0] = sp.x; o[1] = sp.y;
-            o[2] = (float)((double)sp.A / (0.5 * l2e)); o[3] = (float)((double)sp.B / l2e); o[4] = (float)((double)sp.C / (0.5 * l2e));
+            // (the record holds the completed square A (dx + k dy)^2 + C' dy^2 in the slots A, B, C: B = 2 A k, C = A k^2 + C')
+            const double A_ = sp.A, k_ = sp.B, Cp_ = sp.C;
+            o[2] = (float)(A_ / (0.5 * l2e)); o[3] = (float)(2.0 * A_ * k_ / l2e); o[4] = (float)((A_ * k_ * k_ + Cp_) / (0.5 * l2e));
             o[5] = sp.o; o[6] = sp.r; o[7] = sp.g; o[8] = sp.b;
             memcpy(o + 9, &sp.key, 4); memcpy(o + 10, &sp.rect01, 4); memcpy(o + 11, &sp.rect23, 4);
         }

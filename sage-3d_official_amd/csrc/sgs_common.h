@@ -119,8 +119,9 @@ struct FrameGroup {
 // k_preprocess (at the Gaussian's ORIGINAL index: with the scene in Z-order that is a scatter, and a 48-B record
 // straddling sectors made every such write a read-modify-write) and gathered by k_tile_render.  Everything the composite
 // needs per (splat, tile) that does not depend on the tile is computed here once, per splat:
-//   word 0..3   x, y, A, B            q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e):  A = conic_a log2(e)/2, B = conic_b log2(e)
-//   word 4..7   C, opacity, qcut, r   qcut = bits(log2(opacity / alpha_min)) + 1 (0 when below alpha_min)
+//   word 0..3   x, y, A, k            q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e)  (A = conic_a log2(e)/2, B = conic_b log2(e), ...)
+//                                     stored as the completed square A (dx + k dy)^2 + C' dy^2:  k = B / 2A in the slot `B`,
+//   word 4..7   C', opacity, qcut, r  C' = C - B^2 / 4A in the slot `C`;  qcut = bits(log2(opacity / alpha_min)) + 1 (0 when below alpha_min)
 //   word 8..11  g, b, depth bits, hx  hx, hy = half extents of the ellipse {alpha >= alpha_min}, padded outward
 //   word 12..15 hy, qmax, rect x0|y0<<16, rect x1|y1<<16     qmax = log2(opacity / alpha_min); rect = S3's reference rect (tests)
 struct alignas(64) Splat {

@@ -441,8 +441,17 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         // the record of the composite (sgs_common.h): constants folded per splat, not per (splat, tile) or per pixel
         const unsigned qcut = qmax >= 0.0f ? __float_as_uint(qmax) + 1u : 0u;
         float4* sp = reinterpret_cast<float4*>(splats + slot);
-        sp[0] = make_float4(sx, sy, (0.5f * SGS_LOG2E) * ca, SGS_LOG2E * cb);
-        sp[1] = make_float4((0.5f * SGS_LOG2E) * cc, g0.w, __uint_as_float(qcut), r);
+        // q2 = -power * log2(e) = A dx^2 + B dx dy + C dy^2 with the fp32 conic (ca, cb, cc) — the form S6 defines — is stored as
+        // the completed square  A (dx + k dy)^2 + C' dy^2,  k = B / 2A,  C' = C - B^2 / 4A = det / A,  derived in fp64 FROM the
+        // fp32 conic: two non-negative terms instead of three that cancel.  A needle (sigma_minor ~ 0.55 px from the dilation,
+        // sigma_major hundreds of pixels) evaluated far along its axis has A dx^2 ~ 1e6 cancelling to q2 ~ 1; the three-term
+        // form in fp32 then carries an error of ~0.1 in the exponent (found by the wild fuzz cases), this one ~1e-4.
+        const double A64 = (0.5 * 1.4426950408889634) * (double)ca, B64 = 1.4426950408889634 * (double)cb,
+                     C64 = (0.5 * 1.4426950408889634) * (double)cc;
+        const double iA = A64 > 0.0 ? 1.0 / A64 : 0.0;
+        const double k64 = 0.5 * B64 * iA, Cp64 = C64 - 0.25 * B64 * B64 * iA;
+        sp[0] = make_float4(sx, sy, (float)A64, (float)k64);
+        sp[1] = make_float4((float)Cp64, g0.w, __uint_as_float(qcut), r);
         sp[2] = make_float4(g, b, depth, ext_x);
         sp[3] = make_float4(ext_y, qmax, __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
@@ -1119,6 +1128,8 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // per-pixel work is written for the smallest issue count rather than the fewest flops:
 //   * staging folds every constant into the splat (per splat, not per pixel):
 //         A = ca * log2(e)/2,  B = cb * log2(e),  C = cc * log2(e)/2      q2 = A dx^2 + B dx dy + C dy^2 = -power * log2(e)
+//         stored as the completed square  q2 = A (dx + k dy)^2 + C' dy^2,  k = B / 2A,  C' = C - B^2 / 4A  (k_preprocess: the
+//         same instruction count, and no cancellation between large terms for needle-shaped splats)
 //         qcut = bits(log2(o / alpha_min)) + 1
 //     so alpha = o * 2^-q2 needs no scaling, and BOTH skip tests of S6 are one unsigned compare:
 //         power <= 0  and  alpha >= alpha_min   <=>   bits(q2) < qcut     (a negative q2 has the sign bit set);
@@ -1129,7 +1140,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 //   * D_f (how far into the queue the tile's pixels read) is not tracked per splat: when a trip leaves a wave with
 //     no live pixel — once per wave and tile — the trip is replayed from the saved T to find the splat that ended
 //     the last pixel.
-// s_a[j] = (x, y, A, B)   s_b[j] = (C, o, qcut, r)   s_c[j] = (g, b[, view depth, 0])
+// s_a[j] = (x, y, A, k)   s_b[j] = (C', o, qcut, r)   s_c[j] = (g, b[, view depth, 0])
 // A wave walks the splats of the batch that can touch ITS quadrant four per trip: the four alphas are
 // independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
 // is applied in depth order.  Predicates stay on the VALU (compare -> select).  A short tail reads the inert
@@ -1160,7 +1171,8 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     {                                                                                                  \
         const float4 qa = SGS_AT(s_a, float4, O), qb = SGS_AT(s_b, float4, O);                         \
         const float dx = qa.x - fpx, dy = qa.y - fpy;                                                  \
-        const float q2 = __builtin_fmaf(dx, __builtin_fmaf(qa.w, dy, qa.z * dx), (qb.x * dy) * dy);    \
+        const float u = __builtin_fmaf(qa.w, dy, dx);                                                  \
+        const float q2 = __builtin_fmaf(qa.z * u, u, (qb.x * dy) * dy);         /* A u^2 + C' dy^2 */  \
         const bool valid = __float_as_uint(q2) < __float_as_uint(qb.z);   /* S6: power <= 0 and alpha >= 1/255 */ \
         const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
         AL = valid ? a : 0.0f;                                                                         \
@@ -1251,7 +1263,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // ---- which 8x8 quadrants of the tile can a splat reach? -------------------------------------------------
 // The axis-aligned extent of {alpha >= alpha_min} is a loose test for elongated splats (measured: 27 % of the
 // (wave, splat) evaluations it let through had no pixel inside the cut-off).  This is the exact one: the minimum of
-//     q2(d) = A dx^2 + B dx dy + C dy^2        (the staged coefficients, q2 <= qmax  <=>  alpha >= alpha_min)
+//     q2(d) = A dx^2 + B dx dy + C dy^2        (B = 2 A k, C = A k^2 + C' of the staged record; q2 <= qmax  <=>  alpha >= alpha_min)
 // over the rectangle of a quadrant's pixel centres is 0 if the centre lies inside, else it is attained on one of
 // the (at most two) edges facing the centre, where q2 is a 1-D parabola (minimiser -B e / 2C, clamped to the edge).  The comparison carries a
 // bound on the rounding error of both this evaluation and the per-pixel one (a few ulps of the largest possible sum
@@ -1261,9 +1273,11 @@ __device__ __forceinline__ float sgs_edge_min(float e, float d0, float d1, float
     const float t = __builtin_amdgcn_fmed3f(k * e, d0, d1);
     return (P_ * e + B_ * t) * e + (R_ * t) * t;
 }
-__device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float B, float C, float qmax) {
-    // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15]
-    const float kv = (-0.5f * B) * SGS_RCP(C), kh = (-0.5f * B) * SGS_RCP(A);   // (an ulp off the minimiser changes the minimum by O(ulp^2))
+__device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float k, float Cp, float qmax) {
+    // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15].
+    // The record holds the completed square A (dx + k dy)^2 + C' dy^2: B = 2 A k, C = A k^2 + C'.
+    const float Ak = A * k, B = 2.0f * Ak, C = __builtin_fmaf(Ak, k, Cp);
+    const float kv = -Ak * SGS_RCP(C), kh = -k;        // the edge minimisers -B e / 2C and -B e / 2A (an ulp off changes the minimum by O(ulp^2))
     const float xs[4] = {0.0f - rx, 7.0f - rx, 8.0f - rx, 15.0f - rx};
     const float ys[4] = {0.0f - ry, 7.0f - ry, 8.0f - ry, 15.0f - ry};
     const float aB = fabsf(B);

@@ -127,7 +127,7 @@ def case_ragged(drv):
         check_against_oracle(drv, scene, cam, what=f"ragged n={n} {w}x{h}")
 
 
-def case_fuzz(drv, seeds, max_n=700):
+def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
     """Seeded random small frames through the full comparison: scene size, resolution (ragged tiles), SH degree, splat
     sizes from sub-pixel to screen-filling, opacities down to the cut-off, cameras inside and outside the cloud (Gaussians
     behind the camera, across the near plane, off screen), non-default thresholds / dilation / background, and a band of
@@ -135,10 +135,12 @@ def case_fuzz(drv, seeds, max_n=700):
     for seed in seeds:
         rng = np.random.default_rng(10_000 + seed)
         n = int(rng.integers(1, max_n))
-        w, h = int(rng.integers(17, 260)), int(rng.integers(17, 160))
+        w, h = int(rng.integers(17, max_res[0])), int(rng.integers(17, max_res[1]))
         deg = int(rng.integers(0, 4))
         lo = float(10 ** rng.uniform(-2.7, -1.0)); hi = lo * float(10 ** rng.uniform(0.3, 2.0))
-        scene = random_scene(n, 20_000 + seed, deg, box=((-3, 3), (-2, 2), (-1, 9)), scale=(lo, min(hi, 3.0)),
+        if wild:                     # needles and pancakes up to the size of the scene, specks far below a pixel
+            lo = float(10 ** rng.uniform(-4.0, -1.0)); hi = lo * float(10 ** rng.uniform(0.3, 4.0))
+        scene = random_scene(n, 20_000 + seed, deg, box=((-3, 3), (-2, 2), (-1, 9)), scale=(lo, min(hi, 20.0 if wild else 3.0)),
                              opac_mu=float(rng.uniform(-3.0, 2.0)))
         eye = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(-3, 6)])
         target = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(3, 8)])
