@@ -142,13 +142,18 @@ def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
             lo = float(10 ** rng.uniform(-4.0, -1.0)); hi = lo * float(10 ** rng.uniform(0.3, 4.0))
         scene = random_scene(n, 20_000 + seed, deg, box=((-3, 3), (-2, 2), (-1, 9)), scale=(lo, min(hi, 20.0 if wild else 3.0)),
                              opac_mu=float(rng.uniform(-3.0, 2.0)))
+        if wild and seed % 3 == 0:   # opacities at both ends of (0, 1); a tenth of the cloud pushed far away (last depth buckets)
+            scene[3][:] = np.clip(np.where(rng.random(n) < 0.5, 1.0 - 10 ** rng.uniform(-7, -2, n), 10 ** rng.uniform(-4, -1, n)), 1e-6, 1.0 - 1e-7).astype(np.float32)
+            far = rng.random(n) < 0.1
+            scene[0][far, 2] = (scene[0][far, 2] * float(10 ** rng.uniform(1, 3.5))).astype(np.float32)
+            scene[1][far] *= np.float32(30.0)
         eye = np.array([rng.uniform(-3, 3), rng.uniform(-2, 2), rng.uniform(-3, 6)])
         target = np.array([rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), rng.uniform(3, 8)])
         if np.linalg.norm(target - eye) < 0.5:
             target = eye + np.array([0.1, 0.0, 1.0])
         down = np.array([rng.normal(0, 0.3), 1.0, rng.normal(0, 0.3)])
         view = look_at_view(eye, target, down)
-        f = float(w * rng.uniform(0.35, 1.6))
+        f = float(w * rng.uniform(0.12 if wild else 0.35, 1.6))
         cam = onp.Camera(w, h, f, f * float(rng.uniform(0.9, 1.1)), w / 2.0 + float(rng.uniform(-3, 3)),
                          h / 2.0 + float(rng.uniform(-3, 3)), view)
         cfg = onp.Config(near=float(rng.choice([0.2, 0.05, 0.5])), dilation=float(rng.choice([0.3, 0.1, 0.6])),
