@@ -167,6 +167,17 @@ def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
         if seed % 4 == 0:            # default constants and the whole frame: also the depth / coverage outputs (f-4)
             cfg, rows = None, (0, -1)
         check_against_oracle(drv, scene, cam, cfg, rows, what=f"fuzz seed {seed} (n={n} {w}x{h} deg {deg} rows {rows})")
+        if seed % 5 == 1 and rows == (0, -1):      # interleaved tile-row shards reproduce the frame's rows bit for bit
+            full, st_full = drv.render(cam, cfg)
+            stride = int(rng.integers(2, 5))
+            d_sum = 0
+            for phase in range(min(stride, gy)):         # (a shard beyond the frame's rows owns nothing and is never rendered)
+                part, st_p = drv.render(cam, cfg, interleave=(stride, phase))
+                for k, row in enumerate(range(phase, gy, stride)):
+                    y0, y1 = 16 * row, min(16 * row + 16, h)
+                    assert (part[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"fuzz seed {seed}: stride {stride} phase {phase} row {row}"
+                d_sum += st_p["d_total"]
+            assert d_sum == st_full["d_total"], f"fuzz seed {seed}: interleaved shards queue {d_sum} records, the frame {st_full['d_total']}"
         if seed % 4 == 0:
             rgb0, _ = drv.render(cam)
             rgb, aux = drv.render_aux(cam)
