@@ -614,7 +614,7 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
                 for (int64_t i = 0; i < n; ++i)
                     for (int c = 0; c < 3; ++c) {
                         const float v = hm[(size_t)i * 3 + c];
-                        if (v == v) { lo[c] = std::min(lo[c], v); hi[c] = std::max(hi[c], v); }
+                        if (std::isfinite(v)) { lo[c] = std::min(lo[c], v); hi[c] = std::max(hi[c], v); }   // (a NaN / inf mean is never visible)
                     }
                 float inv[3];
                 for (int c = 0; c < 3; ++c) inv[c] = hi[c] > lo[c] ? 2097151.0f / (hi[c] - lo[c]) : 0.f;
@@ -630,7 +630,7 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
                     uint64_t q[3];
                     for (int c = 0; c < 3; ++c) {
                         const float v = hm[(size_t)i * 3 + c];
-                        const float u = v == v ? (v - lo[c]) * inv[c] : 0.f;
+                        const float u = std::isfinite(v) ? (v - lo[c]) * inv[c] : 0.f;
                         q[c] = (uint64_t)std::min(2097151.0f, std::max(0.0f, u));
                     }
                     keys[(size_t)i] = {spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2, (unsigned)i};

@@ -190,6 +190,34 @@ def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
                 assert np.abs(aux[..., 1] - (1.0 - o["final_T"]))[safe].max() < 1e-3, f"fuzz seed {seed}: coverage"
 
 
+def case_non_finite_gaussians(drv, n=3000, res=(160, 120), seed=3):
+    """NaN / +-inf in a Gaussian's mean, scale, rotation or opacity (or an all-zero quaternion): that Gaussian is never
+    visible and the frame is, bit for bit, the frame of the scene without it — its chunk neighbours, the Z-order and the
+    per-chunk bounds are unaffected."""
+    rng = np.random.default_rng(seed)
+    means, scales, quats, opac, sh, deg = random_scene(n, 900 + seed, 2, scale=(0.03, 0.4))
+    hit = rng.random(n) < 0.05
+    bm, bs, bq, bo = means.copy(), scales.copy(), quats.copy(), opac.copy()
+    vals = [np.nan, np.inf, -np.inf]
+    for i in np.nonzero(hit)[0]:
+        f = int(rng.integers(0, 6)); v = vals[int(rng.integers(0, 3))]
+        if f == 0: bm[i, int(rng.integers(0, 3))] = v
+        elif f == 1: bs[i, int(rng.integers(0, 3))] = v
+        elif f == 2: bq[i, int(rng.integers(0, 4))] = v
+        elif f == 3: bq[i] = 0.0
+        elif f == 4: bo[i] = np.nan
+        else: bm[i] = v
+    w, h = res
+    cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+    keep = ~hit
+    drv.upload(means[keep], scales[keep], quats[keep], opac[keep], sh[keep], deg)
+    ref, st_ref = drv.render(cam)
+    drv.upload(bm, bs, bq, bo, sh, deg)
+    img, st = drv.render(cam)
+    assert np.isfinite(img).all() and (img == ref).all(), "a non-finite Gaussian changed the frame"
+    assert st["d_total"] == st_ref["d_total"]
+
+
 def case_padding_lanes(drv):
     """N not a multiple of 64 with a camera looking down -z: the padding lanes of the last chunk must stay
     culled (their placeholder mean projects to a huge POSITIVE depth for such a view)."""

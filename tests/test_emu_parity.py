@@ -38,6 +38,11 @@ def test_seeded_random_frames_with_needles_and_specks(drv):
     pc.case_fuzz(drv, range(7000, 7006), 400, (200, 120), wild=True)
 
 
+def test_non_finite_gaussians_are_invisible_and_harmless(drv):
+    pc.case_non_finite_gaussians(drv)
+    pc.case_non_finite_gaussians(drv, n=700, res=(96, 64), seed=4)
+
+
 def test_padding_lanes_stay_culled(drv):
     pc.case_padding_lanes(drv)
 
