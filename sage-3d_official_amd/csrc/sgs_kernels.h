@@ -417,9 +417,18 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     // A splat whose rect covers hundreds of tiles (a near-camera Gaussian) would keep ONE wave of the
     // binning kernels busy for its whole expansion; those few go to a global list instead and are
     // expanded by entire workgroups.  bigmask tells the per-chunk walk to skip them.
-    if (big) {
-        const unsigned k = atomicAdd(&st->n_big, 1u);
-        if (k < SGS_BIG_CAP) big_list[k] = (unsigned)pos; else big = false;
+    {   // one atomic per wave (the big splats of a near-camera surface come in runs: up to 64 per chunk)
+        const unsigned long long wants = __ballot(big);
+        if (wants != 0ull) {
+            const int leader = __ffsll((long long)wants) - 1;
+            unsigned base = 0;
+            if (lane == leader) base = atomicAdd(&st->n_big, (unsigned)__popcll(wants));
+            base = __shfl(base, leader);
+            if (big) {
+                const unsigned k = base + (unsigned)__popcll(wants & lanemask_lt(lane));
+                if (k < SGS_BIG_CAP) big_list[k] = (unsigned)pos; else big = false;
+            }
+        }
     }
     const unsigned long long bmask = __ballot(big);
     if (lane == 0) { vismask[chunk] = vmask; bigmask[chunk] = bmask; }
