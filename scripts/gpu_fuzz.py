@@ -9,7 +9,7 @@ import conftest, parity_cases as pc
 from test_gpu_parity import GpuDriver
 drv = GpuDriver()
 a, b = int(sys.argv[1]), int(sys.argv[2]); max_n = int(sys.argv[3]) if len(sys.argv) > 3 else 700
-wild = "wild" in sys.argv; max_res = (2400, 1400) if "huge" in sys.argv else (900, 600) if "big" in sys.argv else (260, 160)
+wild = "wild" in sys.argv; max_res = (3900, 2200) if "uhd" in sys.argv else (2400, 1400) if "huge" in sys.argv else (900, 600) if "big" in sys.argv else (260, 160)
 bad = []
 for seed in range(a, b):
     try:
