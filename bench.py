@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--bands", choices=("balanced", "even", "interleave"), default="balanced",
                     help="tile-row shards: contiguous bands re-cut by cost from the previous batch (default), the even "
                          "9,9,9,9,8,8,8,8 split, or every N-th row")
+    ap.add_argument("--no-batch", action="store_true", help="camera mode: issue a sweep of <= 32 frames one by one as well, "
+                                                             "not as one render_batch call")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
     ap.add_argument("--secondary-timeout", type=float, default=120.0,
                     help="N>1: seconds after which a stuck second measurement is abandoned and the headline printed")
@@ -170,9 +172,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    SHORT = 32
+    batch_frames = torch.zeros((min(SHORT, max(K, W, 1)), height, width, 3), dtype=torch.float32, device=device) \
+        if pipelined and not args.no_batch else None
+
+    def short_sweep(count):
+        return batch_frames is not None and 0 < count <= batch_frames.shape[0] and K <= SHORT
+
     def run_cameras(first, count, timed):
         """Camera shards: step i is one pose PER RANK (rank rk renders pose (i * world + rk) of the strided sweep); no
         data-path collective.  Returns this rank's per-frame average statistics; every frame is checked for overflow."""
+        if short_sweep(count):
+            # a short sweep is ONE call of the batch entry (the generate_images.py loop, SURVEY A4): frame groups of four per
+            # set of launches fill and drain the pipeline faster than frames issued one by one (0.235 vs 0.256 ms/frame at
+            # 20 frames; from ~40 frames on the per-frame path below is ahead)
+            r.render_batch([cams[pose((first + i) * world + rank)] for i in range(count)], gs, out=batch_frames)
+            return None
         for i in range(count):
             r.render(cams[pose((first + i) * world + rank)], gs, out=frames[i % len(frames)], sync=False,
                      timing=timed and i % max(1, args.event_stride) == 0, pipelined=pipelined)
@@ -316,7 +331,9 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
                        "pose_set": pose_set,
-                       "parallelism": "1 GPU" if world == 1 else
+                       "parallelism": ("1 GPU, " + ("the sweep issued as one render_batch call (frame groups of four on two streams)"
+                                                    if short_sweep(K) else "frames pipelined on the library's three lanes")
+                                       if pipelined else "1 GPU, one frame at a time") if world == 1 else
                                       (f"tile-row shard x{world} ({bands_desc}) + RCCL gatherv to rank 0"
                                        + (f" (bands of {sharded.batch} frames per exchange)" if pipelined else "")
                                        if rows_primary else cameras_desc),
