@@ -173,8 +173,8 @@ def main():
         torch.cuda.synchronize(device)
 
     SHORT = 32
-    batch_frames = torch.zeros((min(SHORT, max(K, W, 1)), height, width, 3), dtype=torch.float32, device=device) \
-        if pipelined and not args.no_batch else None
+    batch_frames = torch.zeros((min(SHORT, max(K, W, 8)), height, width, 3), dtype=torch.float32, device=device) \
+        if pipelined and not args.no_batch and K <= SHORT else None
 
     def short_sweep(count):
         return batch_frames is not None and 0 < count <= batch_frames.shape[0] and K <= SHORT
@@ -186,7 +186,10 @@ def main():
             # a short sweep is ONE call of the batch entry (the generate_images.py loop): frame groups of four per
             # set of launches fill and drain the pipeline faster than frames issued one by one (0.235 vs 0.256 ms/frame at
             # 20 frames; from ~40 frames on the per-frame path below is ahead)
-            r.render_batch([cams[pose((first + i) * world + rank)] for i in range(count)], gs, out=batch_frames)
+            n = count
+            if warming[0]:           # the batch path rotates over eight sets of intermediates (4 frames x 2 streams): touch them
+                n = max(count, 8)    # all before the clock starts (buffers are allocated on first use), whatever W is
+            r.render_batch([cams[pose((first + i % max(1, count)) * world + rank)] for i in range(n)], gs, out=batch_frames)
             return None
         for i in range(count):
             r.render(cams[pose((first + i) * world + rank)], gs, out=frames[i % len(frames)], sync=False,
@@ -198,6 +201,10 @@ def main():
         frames are rendered through the pipelined lanes and travel in one asynchronous exchange, double-buffered."""
         sharded = sharded or sharded_f32
         acc, n_acc, i = None, 0, 0
+        if warming[0] and pipelined and count > 0:
+            # the library's batch path rotates over eight sets of intermediates (buffers allocated on first use): touch them
+            # all before the clock starts, whatever W is
+            sharded.render_batch([cams[pose(first + j % count)] for j in range(8)], gs)
         while i < count:
             nb = min(sharded.batch, count - i) if pipelined else 1
             if warming[0] and nb > 2:          # warm-up: several short batches, so that the bands are re-cut a few times
