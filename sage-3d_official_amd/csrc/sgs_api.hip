@@ -399,12 +399,17 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
         const unsigned grid = ((ntiles + 7u) / 8u) * 8u;
         // (D_f is counted only on request: the per-pixel bookkeeping and the end-of-tile reduction cost ~4 % of a sweep)
         const bool count_df = (cfg.flags & SGS_FLAG_STATS) != 0;
+        // the final transmittance of stopped pixels (one more add per pixel and splat) only where something reads it
+        const bool need_tf = out_aux || cfg.bg[0] != 0.f || cfg.bg[1] != 0.f || cfg.bg[2] != 0.f;
         if (out_aux) {
-            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<true, true>), dim3(grid, F), dim3(256), 0, stream, G);
-            else hipLaunchKernelGGL((sgs::k_tile_render<true, false>), dim3(grid, F), dim3(256), 0, stream, G);
+            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<true, true, true>), dim3(grid, F), dim3(256), 0, stream, G);
+            else hipLaunchKernelGGL((sgs::k_tile_render<true, false, true>), dim3(grid, F), dim3(256), 0, stream, G);
+        } else if (need_tf) {
+            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<false, true, true>), dim3(grid, F), dim3(256), 0, stream, G);
+            else hipLaunchKernelGGL((sgs::k_tile_render<false, false, true>), dim3(grid, F), dim3(256), 0, stream, G);
         } else {
-            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<false, true>), dim3(grid, F), dim3(256), 0, stream, G);
-            else hipLaunchKernelGGL((sgs::k_tile_render<false, false>), dim3(grid, F), dim3(256), 0, stream, G);
+            if (count_df) hipLaunchKernelGGL((sgs::k_tile_render<false, true, false>), dim3(grid, F), dim3(256), 0, stream, G);
+            else hipLaunchKernelGGL((sgs::k_tile_render<false, false, false>), dim3(grid, F), dim3(256), 0, stream, G);
         }
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[4], stream));
@@ -915,7 +920,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         for (int64_t i = 0; i < n; ++i) ((unsigned char*)host_dst)[i] = vm[(size_t)i] == 0ull && bm[(size_t)i] == ~0ull;
     }
     if (what == SGS_BUF_SPLATS) {
-        // device records (sgs_common.h: 64 B, conic pre-scaled for the composite) -> x,y,conic a,b | c,opacity,r,g | b,depth,rect01,rect23
+        // device records (sgs_common.h: 64 B, conic pre-scaled for the composite, opacity also as an exponent offset) -> x,y,conic a,b | c,opacity,r,g | b,depth,rect01,rect23
         const int64_t cnt = n / elem;
         std::vector<Splat> tmp((size_t)std::max<int64_t>(1, cnt));
         hipError_t e = hipMemcpy(tmp.data(), L.splats, (size_t)cnt * sizeof(Splat), hipMemcpyDeviceToHost);

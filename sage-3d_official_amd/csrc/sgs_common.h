@@ -19,6 +19,11 @@
 #ifndef SGS_DYNAMIC_LDS
 #define SGS_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 #endif
+// a wave-uniform value the hot loop multiplies with: pinned to a vector register (an SGPR or literal operand makes a VALU
+// instruction cost 1.6 issue slots on gfx950, scripts/ubench.hip).  Value-preserving; a CPU test harness defines it away.
+#ifndef SGS_PIN_VGPR
+#define SGS_PIN_VGPR(x) asm volatile("" : "+v"(x))
+#endif
 #define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB) ...
 #define SGS_WT_BIG 16384            // ... or 64 KB (SGS_WINDOW_TILES=16384, bands of more than SGS_WT tiles: 4K in two windows, not four)
 #define SGS_BIN_THREADS 512
@@ -121,12 +126,13 @@ struct FrameGroup {
 // needs per (splat, tile) that does not depend on the tile is computed here once, per splat:
 //   word 0..3   x, y, A, k            q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e)  (A = conic_a log2(e)/2, B = conic_b log2(e), ...)
 //                                     stored as the completed square A (dx + k dy)^2 + C' dy^2:  k = B / 2A in the slot `B`,
-//   word 4..7   C', opacity, qcut, r  C' = C - B^2 / 4A in the slot `C`;  qcut = bits(log2(opacity / alpha_min)) + 1 (0 when below alpha_min)
-//   word 8..11  g, b, depth bits, hx  hx, hy = half extents of the ellipse {alpha >= alpha_min}, padded outward
-//   word 12..15 hy, qmax, rect x0|y0<<16, rect x1|y1<<16     qmax = log2(opacity / alpha_min); rect = S3's reference rect (tests)
+//   word 4..7   C', nlo, r, g         C' = C - B^2 / 4A in the slot `C`;  nlo = log2(alpha_max / opacity): the composite evaluates
+//                                     q = q2 + nlo, alpha / alpha_max = min(1, 2^-q), and alpha >= alpha_min <=> q <= log2(alpha_max / alpha_min)
+//   word 8..11  b, depth bits, hx, hy hx, hy = half extents of the ellipse {alpha >= alpha_min}, padded outward
+//   word 12..15 qmax, opacity, rect x0|y0<<16, rect x1|y1<<16     qmax = log2(opacity / alpha_min); rect = S3's reference rect (tests)
 struct alignas(64) Splat {
     float x, y, A, B;
-    float C, o; uint32_t qcut; float r;
-    float g, b; uint32_t key; float hx;
-    float hy, qmax; uint32_t rect01; uint32_t rect23;
+    float C, nlo, r, g;
+    float b; uint32_t key; float hx, hy;
+    float qmax, o; uint32_t rect01; uint32_t rect23;
 };

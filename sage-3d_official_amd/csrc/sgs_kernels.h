@@ -90,11 +90,7 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
     if (i >= 0) {
         g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
         g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
-#ifdef SGS_EXPERIMENT_SLOT_POS   // timing experiment only: splats stored at the layout position (breaks depth-tie order)
-        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)p));
-#else
         g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)i));
-#endif
     }
     geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
     geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
@@ -448,7 +444,6 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         }
         const float depth = (float)tz;
         // the record of the composite (sgs_common.h): constants folded per splat, not per (splat, tile) or per pixel
-        const unsigned qcut = qmax >= 0.0f ? __float_as_uint(qmax) + 1u : 0u;
         float4* sp = reinterpret_cast<float4*>(splats + slot);
         // q2 = -power * log2(e) = A dx^2 + B dx dy + C dy^2 with the fp32 conic (ca, cb, cc) — the form S6 defines — is stored as
         // the completed square  A (dx + k dy)^2 + C' dy^2,  k = B / 2A,  C' = C - B^2 / 4A = det / A,  derived in fp64 FROM the
@@ -459,10 +454,12 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                      C64 = (0.5 * 1.4426950408889634) * (double)cc;
         const double iA = A64 > 0.0 ? 1.0 / A64 : 0.0;
         const double k64 = 0.5 * B64 * iA, Cp64 = C64 - 0.25 * B64 * B64 * iA;
+        // the opacity enters the composite's exponent: alpha / alpha_max = min(1, 2^-(q2 + nlo)),  nlo = log2(alpha_max / o)
+        const float nlo = __log2f(P.alpha_max) - __log2f(g0.w);
         sp[0] = make_float4(sx, sy, (float)A64, (float)k64);
-        sp[1] = make_float4((float)Cp64, g0.w, __uint_as_float(qcut), r);
-        sp[2] = make_float4(g, b, depth, ext_x);
-        sp[3] = make_float4(ext_y, qmax, __uint_as_float(rect01), __uint_as_float(rect23));
+        sp[1] = make_float4((float)Cp64, nlo, r, g);
+        sp[2] = make_float4(b, depth, ext_x, ext_y);
+        sp[3] = make_float4(qmax, g0.w, __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
         binrec[pos] = uint4{__float_as_uint(depth), brect01, brect23, slot};
     }
@@ -1133,34 +1130,44 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // ---- the blend loop of k_tile_render -----------------------------------------------------------------
 // Issue costs measured on gfx950 (scripts/ubench.hip, 6 waves per SIMD, plain v_fma_f32 = 1): packed fp32
 // (v_pk_*) 1.8 — no gain over two plain ops —, v_cmp / v_min / v_max / v_cndmask and any SGPR operand 1.6,
-// v_exp_f32 3, a broadcast ds_read_b128 ~6 on the CU's shared LDS pipe.  The composite is issue-bound, so the
-// per-pixel work is written for the smallest issue count rather than the fewest flops:
-//   * staging folds every constant into the splat (per splat, not per pixel):
-//         A = ca * log2(e)/2,  B = cb * log2(e),  C = cc * log2(e)/2      q2 = A dx^2 + B dx dy + C dy^2 = -power * log2(e)
-//         stored as the completed square  q2 = A (dx + k dy)^2 + C' dy^2,  k = B / 2A,  C' = C - B^2 / 4A  (k_preprocess: the
-//         same instruction count, and no cancellation between large terms for needle-shaped splats)
-//         qcut = bits(log2(o / alpha_min)) + 1
-//     so alpha = o * 2^-q2 needs no scaling, and BOTH skip tests of S6 are one unsigned compare:
-//         power <= 0  and  alpha >= alpha_min   <=>   bits(q2) < qcut     (a negative q2 has the sign bit set);
-//   * a finished (or outside) pixel carries its transmittance NEGATED: T (1 - alpha) is then negative too, and one
-//     SIGNED integer compare bits(T (1 - alpha)) < bits(t_min) is true both for the splat that ends a pixel and for
-//     every later splat — their weight is forced to 0 by the same select, T keeps -|T|.  No live mask, and |T| at
-//     the end is exactly the transmittance the pixel stopped with;
+// v_exp_f32 3, an LDS read 3.5-6 on the CU's shared LDS pipe; source modifiers (neg, abs) and the VOP3 `clamp` output
+// modifier (result saturated to [0, 1], NaN -> 0) are free.  The composite is issue-bound, so the per-pixel work is
+// written for the smallest issue COST: no compare, select or min is left in the common trip — every predicate is a
+// saturated fma, i.e. a factor 0 / 1, and every constant is folded into the splat once (k_preprocess), not per pixel:
+//   * q2 = A dx^2 + B dx dy + C dy^2 = -power log2(e) is stored as the completed square A (dx + k dy)^2 + C' dy^2
+//     (k = B / 2A, C' = C - B^2 / 4A: no cancellation between large terms for needle-shaped splats), and the opacity
+//     rides in the same fma chain:   q = A u^2 + (C' dy^2 + nlo),  nlo = log2(alpha_max / o)   =>   2^-q = alpha / alpha_max;
+//   * S6's clamp  alpha = min(alpha_max, o e^power)  is the clamp modifier of the v_exp:   E = sat(2^-q) = alpha / alpha_max;
+//   * S6's cut-off  alpha >= alpha_min  <=>  q <= cq = log2(alpha_max / alpha_min)  is  vf = sat((cq - q) 2^100)  — exactly
+//     0 or 1 for any fp32 q (the smallest non-zero |cq - q| times 2^100 is far above 1; q = cq counts as outside, a set of
+//     measure zero inside the margin the tests check two-sidedly; NaN -> 0);
+//     S6's other skip, power > 0, cannot fire while A >= 0 and C' >= 0 (then q2 >= 0 term by term).  A splat whose fp32
+//     conic rounded to an indefinite form (C' < 0: needles hundreds of pixels long) is flagged at staging and its whole
+//     batch runs the EXACT variant of the trip (SGS_ALPHA_X: compares and selects, bit-identical results for every
+//     other splat of the batch);
+//   * the pixel carries Tm = alpha_max T, so that  w = E vf Tm = alpha T  is the blend weight with no further factor and
+//     tt = Tm - alpha_max w = alpha_max T (1 - alpha);  S6's stop rule  T (1 - alpha) < t_min  is  lv = sat((tt - alpha_max
+//     t_min) 2^100), again exactly 0 or 1:  w *= lv (the splat that would end the pixel is not blended),  Tm = tt lv.
+//     A finished pixel (and one outside the image) has Tm = 0 and stays there: w = 0, tt = 0, lv = 0.  No live mask;
+//   * the transmittance a stopped pixel ended with (background term, coverage) is 1 - sum of its weights, accumulated
+//     only in the instantiations that need it (TF: a non-black background, or the depth / coverage outputs);
 //   * D_f (how far into the queue the tile's pixels read) is not tracked per splat: when a trip leaves a wave with
-//     no live pixel — once per wave and tile — the trip is replayed from the saved T to find the splat that ended
+//     no live pixel — once per wave and tile — the trip is replayed from the saved Tm to find the splat that ended
 //     the last pixel.
-// s_a[j] = (x, y, A, k)   s_b[j] = (C', o, qcut, r)   s_c[j] = (g, b[, view depth, 0])
+// Staged batch, five arrays of 8-byte pairs at ONE byte offset O = 8 j (so a trip computes no addresses):
+//   s_p0[j] = (x, y)   s_p1[j] = (A, k)   s_p2[j] = (C', nlo)   s_p3[j] = (r, g)   s_p4[j] = (b, view depth)
 // A wave walks the splats of the batch that can touch ITS quadrant four per trip: the four alphas are
 // independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
-// is applied in depth order.  Predicates stay on the VALU (compare -> select).  A short tail reads the inert
-// dummy splat at index SGS_BATCH.
+// is applied in depth order.  A short tail reads the inert dummy splat at index SGS_BATCH (nlo = 1e30: E = vf = 0).
 #define SGS_EXP2(x) __builtin_amdgcn_exp2f(x)
 #define SGS_RCP(x) __builtin_amdgcn_rcpf(x)         // 1 ulp; every use below is padded outward
 #define SGS_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#define SGS_SAT(x) __builtin_amdgcn_fmed3f((x), 0.0f, 1.0f)   // folds into the producing instruction's clamp modifier
+#define SGS_BIG 1.2676506002282294e30f              // 2^100
 #ifdef SGS_TILE_PROF   // profiling build: how many (wave, splat) evaluations had no pixel inside the alpha cut-off
 #define SGS_PROF_EVAL(valid, J)                                                                        \
     if ((J) != (unsigned)SGS_BATCH) {                                                                  \
-        const unsigned long long vb_ = __ballot(valid), lb_ = __ballot((valid) && T > 0.0f);           \
+        const unsigned long long vb_ = __ballot(valid), lb_ = __ballot((valid) && Tm > 0.0f);          \
         ++pe_eval; pe_empty += vb_ == 0ull; pe_valid += (unsigned)__popcll(vb_); pe_useful += (unsigned)__popcll(lb_); \
     }
 #define SGS_PROF_STAGED_ALL() atomicAdd(&s_pe[4], 1u);
@@ -1172,44 +1179,58 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #endif
 #define SGS_AT(arr, T_, off) (*reinterpret_cast<const T_*>(reinterpret_cast<const char*>(arr) + (off)))
 #define SGS_NEXT(OV)                                                                                   \
-    const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 4; \
+    const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 3; \
     mm &= mm - 1ull;
-// O = byte offset of the splat's slot in the staging arrays (16 B per splat in s_a and s_b)
-#define SGS_ALPHA(O, AL, RED)                                                                          \
-    float AL, RED;                                                                                     \
+// O = byte offset of the splat's slot in the five staging arrays (8 B per splat in each); AL = alpha / alpha_max or 0
+#define SGS_ALPHA_F(O, AL)                                                                             \
+    float AL;                                                                                          \
     {                                                                                                  \
-        const float4 qa = SGS_AT(s_a, float4, O), qb = SGS_AT(s_b, float4, O);                         \
-        const float dx = qa.x - fpx, dy = qa.y - fpy;                                                  \
-        const float u = __builtin_fmaf(qa.w, dy, dx);                                                  \
-        const float q2 = __builtin_fmaf(qa.z * u, u, (qb.x * dy) * dy);         /* A u^2 + C' dy^2 */  \
-        const bool valid = __float_as_uint(q2) < __float_as_uint(qb.z);   /* S6: power <= 0 and alpha >= 1/255 */ \
-        const float a = fminf(qb.y * SGS_EXP2(-q2), amax);                                             \
-        AL = valid ? a : 0.0f;                                                                         \
-        RED = qb.w;                                                                                    \
-        SGS_PROF_EVAL(valid, (O) >> 4)                                                                 \
+        const float2 p0 = SGS_AT(s_p0, float2, O), p1 = SGS_AT(s_p1, float2, O), p2 = SGS_AT(s_p2, float2, O); \
+        const float dx = p0.x - fpx, dy = p0.y - fpy;                                                  \
+        const float u = __builtin_fmaf(p1.y, dy, dx);                                                  \
+        const float q = __builtin_fmaf(p1.x * u, u, __builtin_fmaf(p2.x * dy, dy, p2.y));   /* A u^2 + (C' dy^2 + nlo) */ \
+        AL = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));                     \
+        SGS_PROF_EVAL(q < cq, (O) >> 3)                                                                \
     }
-#define SGS_APPLY(O, AL, RED)                                                                          \
+// the exact variant (a batch holding a splat with an indefinite conic): S6's power > 0 skip as well; the same q, hence the
+// same AL bit for bit, for every splat with A, C' >= 0
+#define SGS_ALPHA_X(O, AL)                                                                             \
+    float AL;                                                                                          \
     {                                                                                                  \
-        const ColT qc = SGS_AT(s_c, ColT, AUX ? (O) : ((O) >> 1));                                     \
-        const float testT = __builtin_fmaf(-(AL), T, T);                                               \
-        const bool stop = (int)__float_as_uint(testT) < tmin_bits;   /* ends here, or ended before (negative) */ \
-        float wgt = (AL) * T;                                                                          \
-        wgt = stop ? 0.0f : wgt;                   /* the splat that would end the pixel is not blended */ \
-        C0 = __builtin_fmaf(wgt, RED, C0); C1 = __builtin_fmaf(wgt, qc.x, C1); C2 = __builtin_fmaf(wgt, qc.y, C2); \
-        if (AUX) Dz = __builtin_fmaf(wgt, col_z(qc), Dz);   /* expected depth (template instantiation only) */ \
-        T = stop ? -__builtin_fabsf(T) : testT;                                                        \
+        const float2 p0 = SGS_AT(s_p0, float2, O), p1 = SGS_AT(s_p1, float2, O), p2 = SGS_AT(s_p2, float2, O); \
+        const float dx = p0.x - fpx, dy = p0.y - fpy;                                                  \
+        const float u = __builtin_fmaf(p1.y, dy, dx);                                                  \
+        const float au = p1.x * u, cd = p2.x * dy;                                                     \
+        const float q = __builtin_fmaf(au, u, __builtin_fmaf(cd, dy, p2.y));                           \
+        const float q2 = __builtin_fmaf(au, u, cd * dy);                       /* the sign S6 tests */ \
+        const bool valid = q < cq && q2 >= 0.0f;                                                       \
+        const float e = SGS_SAT(SGS_EXP2(-q));                                                         \
+        AL = valid ? e : 0.0f;                                                                         \
+        SGS_PROF_EVAL(valid, (O) >> 3)                                                                 \
+    }
+#define SGS_APPLY(O, AL)                                                                               \
+    {                                                                                                  \
+        const float2 p3 = SGS_AT(s_p3, float2, O), p4 = SGS_AT(s_p4, float2, O);                       \
+        float wgt = (AL) * Tm;                                                  /* alpha T */          \
+        const float tt = __builtin_fmaf(-wgt, amax, Tm);                        /* alpha_max T (1 - alpha) */ \
+        const float lv = SGS_SAT(__builtin_fmaf(tt, big, nt_big));          /* 0: ends here, or ended before */ \
+        wgt *= lv;                                 /* the splat that would end the pixel is not blended */ \
+        Tm = tt * lv;                                                                                  \
+        C0 = __builtin_fmaf(wgt, p3.x, C0); C1 = __builtin_fmaf(wgt, p3.y, C1); C2 = __builtin_fmaf(wgt, p4.x, C2); \
+        if (AUX) Dz = __builtin_fmaf(wgt, p4.y, Dz);        /* expected depth (template instantiation only) */ \
+        if (TF) Wsum += wgt;                                                                           \
     }
 #define SGS_REPLAY(O, AL)                                                                              \
     {                                                                                                  \
-        if (__ballot(Ts > 0.0f) != 0ull) last = ((O) >> 4) + 1u;                                       \
-        const float testT = __builtin_fmaf(-(AL), Ts, Ts);                                             \
-        Ts = (int)__float_as_uint(testT) < tmin_bits ? -__builtin_fabsf(Ts) : testT;                   \
+        if (__ballot(Ts > 0.0f) != 0ull) last = ((O) >> 3) + 1u;                                       \
+        const float tt = __builtin_fmaf(-((AL) * Ts), amax, Ts);                                       \
+        Ts = tt * SGS_SAT(__builtin_fmaf(tt, big, nt_big));                                        \
     }
-#define SGS_TRIP(o0, o1, o2, o3)                                                                       \
-    const float Tb = T;                                                                                \
-    SGS_ALPHA(o0, al0, r0) SGS_ALPHA(o1, al1, r1) SGS_ALPHA(o2, al2, r2) SGS_ALPHA(o3, al3, r3)        \
-    SGS_APPLY(o0, al0, r0) SGS_APPLY(o1, al1, r1) SGS_APPLY(o2, al2, r2) SGS_APPLY(o3, al3, r3)        \
-    if (__ballot(T > 0.0f) == 0ull) {                                                                  \
+#define SGS_TRIP(ALPHA, o0, o1, o2, o3)                                                                \
+    const float Tb = Tm;                                                                               \
+    ALPHA(o0, al0) ALPHA(o1, al1) ALPHA(o2, al2) ALPHA(o3, al3)                                        \
+    SGS_APPLY(o0, al0) SGS_APPLY(o1, al1) SGS_APPLY(o2, al2) SGS_APPLY(o3, al3)                        \
+    if (__ballot(Tm > 0.0f) == 0ull) {                                                                 \
         /* the wave's last pixel ended in this trip: replay it to find the splat that did it */        \
         if (STATS) {                                                                                   \
             float Ts = Tb; unsigned last = 0u;                                                         \
@@ -1219,55 +1240,61 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         wave_done = true; break;                                                                       \
     }
 // multi-batch groups: walk the quadrant's 64-bit masks with scalar bit scans
-#define SGS_BLEND_WAVE_SCAN()                                                                          \
-    if (__ballot(T > 0.0f) != 0ull) {                                                                  \
-        bool wave_done = false;                                                                        \
+#define SGS_SCAN_LOOP(ALPHA)                                                                           \
         for (int gw = 0; gw < 4 && !wave_done; ++gw) {                                                 \
             unsigned long long mm = uniform_u64(s_ball[par][wave][gw]);   /* splats with a footprint in this quadrant */ \
             const unsigned gwb = (unsigned)gw * 64u;                                                   \
             while (mm != 0ull) {                                                                       \
                 SGS_NEXT(o0) SGS_NEXT(o1) SGS_NEXT(o2) SGS_NEXT(o3)                                    \
-                SGS_TRIP(o0, o1, o2, o3)                                                               \
+                SGS_TRIP(ALPHA, o0, o1, o2, o3)                                                        \
             }                                                                                          \
-        }                                                                                              \
-        if (STATS) used = T > 0.0f ? base + m : used;   /* still live: the whole batch counts as examined */ \
+        }
+#define SGS_BLEND_WAVE_SCAN()                                                                          \
+    if (__ballot(Tm > 0.0f) != 0ull) {                                                                 \
+        bool wave_done = false;                                                                        \
+        if (!hyper) { SGS_SCAN_LOOP(SGS_ALPHA_F) } else { SGS_SCAN_LOOP(SGS_ALPHA_X) }                 \
+        if (STATS) used = Tm > 0.0f ? base + m : used;   /* still live: the whole batch counts as examined */ \
     }
 // single-batch groups (the common case): the wave first compacts ITS quadrant's splats into a private list of
 // staging offsets (in the idle s_sorted storage) — then the loop has no bit scans on the CU-shared scalar unit,
 // no address moves, and one ragged tail per batch instead of one per 64-splat mask word
+#define SGS_LIST_LOOP(ALPHA)                                                                           \
+        for (unsigned k = 0; k < cntq; k += 4) {                                                       \
+            const uint4 pk = *reinterpret_cast<const uint4*>(lst + k);                                 \
+            const unsigned o0 = pk.x, o1 = pk.y, o2 = pk.z, o3 = pk.w;                                 \
+            SGS_TRIP(ALPHA, o0, o1, o2, o3)                                                            \
+        }
 #define SGS_BLEND_WAVE_LIST()                                                                          \
-    if (__ballot(T > 0.0f) != 0ull) {                                                                  \
+    if (__ballot(Tm > 0.0f) != 0ull) {                                                                 \
         unsigned* const lst = s_sorted + (unsigned)wave * (SGS_BATCH + 4);                             \
         unsigned cntq = 0;                                                                             \
         for (int gw = 0; gw < 4; ++gw) {                                                               \
             const unsigned long long mq = uniform_u64(s_ball[par][wave][gw]);                          \
             if ((mq >> lane) & 1ull)                                                                   \
-                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = ((unsigned)gw * 64u + (unsigned)lane) << 4;        \
+                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = ((unsigned)gw * 64u + (unsigned)lane) << 3;        \
             cntq += (unsigned)__popcll(mq);                                                            \
         }                                                                                              \
-        if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned)(SGS_BATCH << 4);         /* inert tail */ \
+        if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned)(SGS_BATCH << 3);         /* inert tail */ \
         wave_lds_sync();                                                                               \
         bool wave_done = false;                                                                        \
-        for (unsigned k = 0; k < cntq; k += 4) {                                                       \
-            const uint4 pk = *reinterpret_cast<const uint4*>(lst + k);                                 \
-            const unsigned o0 = pk.x, o1 = pk.y, o2 = pk.z, o3 = pk.w;                                 \
-            SGS_TRIP(o0, o1, o2, o3)                                                                   \
-        }                                                                                              \
+        if (!hyper) { SGS_LIST_LOOP(SGS_ALPHA_F) } else { SGS_LIST_LOOP(SGS_ALPHA_X) }                 \
         (void)wave_done;                                                                               \
-        if (STATS) used = T > 0.0f ? base + m : used;                                                  \
+        if (STATS) used = Tm > 0.0f ? base + m : used;                                                 \
     }
-// staging: write splat J from its record (A_ = x,y,A,B  B_ = C,o,qcut,r  C_ = g,b,depth,hx) — a plain copy: k_preprocess
-// has folded every constant into the record
+// staging: write splat J from its record (A_ = x,y,A,k  B_ = C',nlo,r,g  C_ = b,depth,hx,hy) — a plain copy: k_preprocess
+// has folded every constant into the record.  A splat whose conic is not positive semi-definite flags the batch.
 #define SGS_STAGE(J, A_, B_, C_)                                                                       \
     {                                                                                                  \
-        s_a[J] = A_;                                                                                   \
-        s_b[J] = B_;                                                                                   \
-        s_c[J] = make_col<ColT>(C_.x, C_.y, C_.z);                                                     \
+        s_p0[J] = make_float2(A_.x, A_.y); s_p1[J] = make_float2(A_.z, A_.w);                          \
+        s_p2[J] = make_float2(B_.x, B_.y); s_p3[J] = make_float2(B_.z, B_.w);                          \
+        s_p4[J] = make_float2(C_.x, C_.y);                                                             \
+        if (!(A_.z >= 0.0f) || !(B_.x >= 0.0f)) s_hyper[par] = 1u;                                     \
     }
 #define SGS_STAGE_DUMMY()                                                                              \
     {                                                                                                  \
-        s_a[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s_b[SGS_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); \
-        s_c[SGS_BATCH] = make_col<ColT>(0.f, 0.f, 0.f);                                                \
+        s_p0[SGS_BATCH] = make_float2(0.f, 0.f); s_p1[SGS_BATCH] = make_float2(0.f, 0.f);              \
+        s_p2[SGS_BATCH] = make_float2(0.f, 1.0e30f); s_p3[SGS_BATCH] = make_float2(0.f, 0.f);          \
+        s_p4[SGS_BATCH] = make_float2(0.f, 0.f);                                                       \
     }
 // ---- which 8x8 quadrants of the tile can a splat reach? -------------------------------------------------
 // The axis-aligned extent of {alpha >= alpha_min} is a loose test for elongated splats (measured: 27 % of the
@@ -1312,14 +1339,6 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
     }
     return bits;
 }
-template <class C> __device__ __forceinline__ C make_col(float g, float b, float z);
-template <> __device__ __forceinline__ float2 make_col<float2>(float g, float b, float) { return make_float2(g, b); }
-template <> __device__ __forceinline__ float4 make_col<float4>(float g, float b, float z) { return make_float4(g, b, z, 0.f); }
-__device__ __forceinline__ float col_z(const float2&) { return 0.f; }
-__device__ __forceinline__ float col_z(const float4& c) { return c.z; }
-template <bool AUX> struct ColOf { typedef float2 type; };
-template <> struct ColOf<true> { typedef float4 type; };
-
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.  One workgroup per 16x16 tile,
 // one lane per pixel, each of the four waves owns an 8x8 quadrant.
@@ -1365,8 +1384,11 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-template <bool AUX, bool STATS>
+// AUX: expected depth + coverage outputs.  STATS: D_f bookkeeping.  TF: the final transmittance of stopped pixels is needed
+// (AUX, or a background that is not black) — one more add per (pixel, splat).
+template <bool AUX, bool STATS, bool TF>
 __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGroup G) {
+    static_assert(TF || !AUX, "the coverage output needs the final transmittance");
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ tile_order = S.tile_order; const unsigned long long* __restrict__ rec = S.rec;
@@ -1378,12 +1400,13 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     // LDS: the (partitioned) queue or the current group, the staged batch, bucket tables.
     __shared__ unsigned long long s_q[SGS_QCAP + 8 + SGS_RANK_BUCKET_MAX];  // records: depth bits << 32 | slot (+8 sentinels, + slack
                                                                           // for the masked reads past a short bucket)
-    typedef typename ColOf<AUX>::type ColT;
-    __shared__ float4 s_arena[2 * (SGS_BATCH + 1) + ((SGS_BATCH + 1) * sizeof(ColT) + 15) / 16];
-    static_assert(sizeof(float4) * 2 * (SGS_BATCH + 1) >= sizeof(SortShared), "arena");
-    float4* const s_a = s_arena;                                      // blend phase: the staged batch (+1 inert dummy)
-    float4* const s_b = s_arena + (SGS_BATCH + 1);
-    ColT* const s_c = reinterpret_cast<ColT*>(s_arena + 2 * (SGS_BATCH + 1));
+    __shared__ __attribute__((aligned(16))) float2 s_arena[5 * (SGS_BATCH + 1)];
+    static_assert(sizeof(s_arena) >= sizeof(SortShared), "arena");
+    float2* const s_p0 = s_arena;                                     // blend phase: the staged batch (+1 inert dummy),
+    float2* const s_p1 = s_arena + (SGS_BATCH + 1);                   // five arrays of pairs at one common offset
+    float2* const s_p2 = s_arena + 2 * (SGS_BATCH + 1);
+    float2* const s_p3 = s_arena + 3 * (SGS_BATCH + 1);
+    float2* const s_p4 = s_arena + 4 * (SGS_BATCH + 1);
     SortShared& sh = *reinterpret_cast<SortShared*>(s_arena);   // HBM radix path only (never while blending)
     __shared__ __attribute__((aligned(16))) unsigned s_sorted[(SGS_QCAP + 16) > 4 * (SGS_BATCH + 4) ? (SGS_QCAP + 16) : 4 * (SGS_BATCH + 4)];   // the group's slots in (depth, index) order; single-batch
                                                                               // groups: the four waves' splat lists
@@ -1393,11 +1416,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     __shared__ unsigned s_wsum[4], s_wne[4], s_fill;
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
+    __shared__ unsigned s_hyper[2];                   // the batch holds a splat with an indefinite conic: exact trips (by parity)
     __shared__ unsigned s_used[4];
-#ifdef SGS_EXPERIMENT_LDS_PAD
-    __shared__ unsigned s_pad_experiment[SGS_EXPERIMENT_LDS_PAD / 4];    // occupancy experiment: fewer workgroups per CU
-    if (threadIdx.x == 0 && P.n < 0) s_pad_experiment[0] = 1;
-#endif
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
@@ -1431,14 +1451,18 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     const float fpx = (float)px, fpy = (float)py;
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
-    const float amax = P.alpha_max, tmin = P.t_min;
-    const int tmin_bits = (int)__float_as_uint(tmin);
+    // per-frame constants of the trip (the header of the blend macros): all in VGPRs, an SGPR operand costs 1.6 issues
+    float amax = P.alpha_max, big = SGS_BIG;
+    SGS_PIN_VGPR(amax); SGS_PIN_VGPR(big);
+    const float cq = __log2f(P.alpha_max) - __log2f(P.alpha_min);      // alpha >= alpha_min  <=>  q <= cq
+    float cq_big = cq * SGS_BIG, nt_big = -(P.alpha_max * P.t_min) * SGS_BIG;
+    SGS_PIN_VGPR(cq_big); SGS_PIN_VGPR(nt_big);
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
     const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
 
     const unsigned beg = job.y, n = job.z;            // the tile's 8 per-XCD sub-queues are adjacent: one queue
-    float T = inside ? 1.0f : -1.0f;     // transmittance; negative = finished (or outside the image): takes nothing more
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f;
+    float Tm = inside ? amax : 0.0f;     // alpha_max x transmittance; 0 = finished (or outside the image): takes nothing more
+    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dz = 0.f, Wsum = 0.f;
     unsigned used = 0;                   // queue position up to which this pixel examined records (D_f bookkeeping)
 
     // ---- 1. MSD partition into depth buckets (queues longer than one group only) -----------------
@@ -1448,7 +1472,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
     const bool parted = n > SGS_GROUP;
     const bool in_lds = n <= SGS_QCAP;
     const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
-    if (tid < 2) s_any[tid] = 0;
+    if (tid < 2) { s_any[tid] = 0; s_hyper[tid] = 0; }
     if (tid < 64) reinterpret_cast<unsigned*>(&s_ball[0][0][0])[tid] = 0u;   // both parities: 2 x 4 quadrants x 4 x 64 bits
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
     {
@@ -1595,7 +1619,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
             // the gather right here — instead of behind the ranking below, which is what hides its latency
             const float4* const sp = reinterpret_cast<const float4*>(splats + (have ? (unsigned)mine : 0u));
             const float4 nA = sp[0], nB = sp[1], nC = sp[2];
-            const float2 nD = *reinterpret_cast<const float2*>(sp + 3);          // hy, qmax
+            const float nD = *reinterpret_cast<const float*>(sp + 3);           // qmax
             // Rank of my record inside the group.  The resident queue is bucket-contiguous (MSD partition) and the
             // buckets are disjoint depth ranges, so rank = (records of shallower buckets) + (rank inside MY bucket):
             // a lane walks only its own bucket's slice — typically a few dozen records instead of the group's ~256.
@@ -1633,7 +1657,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
             //  cleared when the batch before last was consumed)
             if (tid == 0) SGS_STAGE_DUMMY()
             if (have) {
-                const float qmax = nD.y, hx = nC.w, hy = nD.x;      // log2(o / alpha_min); half extents of {alpha >= alpha_min}
+                const float qmax = nD, hx = nC.z, hy = nC.w;        // log2(o / alpha_min); half extents of {alpha >= alpha_min}
                 SGS_PROF_STAGED_ALL()
                 SGS_STAGE(rank, nA, nB, nC)
                 if (qmax > 0.0f) {
@@ -1658,14 +1682,11 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 #ifdef SGS_TILE_PROF
             ++pn_groups; ++pn_batches;
 #endif
-            if (tid == 0) s_any[par ^ 1u] = 0;
+            if (tid == 0) { s_any[par ^ 1u] = 0; s_hyper[par ^ 1u] = 0; }
             const unsigned base = lo, m = cnt;
-#ifndef SGS_EXPERIMENT_NO_BLEND
+            const bool hyper = s_hyper[par] != 0u;           // (uniform)
             SGS_BLEND_WAVE_LIST()
-#else
-            T = -1.0f;                       // timing experiment: everything but the blend loop
-#endif
-            const bool still_live = __ballot(T > 0.0f) != 0ull;
+            const bool still_live = __ballot(Tm > 0.0f) != 0ull;
             if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
             __syncthreads();
             tile_done = s_any[par] == 0u;
@@ -1737,11 +1758,11 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
-            float4 nA, nB, nC; float2 nD;
+            float4 nA, nB, nC; float nD;
             {   // unconditional (see the single-batch path): lanes past the batch read the group's first splat
                 const float4* sp = reinterpret_cast<const float4*>(splats + gv[(unsigned)tid < min((unsigned)SGS_BATCH, cnt) ? tid : 0]);
                 nA = sp[0]; nB = sp[1]; nC = sp[2];
-                nD = *reinterpret_cast<const float2*>(sp + 3);
+                nD = *reinterpret_cast<const float*>(sp + 3);
             }
             for (unsigned gb = 0; gb < cnt && !tile_done; gb += SGS_BATCH, ++it) {
                 const unsigned par = it & 1u;
@@ -1752,7 +1773,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
                 unsigned qbits = 0;
                 if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
                 if (have) {
-                    const float qmax = nD.y, hx = nC.w, hy = nD.x;
+                    const float qmax = nD, hx = nC.z, hy = nC.w;
                     SGS_STAGE((unsigned)tid, nA, nB, nC)
                     if (qmax > 0.0f) {
                         const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
@@ -1773,12 +1794,13 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
                 if (ngb < cnt) {                 // (uniform) lanes past the next batch re-read its first splat
                     const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + ((unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb) ? tid : 0)]);
                     nA = sp[0]; nB = sp[1]; nC = sp[2];
-                    nD = *reinterpret_cast<const float2*>(sp + 3);
+                    nD = *reinterpret_cast<const float*>(sp + 3);
                 }
                 __syncthreads();                 // batch staged
-                if (tid == 0) s_any[par ^ 1u] = 0;   // the other parity's flag: all its readers are past
+                if (tid == 0) { s_any[par ^ 1u] = 0; s_hyper[par ^ 1u] = 0; }   // the other parity's flags: all their readers are past
+                const bool hyper = s_hyper[par] != 0u;       // (uniform)
                 SGS_BLEND_WAVE_SCAN()
-                const bool still_live = __ballot(T > 0.0f) != 0ull;
+                const bool still_live = __ballot(Tm > 0.0f) != 0ull;
                 if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
@@ -1805,12 +1827,15 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 #endif
     if (inside) {
         float* o = out_rgb + ((size_t)out_py * P.width + px) * 3;
-        const float Tf = __builtin_fabsf(T);            // a finished pixel holds its final transmittance negated
-        o[0] = C0 + Tf * P.bg[0]; o[1] = C1 + Tf * P.bg[1]; o[2] = C2 + Tf * P.bg[2];
-        if (AUX) {                        // expected depth sum(T alpha z) and coverage 1 - T_final
-            float* a = out_aux + ((size_t)out_py * P.width + px) * 2;
-            a[0] = Dz; a[1] = 1.0f - Tf;
-        }
+        if (TF) {
+            // a pixel that never stopped still holds alpha_max T; one that stopped ended with 1 - (the sum of its weights)
+            const float Tf = Tm > 0.0f ? Tm / amax : fmaxf(1.0f - Wsum, 0.0f);
+            o[0] = C0 + Tf * P.bg[0]; o[1] = C1 + Tf * P.bg[1]; o[2] = C2 + Tf * P.bg[2];
+            if (AUX) {                    // expected depth sum(T alpha z) and coverage 1 - T_final
+                float* a = out_aux + ((size_t)out_py * P.width + px) * 2;
+                a[0] = Dz; a[1] = 1.0f - Tf;
+            }
+        } else { o[0] = C0; o[1] = C1; o[2] = C2; }  // black background
     }
     if (STATS) {                         // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
         const unsigned wu = wave_max(inside ? used : 0u);

@@ -316,5 +316,6 @@ inline void* dyn_shared() {
 }
 }  // namespace hipemu
 #define SGS_DYNAMIC_LDS(T, name) T* const name = static_cast<T*>(hipemu::dyn_shared())
+#define SGS_PIN_VGPR(x) ((void)(x))      // (register-class hint of the GPU build)
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     (hipemu::dyn_bytes() = (size_t)(shmem), hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))
