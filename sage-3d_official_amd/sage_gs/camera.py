@@ -15,8 +15,9 @@ closed — the view matrix that results:
   * the benchmark environment adds sin(-45 deg / 2) to component 0 and optionally composes a yaw delta
     (`simple_env.py:1196-1238`), un-normalised; Isaac Sim normalises quaternions, so do we.
 
-Golden vectors for the first three come from running the reference's own importable functions
-(`tests/golden/make_golden.py` -> `tests/golden/pose_golden.json`).
+Golden vectors come from running the reference's own code (`tests/golden/make_golden.py`): the importable pose
+functions -> `tests/golden/pose_golden.json`, and `SimpleVLNEnv.set_start_pose` / `_update_camera_position` themselves,
+on an instance made without the simulator -> `tests/golden/pose_env_golden.json`.
 """
 from __future__ import annotations
 
@@ -84,6 +85,21 @@ def env_orientation(original_quaternion: Sequence[float], yaw: float = None, ini
         qz_d, qw_d = math.sin(d / 2.0), math.cos(d / 2.0)
         return [bx * qw_d + bw * (-qz_d), by * qw_d, bz * qw_d, bw * qw_d - bx * (-qz_d)]
     return [bx, by, bz, bw]
+
+
+def env_fallback_orientation(yaw: float):
+    """simple_env.py:1258-1266: the orientation when no trajectory quaternion is known (before set_start_pose)."""
+    return [-math.sin(yaw / 2.0), 0.0, 0.0, math.cos(yaw / 2.0)]
+
+
+def env_pose(agent_position: Sequence[float], original_quaternion: Sequence[float] = None, yaw: float = None,
+             initial_yaw: float = None):
+    """(position, orientation) exactly as simple_env.py:1196-1284 passes them to `cam.set_world_pose`: the agent's xy at
+    eye height 1.2 m, both as float32."""
+    pos = np.asarray(agent_position, np.float32).copy()
+    pos[2] = EYE_HEIGHT
+    o = env_orientation(original_quaternion, yaw, initial_yaw) if original_quaternion is not None else env_fallback_orientation(yaw)
+    return pos, np.asarray(o, np.float32)
 
 
 def env_start_yaw(rotation_xyzw: Sequence[float]) -> float:

@@ -7,6 +7,11 @@
                         Code/data_pipeline/training_data_construction/generate_actions.py:
                         BatchActionGenerator.yaw_from_quaternion :117).  The reference holds no tests, so these
                        are the only results of the reference itself that can be pinned for this path.
+  pose_env_golden.json — the benchmark environment's pose branch: SimpleVLNEnv.set_start_pose (simple_env.py:1149-1195) and
+                       _update_camera_position (:1196-1317) run AS THEY ARE on an instance made without Isaac Sim (stub
+                       modules stand in for `imageio` / `isaacsim` at import time only; a recording object stands in for
+                       the camera) — captured: the yaw the environment derives and the (position, orientation) it hands to
+                       cam.set_world_pose, at the start pose and after yaw changes.
   usda_golden.json   — the shape of a scene stage built by the reference's own builder from Data/template.usda, as
                        (type, name, value) triples of the two prims the render path reads (see usda_fixture)
   config1_golden.npz — a small BASELINE config-1 frame from the fp64 NumPy oracle (image, tile offsets,
@@ -54,6 +59,82 @@ def pose_fixture():
     json.dump({"source": "Galery23/SAGE-3D_Official @ /root/reference (functions named in make_golden.py)", "cases": cases},
               open(os.path.join(HERE, "pose_golden.json"), "w"), indent=1)
     print("pose_golden.json:", len(cases), "cases")
+
+
+def pose_env_fixture():
+    """pose_env_golden.json: inputs -> what SimpleVLNEnv passes to cam.set_world_pose.  Nothing of the simulator runs: the
+    two methods are pure arithmetic on self._pos / self._yaw / self._original_quaternion / self._initial_yaw."""
+    import contextlib
+    import io
+    import types
+    stubs = {}
+    for name in ("imageio", "isaacsim", "isaacsim.simulation_app"):
+        if name not in sys.modules:
+            stubs[name] = sys.modules[name] = types.ModuleType(name)
+    sys.modules["isaacsim.simulation_app"].SimulationApp = object
+    sys.path.insert(0, os.path.join(REF, "benchmark", "environment_evaluation"))
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            import simple_env
+    finally:
+        for name in stubs:
+            sys.modules.pop(name, None)
+
+    class RecCam:
+        def __init__(self): self.calls = []
+        def set_world_pose(self, position=None, orientation=None):
+            self.calls.append(([float(v) for v in position], [float(v) for v in orientation],
+                               str(np.asarray(position).dtype), str(np.asarray(orientation).dtype)))
+
+    class NoWorld:
+        def step(self, render=True): pass
+
+    def fresh():
+        env = object.__new__(simple_env.SimpleVLNEnv)
+        env._log_function = None
+        env.cam = RecCam()
+        env.world = NoWorld()
+        return env
+
+    rng = np.random.default_rng(7)
+    yaws = [0.0, 0.3, -0.3, 1.0, -2.5, 3.0, -3.1, math.pi / 2, -math.pi / 2] + list(rng.uniform(-math.pi, math.pi, 7))
+    sys.path.insert(0, os.path.join(REF, "data_pipeline", "trajectory_generation"))
+    import trajectory_2d_to_3d as t23
+    cases = []
+    for yaw in yaws:
+        # a trajectory rotation exactly as the reference's own pipeline writes it (transform_trajectory_points)
+        pts = [{"position": [0.0, 0.0, 0.0], "rotation": list(t23.quaternion_from_yaw(float(yaw)))},
+               {"position": [1.0, 1.0, 0.0], "rotation": list(t23.quaternion_from_yaw(float(yaw)))}]
+        t23.transform_trajectory_points(pts, 0.0, 5.0, 0.0, 5.0)
+        rot = [float(v) for v in pts[0]["rotation"]]
+        pos = [float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8)), float(rng.uniform(0, 2))]
+        env = fresh()
+        with contextlib.redirect_stdout(io.StringIO()):
+            env.set_start_pose(list(pos), list(rot))
+        start = env.cam.calls[-1]
+        steps = []
+        for d in (0.004, 0.02, -0.35, 1.3, float(rng.uniform(-3, 3))):     # yaw changes: below / above the 0.01 rad switch
+            env._yaw = env._initial_yaw + d                                 # (what the step loop does, simple_env.py:2054)
+            env._pos = np.array([pos[0] + 0.25 * d, pos[1] - 0.5 * d, pos[2]], dtype=np.float32)
+            with contextlib.redirect_stdout(io.StringIO()):
+                env._update_camera_position()
+            c = env.cam.calls[-1]
+            steps.append({"yaw": float(env._yaw), "agent_position": [float(v) for v in env._pos],
+                          "camera_position": c[0], "orientation": c[1]})
+        cases.append({"trajectory_yaw": float(yaw), "position": pos, "rotation_xyzw": rot,
+                      "start_yaw": float(env._initial_yaw), "start_camera_position": start[0], "start_orientation": start[1],
+                      "dtypes": [start[2], start[3]], "steps": steps})
+    # the fallback branch (no trajectory quaternion known): orientation from the yaw alone
+    fb = []
+    for yaw in (0.0, 0.7, -2.0):
+        env = fresh(); env._pos = np.array([1.0, 2.0, 0.3], dtype=np.float32); env._yaw = yaw
+        with contextlib.redirect_stdout(io.StringIO()):
+            env._update_camera_position()
+        fb.append({"yaw": yaw, "camera_position": env.cam.calls[-1][0], "orientation": env.cam.calls[-1][1]})
+    json.dump({"source": "SimpleVLNEnv.set_start_pose / _update_camera_position of Galery23/SAGE-3D_Official run by make_golden.py "
+                         "(no simulator: stub imports, recording camera)", "cases": cases, "fallback": fb},
+              open(os.path.join(HERE, "pose_env_golden.json"), "w"), indent=1)
+    print("pose_env_golden.json:", len(cases), "cases x", len(cases[0]["steps"]), "steps,", len(fb), "fallback")
 
 
 def usda_fixture():
@@ -125,6 +206,7 @@ def config1_fixture():
 if __name__ == "__main__":
     if "--frames-only" not in sys.argv:          # (the pose / usda fixtures import the reference; the frame fixture does not)
         pose_fixture()
+        pose_env_fixture()
         usda_fixture()
     if "--reference-only" not in sys.argv:
         config1_fixture()

@@ -103,3 +103,52 @@ def test_oracle_reproduces_config1_golden(gold, which):
     assert (tiles == gold["tiles"]).all() and (rect[vis] == gold["rect"][vis]).all() and (depth == gold["depth_bits"]).all()
     assert (aux["n_contrib"] == gold["n_contrib"]).all()
     assert np.abs(np.asarray(img, np.float64) - gold["image"]).max() < 1e-6
+
+
+# ---- the benchmark environment's pose branch, against the reference's own methods (pose_env_golden.json) ----
+@pytest.fixture(scope="module")
+def env_poses():
+    return json.load(open(os.path.join(GOLD, "pose_env_golden.json")))
+
+
+def test_env_start_pose_matches_simple_env(env_poses):
+    """SimpleVLNEnv.set_start_pose (simple_env.py:1149-1195): the yaw it derives and the pose it hands to the camera."""
+    for c in env_poses["cases"]:
+        yaw0 = camera.env_start_yaw(c["rotation_xyzw"])
+        assert abs(yaw0 - c["start_yaw"]) < 1e-12
+        assert abs(_wrap(yaw0 - c["trajectory_yaw"])) < 1e-9            # it undoes the +pi of the trajectory transform
+        pos, o = camera.env_pose(c["position"], c["rotation_xyzw"], yaw0, yaw0)
+        assert pos.dtype == np.float32 and o.dtype == np.float32 and c["dtypes"] == ["float32", "float32"]
+        assert pos.tolist() == c["start_camera_position"]              # float32 of the same numbers: bit for bit
+        assert np.allclose(o, c["start_orientation"], rtol=0, atol=1e-7)
+
+
+def test_env_camera_update_matches_simple_env(env_poses):
+    """SimpleVLNEnv._update_camera_position (simple_env.py:1196-1284) after yaw changes on both sides of its 0.01 rad switch."""
+    n_switch = 0
+    for c in env_poses["cases"]:
+        for s in c["steps"]:
+            pos, o = camera.env_pose(s["agent_position"], c["rotation_xyzw"], s["yaw"], c["start_yaw"])
+            assert pos.tolist() == s["camera_position"] and abs(pos[2] - 1.2) < 1e-6
+            assert np.allclose(o, s["orientation"], rtol=0, atol=1e-7), (c["trajectory_yaw"], s["yaw"])
+            n_switch += abs(s["yaw"] - c["start_yaw"]) > 0.01
+    assert n_switch >= 3 * len(env_poses["cases"])                     # the composed branch was exercised
+    for f in env_poses["fallback"]:
+        pos, o = camera.env_pose([1.0, 2.0, 0.3], None, f["yaw"])
+        assert pos.tolist() == f["camera_position"] and np.allclose(o, f["orientation"], rtol=0, atol=1e-7)
+
+
+def test_env_pose_gives_a_rigid_level_view(env_poses):
+    """The environment's 4-vector is not a unit quaternion (simple_env.py:1212-1221 adds a scalar to one component); Isaac
+    Sim normalises it, and so does view_from_isaac_pose: the view stays rigid and the camera stays level (a rotation
+    about +Z only), looking along the heading the 4-vector encodes when read scalar-first."""
+    for c in env_poses["cases"]:
+        for s in [dict(camera_position=c["start_camera_position"], orientation=c["start_orientation"])] + c["steps"]:
+            V = camera.view_from_isaac_pose(s["camera_position"], s["orientation"])
+            R = V[:3, :3]
+            assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+            w, x, y, z = s["orientation"]                     # Isaac reads the 4-vector scalar-first
+            assert abs(x) < 1e-12 and abs(y) < 1e-12
+            a = 2.0 * math.atan2(z, w)                        # a rotation about +Z: the camera stays level
+            assert np.allclose(R[2], [math.cos(a), math.sin(a), 0.0], atol=1e-9)      # camera +Z = heading
+            assert np.allclose(R[1], [0.0, 0.0, -1.0], atol=1e-9)                     # camera +Y = world down
