@@ -1181,43 +1181,47 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_NEXT(OV)                                                                                   \
     const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 3; \
     mm &= mm - 1ull;
-// O = byte offset of the splat's slot in the five staging arrays (8 B per splat in each); AL = alpha / alpha_max or 0
-#define SGS_ALPHA_F(O, AL)                                                                             \
+// O = byte offset of the splat's slot in the five staging arrays (8 B per splat in each).  The reads are left where the
+// compiler puts them — three pairs, evaluate, four times over, then the colours: issuing a trip's twenty reads ahead of
+// its arithmetic (volatile reads + a scheduling barrier) was measured 8 % SLOWER with or without register spills (r03d):
+// the CU's LDS pipe is shared by 24 waves, and bursts queue behind each other.
+#define SGS_LOAD(O, N)                                                                                 \
+    const float2 N##0 = SGS_AT(s_p0, float2, O), N##1 = SGS_AT(s_p1, float2, O), N##2 = SGS_AT(s_p2, float2, O), \
+                 N##3 = SGS_AT(s_p3, float2, O), N##4 = SGS_AT(s_p4, float2, O);
+// AL = alpha / alpha_max, or 0 outside the cut-off
+#define SGS_ALPHA_F(O, N, AL)                                                                          \
     float AL;                                                                                          \
     {                                                                                                  \
-        const float2 p0 = SGS_AT(s_p0, float2, O), p1 = SGS_AT(s_p1, float2, O), p2 = SGS_AT(s_p2, float2, O); \
-        const float dx = p0.x - fpx, dy = p0.y - fpy;                                                  \
-        const float u = __builtin_fmaf(p1.y, dy, dx);                                                  \
-        const float q = __builtin_fmaf(p1.x * u, u, __builtin_fmaf(p2.x * dy, dy, p2.y));   /* A u^2 + (C' dy^2 + nlo) */ \
-        AL = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));                     \
+        const float dx = (N##0).x - fpx, dy = (N##0).y - fpy;                                              \
+        const float u = __builtin_fmaf((N##1).y, dy, dx);                                                \
+        const float q = __builtin_fmaf((N##1).x * u, u, __builtin_fmaf((N##2).x * dy, dy, (N##2).y));   /* A u^2 + (C' dy^2 + nlo) */ \
+        AL = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));                         \
         SGS_PROF_EVAL(q < cq, (O) >> 3)                                                                \
     }
 // the exact variant (a batch holding a splat with an indefinite conic): S6's power > 0 skip as well; the same q, hence the
 // same AL bit for bit, for every splat with A, C' >= 0
-#define SGS_ALPHA_X(O, AL)                                                                             \
+#define SGS_ALPHA_X(O, N, AL)                                                                          \
     float AL;                                                                                          \
     {                                                                                                  \
-        const float2 p0 = SGS_AT(s_p0, float2, O), p1 = SGS_AT(s_p1, float2, O), p2 = SGS_AT(s_p2, float2, O); \
-        const float dx = p0.x - fpx, dy = p0.y - fpy;                                                  \
-        const float u = __builtin_fmaf(p1.y, dy, dx);                                                  \
-        const float au = p1.x * u, cd = p2.x * dy;                                                     \
-        const float q = __builtin_fmaf(au, u, __builtin_fmaf(cd, dy, p2.y));                           \
+        const float dx = (N##0).x - fpx, dy = (N##0).y - fpy;                                              \
+        const float u = __builtin_fmaf((N##1).y, dy, dx);                                                \
+        const float au = (N##1).x * u, cd = (N##2).x * dy;                                                 \
+        const float q = __builtin_fmaf(au, u, __builtin_fmaf(cd, dy, (N##2).y));                         \
         const float q2 = __builtin_fmaf(au, u, cd * dy);                       /* the sign S6 tests */ \
         const bool valid = q < cq && q2 >= 0.0f;                                                       \
         const float e = SGS_SAT(SGS_EXP2(-q));                                                         \
         AL = valid ? e : 0.0f;                                                                         \
         SGS_PROF_EVAL(valid, (O) >> 3)                                                                 \
     }
-#define SGS_APPLY(O, AL)                                                                               \
+#define SGS_APPLY(N, AL)                                                                               \
     {                                                                                                  \
-        const float2 p3 = SGS_AT(s_p3, float2, O), p4 = SGS_AT(s_p4, float2, O);                       \
         float wgt = (AL) * Tm;                                                  /* alpha T */          \
         const float tt = __builtin_fmaf(-wgt, amax, Tm);                        /* alpha_max T (1 - alpha) */ \
-        const float lv = SGS_SAT(__builtin_fmaf(tt, big, nt_big));          /* 0: ends here, or ended before */ \
+        const float lv = SGS_SAT(__builtin_fmaf(tt, big, nt_big));              /* 0: ends here, or ended before */ \
         wgt *= lv;                                 /* the splat that would end the pixel is not blended */ \
         Tm = tt * lv;                                                                                  \
-        C0 = __builtin_fmaf(wgt, p3.x, C0); C1 = __builtin_fmaf(wgt, p3.y, C1); C2 = __builtin_fmaf(wgt, p4.x, C2); \
-        if (AUX) Dz = __builtin_fmaf(wgt, p4.y, Dz);        /* expected depth (template instantiation only) */ \
+        C0 = __builtin_fmaf(wgt, (N##3).x, C0); C1 = __builtin_fmaf(wgt, (N##3).y, C1); C2 = __builtin_fmaf(wgt, (N##4).x, C2); \
+        if (AUX) Dz = __builtin_fmaf(wgt, (N##4).y, Dz);      /* expected depth (template instantiation only) */ \
         if (TF) Wsum += wgt;                                                                           \
     }
 #define SGS_REPLAY(O, AL)                                                                              \
@@ -1228,8 +1232,9 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     }
 #define SGS_TRIP(ALPHA, o0, o1, o2, o3)                                                                \
     const float Tb = Tm;                                                                               \
-    ALPHA(o0, al0) ALPHA(o1, al1) ALPHA(o2, al2) ALPHA(o3, al3)                                        \
-    SGS_APPLY(o0, al0) SGS_APPLY(o1, al1) SGS_APPLY(o2, al2) SGS_APPLY(o3, al3)                        \
+    SGS_LOAD(o0, sa) SGS_LOAD(o1, sb) SGS_LOAD(o2, sc) SGS_LOAD(o3, sd)                                \
+    ALPHA(o0, sa, al0) ALPHA(o1, sb, al1) ALPHA(o2, sc, al2) ALPHA(o3, sd, al3)                        \
+    SGS_APPLY(sa, al0) SGS_APPLY(sb, al1) SGS_APPLY(sc, al2) SGS_APPLY(sd, al3)                        \
     if (__ballot(Tm > 0.0f) == 0ull) {                                                                 \
         /* the wave's last pixel ended in this trip: replay it to find the splat that did it */        \
         if (STATS) {                                                                                   \
@@ -1387,7 +1392,10 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // AUX: expected depth + coverage outputs.  STATS: D_f bookkeeping.  TF: the final transmittance of stopped pixels is needed
 // (AUX, or a background that is not black) — one more add per (pixel, splat).
 template <bool AUX, bool STATS, bool TF>
-__global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGroup G) {
+#ifndef SGS_RENDER_WGS
+#define SGS_RENDER_WGS 6
+#endif
+__global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(const FrameGroup G) {
     static_assert(TF || !AUX, "the coverage output needs the final transmittance");
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
@@ -1758,22 +1766,19 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
 
         // ---- 3. blend the group in batches of 256 ------------------------------------------------
         if (!tile_done) {
-            float4 nA, nB, nC; float nD;
-            {   // unconditional (see the single-batch path): lanes past the batch read the group's first splat
-                const float4* sp = reinterpret_cast<const float4*>(splats + gv[(unsigned)tid < min((unsigned)SGS_BATCH, cnt) ? tid : 0]);
-                nA = sp[0]; nB = sp[1]; nC = sp[2];
-                nD = *reinterpret_cast<const float*>(sp + 3);
-            }
+            // (a group of more than one batch is one oversized depth bucket: rare — no splat prefetch is carried across the
+            //  blend here, its registers are worth more to the common path)
             for (unsigned gb = 0; gb < cnt && !tile_done; gb += SGS_BATCH, ++it) {
                 const unsigned par = it & 1u;
                 const unsigned m = min((unsigned)SGS_BATCH, cnt - gb);
                 const unsigned base = lo + gb;               // queue position of this batch
-                // stage the prefetched batch + per-quadrant overlap ballots
                 const bool have = (unsigned)tid < m;
                 unsigned qbits = 0;
                 if (tid == 0) SGS_STAGE_DUMMY()       // (the arena is shared with the sort scratch: rewritten per batch)
                 if (have) {
-                    const float qmax = nD, hx = nC.z, hy = nC.w;
+                    const float4* sp = reinterpret_cast<const float4*>(splats + gv[gb + (unsigned)tid]);
+                    const float4 nA = sp[0], nB = sp[1], nC = sp[2];
+                    const float qmax = *reinterpret_cast<const float*>(sp + 3), hx = nC.z, hy = nC.w;
                     SGS_STAGE((unsigned)tid, nA, nB, nC)
                     if (qmax > 0.0f) {
                         const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
@@ -1788,13 +1793,6 @@ __global__ __launch_bounds__(256, AUX ? 4 : 6) void k_tile_render(const FrameGro
                 for (int q = 0; q < 4; ++q) {
                     const unsigned long long bal = __ballot((qbits >> q) & 1u);
                     if (lane == 0) s_ball[par][q][wave] = bal;
-                }
-                // prefetch the next batch of this group (loads stay in flight across the blend loop)
-                const unsigned ngb = gb + SGS_BATCH;
-                if (ngb < cnt) {                 // (uniform) lanes past the next batch re-read its first splat
-                    const float4* sp = reinterpret_cast<const float4*>(splats + gv[ngb + ((unsigned)tid < min((unsigned)SGS_BATCH, cnt - ngb) ? tid : 0)]);
-                    nA = sp[0]; nB = sp[1]; nC = sp[2];
-                    nD = *reinterpret_cast<const float*>(sp + 3);
                 }
                 __syncthreads();                 // batch staged
                 if (tid == 0) { s_any[par ^ 1u] = 0; s_hyper[par ^ 1u] = 0; }   // the other parity's flags: all their readers are past
