@@ -1366,7 +1366,9 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
 // Workgroup b renders position b of k_tile_scan's longest-queue-first order.
 #define SGS_BATCH 256
 #define SGS_NB 256
-#define SGS_BUCKET_SHIFT 18
+#ifndef SGS_PART_MIN
+#define SGS_PART_MIN 64               // queues up to this long are one group ranked all pairs; longer ones are partitioned into depth buckets
+#endif
 #ifndef SGS_GROUP
 #define SGS_GROUP 192                 // soft cap of a group: buckets are added while the total stays below (192 vs 256: -1.3 % per frame, r02y)
 #endif
@@ -1421,7 +1423,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
-    __shared__ unsigned s_wsum[4], s_wne[4], s_fill;
+    __shared__ unsigned s_wsum[4], s_wne[4], s_fill, s_kmn[4], s_kmx[4];
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_hyper[2];                   // the batch holds a splat with an indefinite conic: exact trips (by parity)
@@ -1477,20 +1479,24 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     // n <= SGS_QCAP: the queue is read from HBM exactly once (4 records per lane, held in registers
     // between the histogram and the scatter) and lives in LDS from then on.  Longer queues are
     // partitioned through HBM into the alt buffers and groups are loaded into s_q one at a time.
-    const bool parted = n > SGS_GROUP;
+    const bool parted = n > SGS_PART_MIN;
     const bool in_lds = n <= SGS_QCAP;
-    const unsigned kbase = __float_as_uint(P.near_z) >> SGS_BUCKET_SHIFT;     // every key is > bits(near)
+    // The SGS_NB buckets span the depth range of THIS tile's queue (keys are the bits of positive floats: monotone), not a
+    // fixed grid of the frustum: a tile mostly sees one or two surfaces, its keys sit in a sliver of the depth range, and
+    // buckets cut from that sliver hold a handful of records each — the bucket-local rank below is then one or two trips
+    // instead of ten, and a bucket too long for one batch (the slow paths) all but disappears.  Any monotone map is correct:
+    // bucket(key) = 0 at or below klo, (key - klo) >> ksh above it, capped at SGS_NB - 1.
+    unsigned klo = 0u, ksh = 0u;
+#define SGS_BUCKET_OF(key) ((key) <= klo ? 0u : min((unsigned)(SGS_NB - 1), ((key) - klo) >> ksh))
     if (tid < 2) { s_any[tid] = 0; s_hyper[tid] = 0; }
     if (tid < 64) reinterpret_cast<unsigned*>(&s_ball[0][0][0])[tid] = 0u;   // both parities: 2 x 4 quadrants x 4 x 64 bits
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
     {
-        unsigned long long rq[4];
-        if (in_lds) {
+        unsigned long long rq[4];                      // the queue (n <= SGS_QCAP), or its first SGS_QCAP records: a sample of its depths
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned i = (unsigned)tid + 256u * (unsigned)r;
-                rq[r] = i < n ? rec[beg + i] : ~0ull;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const unsigned i = (unsigned)tid + 256u * (unsigned)r;
+            rq[r] = i < n ? rec[beg + i] : ~0ull;
         }
 #ifdef SGS_TILE_PROF
         __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory");
@@ -1501,12 +1507,34 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             if (tid < 8) s_q[SGS_GROUP + tid] = ~0ull;
         } else {
             s_bcnt[tid] = 0;
+            {   // the depth range of the records held (all of them, or the sample of a long queue: widened by half on both sides)
+                unsigned kmn = 0xffffffffu, kmx = 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if ((unsigned)tid + 256u * (unsigned)r < n) {
+                        const unsigned key = (unsigned)(rq[r] >> 32);
+                        kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
+                    }
+                kmn = wave_min(kmn); kmx = wave_max(kmx);
+                if (lane == 0) { s_kmn[wave] = kmn; s_kmx[wave] = kmx; }
+            }
             __syncthreads();
+            {
+                unsigned kmn = s_kmn[0], kmx = s_kmx[0];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) { kmn = s_kmn[w] < kmn ? s_kmn[w] : kmn; kmx = s_kmx[w] > kmx ? s_kmx[w] : kmx; }
+                if (!in_lds) {
+                    const unsigned half = (kmx - kmn) >> 1;
+                    kmn = kmn > half ? kmn - half : 0u; kmx = kmx < 0xffffffffu - half ? kmx + half : 0xffffffffu;
+                }
+                const unsigned span = kmx - kmn;                                  // (span >> ksh) < SGS_NB
+                klo = kmn; ksh = span < (unsigned)SGS_NB ? 0u : 24u - (unsigned)__clz((int)span);
+            }
             if (in_lds) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if ((unsigned)tid + 256u * (unsigned)r < n)
-                        atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(rq[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                        atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(rq[r] >> 32))], 1u);
             } else {
                 for (unsigned i0 = 0; i0 < n; i0 += 1024) {                 // four loads in flight per lane
                     unsigned long long x[4];
@@ -1518,7 +1546,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (i0 + (unsigned)tid + 256u * (unsigned)r < n)
-                            atomicAdd(&s_bcnt[min((unsigned)(SGS_NB - 1), ((unsigned)(x[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase)], 1u);
+                            atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(x[r] >> 32))], 1u);
                 }
             }
             __syncthreads();
@@ -1543,7 +1571,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if ((unsigned)tid + 256u * (unsigned)r < n) {
-                        const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(rq[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                        const unsigned bk = SGS_BUCKET_OF((unsigned)(rq[r] >> 32));
                         s_q[atomicAdd(&s_bcnt[bk], 1u)] = rq[r];
                     }
                 if (tid < 8) s_q[n + tid] = ~0ull;
@@ -1605,7 +1633,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x[r] >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                    const unsigned bk = SGS_BUCKET_OF((unsigned)(x[r] >> 32));
                     if (i0 + (unsigned)tid + 256u * (unsigned)r < n && bk >= b0 && bk <= b1)
                         s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
                 }
@@ -1635,7 +1663,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             unsigned rank = 0;
             unsigned bbeg = win_lo, blen = 0;
             if (parted && have) {
-                const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(mine >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                const unsigned bk = SGS_BUCKET_OF((unsigned)(mine >> 32));
                 bbeg = bk ? s_bcnt[bk - 1] : 0u;            // cursors after the scatter = bucket ends = next bucket's start
                 blen = s_bcnt[bk] - bbeg;
             }
@@ -1723,9 +1751,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             // One oversized bucket of a long queue: radix sort through HBM.  The bucket's records are filtered
             // out of the queue and split into a key half and a slot half inside two scratch spans.
             const unsigned g0 = s_ne_bkt[e0], g1 = s_ne_bkt[e1];
-            unsigned sub = (kbase + g0) << SGS_BUCKET_SHIFT;
-            unsigned nbits = (g1 == SGS_NB - 1) ? 32u : SGS_BUCKET_SHIFT + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
-            if (nbits >= 32u) { sub = 0u; nbits = 32u; }
+            // buckets g0..g1 hold the keys [klo + (g0 << ksh), klo + ((g1 + 1) << ksh)); the first and the last bucket are open-ended
+            unsigned sub = klo + (g0 << ksh);
+            unsigned nbits = ksh + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
+            if (g0 == 0u || g1 == SGS_NB - 1 || nbits >= 32u) { sub = 0u; nbits = 32u; }
             // alt[beg+lo, +cnt) and part[beg+lo, +cnt) are private to this bucket (cnt 8-byte slots = keys[cnt] | slots[cnt]).
             unsigned* b_k = reinterpret_cast<unsigned*>(alt + beg + lo); unsigned* b_v = b_k + cnt;     // keys[cnt] | slots[cnt]
             unsigned* a_k = reinterpret_cast<unsigned*>(part + beg + lo); unsigned* a_v = a_k + cnt;    // ping-pong space
@@ -1737,7 +1766,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 bool take = false;
                 if (i < n) {
                     x = rec[beg + i];
-                    const unsigned bk = min((unsigned)(SGS_NB - 1), ((unsigned)(x >> 32) >> SGS_BUCKET_SHIFT) - kbase);
+                    const unsigned bk = SGS_BUCKET_OF((unsigned)(x >> 32));
                     take = bk >= g0 && bk <= g1;
                 }
                 const unsigned long long m = __ballot(take);
