@@ -930,9 +930,11 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
             const Splat& sp = tmp[(size_t)i];
             float* o = (float*)((char*)host_dst + i * elem);
             o[0] = sp.x; o[1] = sp.y;
-            // (the record holds the completed square A (dx + k dy)^2 + C' dy^2 in the slots A, B, C: B = 2 A k, C = A k^2 + C')
-            const double A_ = sp.A, k_ = sp.B, Cp_ = sp.C;
-            o[2] = (float)(A_ / (0.5 * l2e)); o[3] = (float)(2.0 * A_ * k_ / l2e); o[4] = (float)((A_ * k_ * k_ + Cp_) / (0.5 * l2e));
+            // (the record holds the roots of the completed square A (dx + k dy)^2 + C' dy^2 in the slots A, B, C: a = sqrt(A),
+            //  a k, c = +-sqrt(|C'|);  B = 2 A k = 2 a (a k),  C = A k^2 + C' = (a k)^2 + C')
+            const double a_ = sp.A, ak_ = sp.B, c_ = sp.C;
+            const double A_ = a_ * a_, Cp_ = c_ * std::fabs(c_);
+            o[2] = (float)(A_ / (0.5 * l2e)); o[3] = (float)(2.0 * a_ * ak_ / l2e); o[4] = (float)((ak_ * ak_ + Cp_) / (0.5 * l2e));
             o[5] = sp.o; o[6] = sp.r; o[7] = sp.g; o[8] = sp.b;
             memcpy(o + 9, &sp.key, 4); memcpy(o + 10, &sp.rect01, 4); memcpy(o + 11, &sp.rect23, 4);
         }

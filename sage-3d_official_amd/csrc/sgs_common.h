@@ -124,10 +124,12 @@ struct FrameGroup {
 // k_preprocess (at the Gaussian's ORIGINAL index: with the scene in Z-order that is a scatter, and a 48-B record
 // straddling sectors made every such write a read-modify-write) and gathered by k_tile_render.  Everything the composite
 // needs per (splat, tile) that does not depend on the tile is computed here once, per splat:
-//   word 0..3   x, y, A, k            q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e)  (A = conic_a log2(e)/2, B = conic_b log2(e), ...)
-//                                     stored as the completed square A (dx + k dy)^2 + C' dy^2:  k = B / 2A in the slot `B`,
-//   word 4..7   C', nlo, r, g         C' = C - B^2 / 4A in the slot `C`;  nlo = log2(alpha_max / opacity): the composite evaluates
-//                                     q = q2 + nlo, alpha / alpha_max = min(1, 2^-q), and alpha >= alpha_min <=> q <= log2(alpha_max / alpha_min)
+//   word 0..3   x, y, a, a k          q2(d) = A dx^2 + B dx dy + C dy^2 = -power * log2(e)  (A = conic_a log2(e)/2, B = conic_b log2(e), ...)
+//                                     as the completed square A (dx + k dy)^2 + C' dy^2 (k = B / 2A, C' = C - B^2 / 4A), stored by its
+//                                     roots a = sqrt(A) (slot `A`), a k (slot `B`):  q2 = U^2 + V^2,  U = a (dx + k dy),  V = c dy
+//   word 4..7   c, nlo, r, g          c = sqrt(|C'|) with the sign of C' (slot `C`; negative: an indefinite fp32 conic);  nlo = log2(alpha_max /
+//                                     opacity): the composite evaluates q = q2 + nlo, alpha / alpha_max = min(1, 2^-q), and
+//                                     alpha >= alpha_min <=> q <= log2(alpha_max / alpha_min)
 //   word 8..11  b, depth bits, hx, hy hx, hy = half extents of the ellipse {alpha >= alpha_min}, padded outward
 //   word 12..15 qmax, opacity, rect x0|y0<<16, rect x1|y1<<16     qmax = log2(opacity / alpha_min); rect = S3's reference rect (tests)
 struct alignas(64) Splat {

@@ -454,10 +454,14 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                      C64 = (0.5 * 1.4426950408889634) * (double)cc;
         const double iA = A64 > 0.0 ? 1.0 / A64 : 0.0;
         const double k64 = 0.5 * B64 * iA, Cp64 = C64 - 0.25 * B64 * B64 * iA;
+        // ... and the record holds the ROOTS a = sqrt(A), a k, c = sqrt(|C'|) (with the sign of C': negative = the fp32 conic
+        // rounded to an indefinite form), so that the composite evaluates  q2 = U^2 + V^2,  U = a (dx + k dy),  V = c dy  with
+        // two fmas for U, one for V and two for the sum (k_tile_render)
+        const double a64 = sqrt(A64 > 0.0 ? A64 : 0.0), c64 = Cp64 < 0.0 ? -sqrt(-Cp64) : sqrt(Cp64);
         // the opacity enters the composite's exponent: alpha / alpha_max = min(1, 2^-(q2 + nlo)),  nlo = log2(alpha_max / o)
         const float nlo = __log2f(P.alpha_max) - __log2f(g0.w);
-        sp[0] = make_float4(sx, sy, (float)A64, (float)k64);
-        sp[1] = make_float4((float)Cp64, nlo, r, g);
+        sp[0] = make_float4(sx, sy, (float)a64, (float)(a64 * k64));
+        sp[1] = make_float4((float)c64, nlo, r, g);
         sp[2] = make_float4(b, depth, ext_x, ext_y);
         sp[3] = make_float4(qmax, g0.w, __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
@@ -1134,17 +1138,18 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 // modifier (result saturated to [0, 1], NaN -> 0) are free.  The composite is issue-bound, so the per-pixel work is
 // written for the smallest issue COST: no compare, select or min is left in the common trip — every predicate is a
 // saturated fma, i.e. a factor 0 / 1, and every constant is folded into the splat once (k_preprocess), not per pixel:
-//   * q2 = A dx^2 + B dx dy + C dy^2 = -power log2(e) is stored as the completed square A (dx + k dy)^2 + C' dy^2
-//     (k = B / 2A, C' = C - B^2 / 4A: no cancellation between large terms for needle-shaped splats), and the opacity
-//     rides in the same fma chain:   q = A u^2 + (C' dy^2 + nlo),  nlo = log2(alpha_max / o)   =>   2^-q = alpha / alpha_max;
+//   * q2 = A dx^2 + B dx dy + C dy^2 = -power log2(e) is evaluated as the completed square A (dx + k dy)^2 + C' dy^2
+//     (k = B / 2A, C' = C - B^2 / 4A: no cancellation between large terms for needle-shaped splats) from the ROOTS
+//     a = sqrt(A), c = sqrt(C'):  q2 = U^2 + V^2,  U = a (dx + k dy),  V = c dy, and the opacity rides in the same fma
+//     chain:   q = U^2 + (V^2 + nlo),  nlo = log2(alpha_max / o)   =>   2^-q = alpha / alpha_max;
 //   * S6's clamp  alpha = min(alpha_max, o e^power)  is the clamp modifier of the v_exp:   E = sat(2^-q) = alpha / alpha_max;
 //   * S6's cut-off  alpha >= alpha_min  <=>  q <= cq = log2(alpha_max / alpha_min)  is  vf = sat((cq - q) 2^100)  — exactly
 //     0 or 1 for any fp32 q (the smallest non-zero |cq - q| times 2^100 is far above 1; q = cq counts as outside, a set of
 //     measure zero inside the margin the tests check two-sidedly; NaN -> 0);
-//     S6's other skip, power > 0, cannot fire while A >= 0 and C' >= 0 (then q2 >= 0 term by term).  A splat whose fp32
-//     conic rounded to an indefinite form (C' < 0: needles hundreds of pixels long) is flagged at staging and its whole
-//     batch runs the EXACT variant of the trip (SGS_ALPHA_X: compares and selects, bit-identical results for every
-//     other splat of the batch);
+//     S6's other skip, power > 0, cannot fire while C' >= 0 (then q2 is a sum of squares).  A splat whose fp32 conic rounded
+//     to an indefinite form (C' < 0, stored as c < 0: needles hundreds of pixels long) is flagged at staging and its whole
+//     batch runs the EXACT variant of the trip (SGS_ALPHA_X: q2 = U^2 - V^2 for such a splat, compares and selects;
+//     bit-identical results for every other splat of the batch);
 //   * the pixel carries Tm = alpha_max T, so that  w = E vf Tm = alpha T  is the blend weight with no further factor and
 //     tt = Tm - alpha_max w = alpha_max T (1 - alpha);  S6's stop rule  T (1 - alpha) < t_min  is  lv = sat((tt - alpha_max
 //     t_min) 2^100), again exactly 0 or 1:  w *= lv (the splat that would end the pixel is not blended),  Tm = tt lv.
@@ -1154,8 +1159,13 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 //   * D_f (how far into the queue the tile's pixels read) is not tracked per splat: when a trip leaves a wave with
 //     no live pixel — once per wave and tile — the trip is replayed from the saved Tm to find the splat that ended
 //     the last pixel.
-// Staged batch, five arrays of 8-byte pairs at ONE byte offset O = 8 j (so a trip computes no addresses):
-//   s_p0[j] = (x, y)   s_p1[j] = (A, k)   s_p2[j] = (C', nlo)   s_p3[j] = (r, g)   s_p4[j] = (b, view depth)
+// Staged batch, five arrays of 8-byte pairs at ONE byte offset O = 8 j (so a trip computes no addresses); the tile-relative
+// constants are computed at staging, once per splat and tile:
+//   s_p0[j] = (m, a)   s_p1[j] = (a k, c ry)   s_p2[j] = (c, nlo)   s_p3[j] = (r, g)   s_p4[j] = (b, view depth)
+//   m = a rx + a k ry,  (rx, ry) = centre - tile origin;  for the pixel (lx, ly) of the tile:
+//   U = m - a lx - a k ly = a (dx + k dy),   V = c ry - c ly = c dy,   q = U^2 + (V^2 + nlo)      — five fmas.
+// Tile-relative coordinates keep every term of U and V at the magnitude of sqrt(q) wherever a pixel can pass the cut-off
+// (a far centre comes with a small a), so nothing cancels.
 // A wave walks the splats of the batch that can touch ITS quadrant four per trip: the four alphas are
 // independent (ILP hides the LDS and transcendental latency), then the short sequential part (T, colour, stop)
 // is applied in depth order.  A short tail reads the inert dummy splat at index SGS_BATCH (nlo = 1e30: E = vf = 0).
@@ -1181,10 +1191,10 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_NEXT(OV)                                                                                   \
     const unsigned OV = (mm != 0ull ? gwb + (unsigned)(__ffsll((long long)mm) - 1) : (unsigned)SGS_BATCH) << 3; \
     mm &= mm - 1ull;
-// O = byte offset of the splat's slot in the five staging arrays (8 B per splat in each).  The reads are left where the
-// compiler puts them — three pairs, evaluate, four times over, then the colours: issuing a trip's twenty reads ahead of
-// its arithmetic (volatile reads + a scheduling barrier) was measured 8 % SLOWER with or without register spills (r03d):
-// the CU's LDS pipe is shared by 24 waves, and bursts queue behind each other.
+// O = byte offset of the splat's slot in the five staging arrays (8 B per splat in each).  The order of a trip's reads and
+// arithmetic is the compiler's: every order forced on it was measured slower (r03c/d/f/i) — all reads ahead of the
+// arithmetic through volatile reads and a scheduling barrier +8 %, sched_group_barrier pipelines of "a splat's reads, then
+// the previous splat's alpha" +7 ... +15 %, 16-byte reads instead of pairs +3 ... +7 %.
 #define SGS_LOAD(O, N)                                                                                 \
     const float2 N##0 = SGS_AT(s_p0, float2, O), N##1 = SGS_AT(s_p1, float2, O), N##2 = SGS_AT(s_p2, float2, O), \
                  N##3 = SGS_AT(s_p3, float2, O), N##4 = SGS_AT(s_p4, float2, O);
@@ -1192,9 +1202,9 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_ALPHA_F(O, N, AL)                                                                          \
     float AL;                                                                                          \
     {                                                                                                  \
-        const float dx = (N##0).x - fpx, dy = (N##0).y - fpy;                                              \
-        const float u = __builtin_fmaf((N##1).y, dy, dx);                                                \
-        const float q = __builtin_fmaf((N##1).x * u, u, __builtin_fmaf((N##2).x * dy, dy, (N##2).y));   /* A u^2 + (C' dy^2 + nlo) */ \
+        const float U = __builtin_fmaf(-(N##1).x, ly, __builtin_fmaf(-(N##0).y, lx, (N##0).x));   /* a (dx + k dy) */ \
+        const float V = __builtin_fmaf(-(N##2).x, ly, (N##1).y);                                  /* c dy */ \
+        const float q = __builtin_fmaf(U, U, __builtin_fmaf(V, V, (N##2).y));                     /* U^2 + (V^2 + nlo) */ \
         AL = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));                         \
         SGS_PROF_EVAL(q < cq, (O) >> 3)                                                                \
     }
@@ -1203,11 +1213,11 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 #define SGS_ALPHA_X(O, N, AL)                                                                          \
     float AL;                                                                                          \
     {                                                                                                  \
-        const float dx = (N##0).x - fpx, dy = (N##0).y - fpy;                                              \
-        const float u = __builtin_fmaf((N##1).y, dy, dx);                                                \
-        const float au = (N##1).x * u, cd = (N##2).x * dy;                                                 \
-        const float q = __builtin_fmaf(au, u, __builtin_fmaf(cd, dy, (N##2).y));                         \
-        const float q2 = __builtin_fmaf(au, u, cd * dy);                       /* the sign S6 tests */ \
+        const float U = __builtin_fmaf(-(N##1).x, ly, __builtin_fmaf(-(N##0).y, lx, (N##0).x));        \
+        const float V = __builtin_fmaf(-(N##2).x, ly, (N##1).y);                                       \
+        const float Vs = (N##2).x < 0.0f ? -V : V;                             /* V^2 carries the sign of C' */ \
+        const float q = __builtin_fmaf(U, U, __builtin_fmaf(Vs, V, (N##2).y));                         \
+        const float q2 = __builtin_fmaf(U, U, Vs * V);                         /* the sign S6 tests */ \
         const bool valid = q < cq && q2 >= 0.0f;                                                       \
         const float e = SGS_SAT(SGS_EXP2(-q));                                                         \
         AL = valid ? e : 0.0f;                                                                         \
@@ -1286,11 +1296,11 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         (void)wave_done;                                                                               \
         if (STATS) used = Tm > 0.0f ? base + m : used;                                                 \
     }
-// staging: write splat J from its record (A_ = x,y,A,k  B_ = C',nlo,r,g  C_ = b,depth,hx,hy) — a plain copy: k_preprocess
-// has folded every constant into the record.  A splat whose conic is not positive semi-definite flags the batch.
-#define SGS_STAGE(J, A_, B_, C_)                                                                       \
+// staging: write splat J from its record (A_ = x,y,a,ak  B_ = c,nlo,r,g  C_ = b,depth,hx,hy) with the tile-relative constants
+// m = a rx + a k ry and c ry.  A splat whose conic is not positive semi-definite (c < 0; NaN) flags the batch.
+#define SGS_STAGE(J, A_, B_, C_, RX, RY)                                                               \
     {                                                                                                  \
-        s_p0[J] = make_float2(A_.x, A_.y); s_p1[J] = make_float2(A_.z, A_.w);                          \
+        s_p0[J] = make_float2(__builtin_fmaf(A_.w, RY, A_.z * (RX)), A_.z); s_p1[J] = make_float2(A_.w, B_.x * (RY)); \
         s_p2[J] = make_float2(B_.x, B_.y); s_p3[J] = make_float2(B_.z, B_.w);                          \
         s_p4[J] = make_float2(C_.x, C_.y);                                                             \
         if (!(A_.z >= 0.0f) || !(B_.x >= 0.0f)) s_hyper[par] = 1u;                                     \
@@ -1344,6 +1354,12 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
     }
     return bits;
 }
+// (the record holds the roots a = sqrt(A), a k, c = +-sqrt(|C'|); the test's own slack of ~130 ulps covers these conversions)
+__device__ __forceinline__ unsigned sgs_quadrant_hits_roots(float rx, float ry, float a, float ak, float c, float qmax) {
+    const float k = a > 0.0f ? ak * SGS_RCP(a) : 0.0f;
+    return sgs_quadrant_hits(rx, ry, a * a, k, c * fabsf(c), qmax);
+}
+
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.  One workgroup per 16x16 tile,
 // one lane per pixel, each of the four waves owns an 8x8 quadrant.
@@ -1394,8 +1410,10 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 // AUX: expected depth + coverage outputs.  STATS: D_f bookkeeping.  TF: the final transmittance of stopped pixels is needed
 // (AUX, or a background that is not black) — one more add per (pixel, splat).
 template <bool AUX, bool STATS, bool TF>
+// workgroups per CU: five (96 VGPRs, no spills, 32 KB of LDS each) render as fast as six (80 VGPRs, 10-19 spilled) alone
+// and 2-3 % faster with frames in flight (r03d/g/h)
 #ifndef SGS_RENDER_WGS
-#define SGS_RENDER_WGS 6
+#define SGS_RENDER_WGS 5
 #endif
 __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(const FrameGroup G) {
     static_assert(TF || !AUX, "the coverage output needs the final transmittance");
@@ -1459,7 +1477,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     const unsigned in_y = (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
     const unsigned py = frame_y * 16u + in_y, out_py = tile_y * 16u + in_y;
     const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
-    const float fpx = (float)px, fpy = (float)py;
+    const float lx = (float)((unsigned)(wave & 1) * 8u + (unsigned)(lane & 7)), ly = (float)in_y;   // the pixel inside its tile
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
     // per-frame constants of the trip (the header of the blend macros): all in VGPRs, an SGPR operand costs 1.6 issues
     float amax = P.alpha_max, big = SGS_BIG;
@@ -1695,14 +1713,14 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             if (have) {
                 const float qmax = nD, hx = nC.z, hy = nC.w;        // log2(o / alpha_min); half extents of {alpha >= alpha_min}
                 SGS_PROF_STAGED_ALL()
-                SGS_STAGE(rank, nA, nB, nC)
+                const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
+                SGS_STAGE(rank, nA, nB, nC, rx, ry)
                 if (qmax > 0.0f) {
-                    const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;
                     const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
                     const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
                     unsigned qb4 = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                    ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits(rx, ry, nA.z, nA.w, nB.x, qmax);
+                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax);
                     SGS_PROF_STAGED(qb4)
                     unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
                     const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
@@ -1808,14 +1826,14 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                     const float4* sp = reinterpret_cast<const float4*>(splats + gv[gb + (unsigned)tid]);
                     const float4 nA = sp[0], nB = sp[1], nC = sp[2];
                     const float qmax = *reinterpret_cast<const float*>(sp + 3), hx = nC.z, hy = nC.w;
-                    SGS_STAGE((unsigned)tid, nA, nB, nC)
+                    const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;          // centre relative to the tile
+                    SGS_STAGE((unsigned)tid, nA, nB, nC, rx, ry)
                     if (qmax > 0.0f) {
-                        const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
                         const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
                         const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
                         qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
                                 ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits(rx, ry, nA.z, nA.w, nB.x, qmax);
+                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax);
                     }
                 }
 #pragma unroll
