@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--bands", choices=("balanced", "even", "interleave"), default="balanced",
                     help="tile-row shards: contiguous bands re-cut by cost from the previous batch (default), the even "
                          "9,9,9,9,8,8,8,8 split, or every N-th row")
+    ap.add_argument("--rows-f32", action="store_true", help="N>=4: keep the fp32 framebuffer gather as the tile-row headline "
+                                                             "(default there: bands packed to uint8 RGBA before the gather)")
     ap.add_argument("--no-batch", action="store_true", help="camera mode: issue a sweep of <= 32 frames one by one as well, "
                                                              "not as one render_batch call")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
@@ -69,6 +71,16 @@ def parse():
     ap.add_argument("--event-stride", type=int, default=16,
                     help="bracket the stages of every n-th frame of the timed region with HIP events (recording them on "
                          "every frame costs ~4 %% of the sweep's throughput)")
+    ap.add_argument("--scene", default=None, metavar="PLY",
+                    help="render THIS scene instead of the synthetic one: a standard 3DGS .ply (or, with --compressed, a "
+                         "PlayCanvas compressed .ply) loaded through sage_gs.ply with the reference's model->world transform "
+                         "(template.usda:120); poses = the same pose generator over the scene's bounds")
+    ap.add_argument("--compressed", action="store_true", help="--scene is a PlayCanvas compressed .ply")
+    ap.add_argument("--scene-kind", choices=("room", "trained"), default="room",
+                    help="synthetic scene: make_room (BASELINE.md, default) or make_trained_like (trained-3DGS statistics: heavy-tailed "
+                         "anisotropic scales, 40 %% nearly transparent splats, floaters, no spatial order)")
+    ap.add_argument("--no-lowres", action="store_true",
+                    help="N=1: skip the one-frame latency at the reference's own resolutions (640x480, 1024x768)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
                          "independent frames in flight on the library's internal streams)")
@@ -139,7 +151,18 @@ def main():
     height = args.height or (2160 if config == 5 else 1080)
 
     # ---- workload: deterministic synthetic scene + pose list (identical on every rank) ---------------
-    scene = scenes.cached_room(args.gaussians, seed=2)          # make_room(n, seed=2), kept in /tmp between processes
+    if args.scene:
+        from sage_gs import ply
+        arrays = (ply.load_compressed_ply if args.compressed else ply.load_ply)(args.scene)
+        scene = scenes.scene_from_arrays(arrays)                # model->world = template.usda:120; bounds -> where the eye points go
+        args.gaussians = int(scene.means.shape[0])
+        scene_desc = f"{os.path.basename(args.scene)} ({'PlayCanvas compressed' if args.compressed else '3DGS'} PLY, {args.gaussians} Gaussians, SH deg {scene.sh_degree})"
+    elif args.scene_kind == "trained":
+        scene = scenes.make_trained_like(args.gaussians, seed=2)
+        scene_desc = f"make_trained_like({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians with trained-3DGS statistics, SH deg 3"
+    else:
+        scene = scenes.cached_room(args.gaussians, seed=2)      # make_room(n, seed=2), kept in /tmp between processes
+        scene_desc = f"make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, SH deg 3"
     if config == 5:
         cams = scenes.sweep_cameras(scene, width, height, n=360, seed=2)
         pose_desc = "360-camera sweep, 1-degree yaw steps at one position"
@@ -152,7 +175,8 @@ def main():
     K, W = args.steps, args.warmup
     timing = not args.no_events
     pipelined = not args.no_pipeline
-    pose_set = f"config{config}:{args.gaussians}:{width}x{height}:W{W}:K{K}:stride{POSE_STRIDE}"
+    pose_set = f"config{config}:{args.gaussians}:{width}x{height}:W{W}:K{K}:stride{POSE_STRIDE}" + \
+        (f":{os.path.basename(args.scene)}" if args.scene else ":trained" if args.scene_kind == "trained" else "")
 
     def pose(i):
         return (i * POSE_STRIDE) % n_poses
@@ -160,9 +184,14 @@ def main():
     # frames of the sweep are independent: up to four are in flight per GPU, each with its own output buffer
     frames = [torch.zeros((height, width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
     frame = frames[0]
-    sharded = sharded_f32 = None
+    sharded = sharded_f32 = sharded_head = None
+    # N >= 4: the bands travel as uint8 RGBA (the array get_rgba() hands the reference's callers) in the HEADLINE — fp32 bands
+    # into rank 0 are ~25 MB per 1080p frame, i.e. all seven of its xGMI links at the frame rates a 4- or 8-way split reaches;
+    # the fp32 gather is then timed afterwards (also_measured.rows_f32).  N = 2: fp32 headline, rgba8 afterwards.
+    head_rgba8 = world >= 4 and args.bands != "interleave" and not args.rows_f32
     if world > 1:
         sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
+        sharded_head = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8") if head_rgba8 else sharded_f32
 
     warming = [False]
 
@@ -199,7 +228,7 @@ def main():
     def run_rows(first, count, timed, sharded=None):
         """`count` frames, each sharded by tile row over all ranks and gathered to rank 0 (RCCL): the bands of `batch`
         frames are rendered through the pipelined lanes and travel in one asynchronous exchange, double-buffered."""
-        sharded = sharded or sharded_f32
+        sharded = sharded or sharded_head
         acc, n_acc, i = None, 0, 0
         if warming[0] and pipelined and count > 0:
             # the library's batch path rotates over eight sets of intermediates (buffers allocated on first use): touch them
@@ -255,8 +284,8 @@ def main():
 
     rows_primary = world > 1 and args.shard == "rows"
     cfg_name = {3: "configs[2]", 4: "configs[3]", 5: "configs[4]"}[config]
-    workload = (f"{cfg_name}: make_room({args.gaussians}, seed=2) ~{args.gaussians / 1e6:.1f}M Gaussians, "
-                f"SH deg 3, {width}x{height}, reference lens (8/20.955), {pose_desc}; step i = pose (i*{POSE_STRIDE}) mod {n_poses}")
+    workload = (f"{cfg_name}: {scene_desc}, "
+                f"{width}x{height}, reference lens (8/20.955), {pose_desc}; step i = pose (i*{POSE_STRIDE}) mod {n_poses}")
     cameras_desc = f"camera shard x{world}: one pose per GPU per step, scene replicated, no data-path collective"
 
     # N > 1, tile rows as the headline: the camera-sharded sweep (no data-path collective, nothing that can get stuck) is
@@ -292,6 +321,16 @@ def main():
             raise
         bail_rows(f"the tile-row-sharded sweep failed: {type(e).__name__}: {e}"[:300])
     frames_total = K if (rows_primary or world == 1) else K * world       # camera shards: one frame per rank per step
+    # a short timed region (the driver's --steps 20 is 5 ms) gets a neighbour measured over 100 steps in the same process:
+    # same poses, same path as a --steps 100 run (frames pipelined on the lanes), W warm-up steps already done
+    value_100 = None
+    if world == 1 and K < 64 and pipelined:
+        K0, bf0 = K, batch_frames
+        K, batch_frames = 100, None                       # (run_cameras reads both: the per-frame path)
+        dt100, _ = measure(run_cameras, min(W, 10), 100, False)
+        K, batch_frames = K0, bf0
+        value_100 = {"value": 100 / dt100, "unit": "frames/s", "steps": 100, "timed_region_ms": 1e3 * dt100,
+                     "ms_per_step": 10.0 * dt100, "what": "the same sweep over 100 steps, frames pipelined on the library's lanes"}
 
     # ---- the same frames one at a time on rank 0 (outside the timed region): kernel durations ALONE, algorithmic bytes,
     #      and the host-timed latency of a synchronous frame -------------------------------------------------------------
@@ -334,7 +373,7 @@ def main():
         out = {
             "metric": "frames/sec, 3M-Gaussian InteriorGS-like scene @1080p (+ achieved HBM GB/s in roofline)",
             "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+            "ms_per_step": 1e3 * elapsed / K, "timed_region_ms": 1e3 * elapsed, "higher_is_better": True,
             "scaling": "strong" if rows_primary else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload,
@@ -343,6 +382,7 @@ def main():
                                                     if short_sweep(K) else "frames pipelined on the library's three lanes")
                                        if pipelined else "1 GPU, one frame at a time") if world == 1 else
                                       (f"tile-row shard x{world} ({bands_desc}) + RCCL gatherv to rank 0"
+                                       + (", bands packed to uint8 RGBA on every rank (4-byte pixels travel)" if head_rgba8 else " (fp32 bands)")
                                        + (f" (bands of {sharded.batch} frames per exchange)" if pipelined else "")
                                        if rows_primary else cameras_desc),
                        "per_frame": {k: (v / nfr if k != "max_tile_len" else v) for k, v in counts.items()}},
@@ -399,6 +439,31 @@ def main():
                         "overlap (not a kernel duration: it includes waiting for the lane's previous kernel)"}
         if latency:
             out["latency_ms"] = dict(pct(latency), what="one frame at a time, host-timed call -> frame complete (no events)")
+        if value_100 is not None:
+            out["value_100"] = value_100
+        if world == 1 and not args.no_lowres:
+            # the reference's own resolutions (simple_env.py:52 get_rgb at 640x480; generate_images.py:43 at 1024x768): what a
+            # synchronous get_rgb()-style caller sees per frame on the same scene and poses, one frame at a time
+            low = {}
+            for (lw, lh) in ((640, 480), (1024, 768)):
+                lc = (scenes.sweep_cameras if config == 5 else scenes.room_cameras)(scene, lw, lh, **({"n": 360, "seed": 2} if config == 5 else {"n_positions": 4, "n_yaw": 64, "seed": 2}))
+                buf = torch.zeros((lh, lw, 3), dtype=torch.float32, device=device)
+                sel_l = [pose(W + i) for i in range(max(K, 32))]
+                for p in sel_l[:4]:
+                    r.render(lc[p], gs, out=buf)
+                lat, stage_l = [], {n: [] for n in STAGE_NAMES}
+                for p in sel_l:
+                    t0 = time.perf_counter()
+                    r.render(lc[p], gs, out=buf)
+                    lat.append(1e3 * (time.perf_counter() - t0))
+                for p in sel_l:
+                    r.render(lc[p], gs, out=buf, timing=True)
+                    for n in STAGE_NAMES:
+                        stage_l[n].append(r.last_stats["ms"][n])
+                low[f"{lw}x{lh}"] = {"latency_ms": pct(lat), "fps_one_at_a_time": 1e3 / float(np.mean(lat)),
+                                     "stages_ms_alone": {n: mean(stage_l[n]) for n in STAGE_NAMES}}
+            out["also_measured"] = dict(out.get("also_measured") or {}, reference_resolutions=dict(
+                low, what="one frame at a time at the resolutions the reference renders (simple_env.py:52, generate_images.py:43), same scene and poses"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, [cams[pose(W + i)] for i in range(min(K, 32))], args.cpu_seconds)
     else:
@@ -417,25 +482,27 @@ def main():
             def bail8():
                 if not done8.is_set():
                     if rank == 0:
-                        out["also_measured"]["rows_rgba8"] = {"error": f"still running after {args.secondary_timeout:.0f} s; abandoned"}
+                        out["also_measured"]["rows_f32" if head_rgba8 else "rows_rgba8"] = {"error": f"still running after {args.secondary_timeout:.0f} s; abandoned"}
                         print(json.dumps(out), flush=True)
                     os._exit(0)
 
             t8 = threading.Timer(args.secondary_timeout, bail8)
             t8.daemon = True
             t8.start()
+            third_key = "rows_f32" if head_rgba8 else "rows_rgba8"
             try:
-                sharded8 = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8")
+                sharded8 = sharded_f32 if head_rgba8 else ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8")
                 dt8, _ = measure(lambda f, c, t: run_rows(f, c, t, sharded8), W, K, False)
                 third = {"value": K / dt8, "unit": "frames/s", "steps": K, "ms_per_step": 1e3 * dt8 / K, "scaling": "strong",
-                         "parallelism": f"tile-row shard x{world} ({bands_desc}), bands packed to uint8 RGBA on every rank, RCCL gatherv "
-                                        f"of 4-byte pixels to rank 0" if rank == 0 else ""}
+                         "parallelism": (f"tile-row shard x{world} ({bands_desc}), fp32 bands, RCCL gatherv to rank 0" if head_rgba8 else
+                                         f"tile-row shard x{world} ({bands_desc}), bands packed to uint8 RGBA on every rank, RCCL gatherv "
+                                         f"of 4-byte pixels to rank 0") if rank == 0 else ""}
             except Exception as e:       # noqa: BLE001
                 third = {"error": f"{type(e).__name__}: {e}"[:300]}
             done8.set()
             t8.cancel()
             if rank == 0:
-                out["also_measured"]["rows_rgba8"] = third
+                out["also_measured"][third_key] = third
     elif world > 1 and not args.no_secondary:
         import threading
         finished = threading.Event()

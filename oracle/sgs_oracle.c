@@ -229,9 +229,10 @@ static void var_leaf(orc_var* v, real T, const real C[3]) {
     double e = 0;
     for (int c = 0; c < 3; ++c) {
         double d = fabs((double)(float)(C[c] + T * (real)v->cfg->bg[c]) - (double)v->got[c]);
-        if (!(d <= e)) e = d;                                    /* NaN propagates as "no match" */
+        if (isnan(d)) { v->leaves++; return; }                   /* a NaN channel matches nothing: this leaf cannot be the best */
+        if (d > e) e = d;
     }
-    if (!(e >= v->best)) v->best = e;
+    if (e < v->best) v->best = e;
     v->leaves++;
 }
 

@@ -253,7 +253,9 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
         for (int r = 0; r < 3; ++r)
             for (int c = r; c < 3; ++c) {
                 const double d = (double)V[4 * r] * V[4 * c] + (double)V[4 * r + 1] * V[4 * c + 1] + (double)V[4 * r + 2] * V[4 * c + 2];
-                if (!(std::fabs(d - (r == c ? 1.0 : 0.0)) < 1.0e-3))
+                // (fp32 pose matrices are orthonormal to ~1e-6; the per-chunk bounds and the footprint bound of k_preprocess
+                //  absorb ~1e-4 of non-rigidity, so the contract is an order of magnitude inside that)
+                if (!(std::fabs(d - (r == c ? 1.0 : 0.0)) < 1.0e-5))
                     SGS_FAIL(ctx, SGS_ERR_INVALID, "camera view is not rigid: rows %d.%d of its 3x3 give %g", r, c, d);
             }
     }
@@ -780,6 +782,27 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
     if (ctx->pending_count > 0 && (rc = sgs_frame_sync(ctx, nullptr)) != SGS_OK) return rc;
     const bool lanes = !(cfg.flags & SGS_FLAG_FULL_SORT);           // own streams (the FULL_SORT test hook stays on the caller's)
     const int F = ctx->group, GL = lanes ? ctx->group_lanes : 1;
+    // every camera (and the stride) is validated BEFORE anything is enqueued: an error return half-way through a batch
+    // would leave earlier groups running on the lane streams with nobody waiting for them
+    int rb0 = tile_row_begin, re0 = tile_row_end;
+    for (int i = 0; i < n_cams; ++i) {
+        int rb = tile_row_begin, re = tile_row_end;
+        if ((rc = validate(ctx, scene, &cams[i], &cfg, rb, re, out_rgb)) != SGS_OK) return rc;
+        if (cams[i].width != cams[0].width || cams[i].height != cams[0].height)
+            SGS_FAIL(ctx, SGS_ERR_INVALID, "the cameras of a batch must share a resolution");
+        if (i == 0) { rb0 = rb; re0 = re; }
+    }
+    if (n_cams > 1) {
+        const int stride_t = cfg.tile_row_stride > 1 ? cfg.tile_row_stride : 1, phase_t = stride_t > 1 ? cfg.tile_row_phase : 0;
+        int64_t rows = 0;                           // pixel rows one frame of the batch writes
+        for (int k = rb0; k < re0; ++k) {
+            const int y0 = (k * stride_t + phase_t) * SGS_TILE;
+            rows += std::max(0, std::min(y0 + SGS_TILE, cams[0].height) - y0);
+        }
+        if (frame_stride < rows * (int64_t)cams[0].width * 3)
+            SGS_FAIL(ctx, SGS_ERR_INVALID, "frame_stride %lld is smaller than the band a frame writes (%lld floats)",
+                     (long long)frame_stride, (long long)(rows * (int64_t)cams[0].width * 3));
+    }
     for (int c0 = 0; c0 < n_cams; c0 += kStatusRing) {
         const int cn = std::min(kStatusRing, n_cams - c0);
         int64_t px[kStatusRing]; int tl[kStatusRing];
@@ -796,14 +819,8 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
         for (int i = 0, g = 0; i < cn; i += F, ++g) {
             const int nf = std::min(F, cn - i);
             float* outs[SGS_MAX_GROUP];
-            int rb = tile_row_begin, re = tile_row_end;
-            for (int f = 0; f < nf; ++f) {
-                rb = tile_row_begin; re = tile_row_end;
-                outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
-                if ((rc = validate(ctx, scene, &cams[c0 + i + f], &cfg, rb, re, outs[f])) != SGS_OK) return rc;
-                if (cams[c0 + i + f].width != cams[c0].width || cams[c0 + i + f].height != cams[c0].height)
-                    SGS_FAIL(ctx, SGS_ERR_INVALID, "the cameras of a batch must share a resolution");
-            }
+            const int rb = rb0, re = re0;
+            for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
                                     (g % GL) * F)) != SGS_OK)
                 return rc;

@@ -614,7 +614,8 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
         // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
         if (t < t_hi) tile_order[pos] = uint4{(unsigned)t, base + wbase + incl - c, c, 0u};
     }
-    {   // records per FRAME tile row, accumulated over frames (sgs_row_records: what cost-balanced bands are cut from)
+    if ((unsigned long long)total <= (unsigned long long)P.rec_capacity) {   // (uniform; an overflowed frame is rendered again: counted then)
+        // records per FRAME tile row, accumulated over frames (sgs_row_records: what cost-balanced bands are cut from)
         const int first_y = (t_lo + g * SGS_SCAN_THREADS) / P.gx;
         const int my_y = t < t_hi ? t / P.gx - first_y : -1;
         if (P.gx >= SGS_WAVE) {                      // a wave's 64 consecutive tiles lie in two rows at most

@@ -371,8 +371,9 @@ class ShardedRenderer:
     """Tile-row-sharded rendering across the ranks of a process group: every rank renders its band of tile rows, the
     bands are gathered to rank `dst`.  balance=True re-cuts the bands of a sweep by cost (see the module docstring)."""
 
-    # first re-cut (no timing yet): cost of a tile row = records queued in it + this many "records" per tile of fixed work
-    TILE_COST = 48.0
+    # the gather buffers of a rank (two batched FrameGather rings + the fp32 scratch of rgba8 output) may take this much
+    # device memory before the constructor refuses (batch x band rows x width grows quickly at 3840x2160)
+    MAX_BUFFER_BYTES = 16 << 30
 
     def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 32,
                  interleave: bool = False, balance: bool = False, output: str = "float32"):
@@ -403,6 +404,20 @@ class ShardedRenderer:
         self._row_cost = None        # the per-row cost the current bands were cut from
         self.bands = list(self.g.bands)
         self.last_stats = None       # statistics of the last batch this rank rendered (per-frame averages)
+        # what the two batched gather buffers (+ the fp32 scratch of rgba8 output) will take on this rank
+        esz = 1 if output == "rgba8" else 4
+        ch = 4 if output == "rgba8" else 3
+        rows = height if self.g.rank == dst else min(height, self.g.max_band_rows * TILE)
+        need = 2 * self.batch * rows * width * ch * esz + (self.batch * min(height, self.g.max_band_rows * TILE) * width * 12 if output == "rgba8" else 0)
+        self.buffer_bytes = int(need)
+        if need > self.MAX_BUFFER_BYTES:
+            raise ValueError(f"ShardedRenderer(batch={self.batch}) would hold {need / 2**30:.1f} GiB of gather buffers on rank "
+                             f"{self.g.rank} at {width}x{height}; use a smaller batch (MAX_BUFFER_BYTES = {self.MAX_BUFFER_BYTES >> 30} GiB)")
+        if self.world > 1:
+            # create the communicator NOW, with every rank taking part: the framebuffer exchange is a group of point-to-point
+            # operations in which a rank with an empty band takes no part, which is only safe on a communicator that exists
+            t = torch.zeros(1, dtype=torch.float32, device="cpu" if dist.get_backend(self.group) == "gloo" else renderer.device)
+            dist.all_reduce(t, group=self.group)
 
     @property
     def world(self) -> int:
@@ -462,10 +477,8 @@ class ShardedRenderer:
         self._cost = None
         n = self.g.n_tile_rows
         rec, times = v[:n], v[n:]
-        if times.sum() > 0:          # measured band times, spread over the rows by their records (timed_row_cost)
-            self._row_cost = timed_row_cost(self._cost_bands, times, rec, self._row_cost)
-        else:
-            self._row_cost = rec + self.TILE_COST * ((self.w + TILE - 1) // TILE)
+        # measured band times (every rank posts a positive wall-clock time), spread over the rows by their records
+        self._row_cost = timed_row_cost(self._cost_bands, times, rec, self._row_cost)
         self.bands = balanced_partition(self._row_cost, self.world, self.g.max_band_rows)
 
     def render_batch(self, cameras, scene, *, config=None, timing=False):

@@ -203,6 +203,47 @@ def make_room(n, seed=1, size=None, height=2.8, sh_degree=3, n_rooms=None):
                        MODEL_TO_WORLD.copy(), (sx, sy, height), rooms)
 
 
+def make_trained_like(n, seed=1, **kw):
+    """The statistics of a TRAINED 3DGS scene laid over `make_room`'s geometry (what InteriorGS assets look like, as far
+    as published 3DGS checkpoints go — none is available offline): log-normal scales with a heavy tail (sigma 0.9 instead
+    of 0.5, 1 % of the splats ten times larger still), strong anisotropy (one tangent axis stretched by exp|N(0, 0.8)|),
+    40 % of the splats nearly transparent (opacity sigmoid(N(-3.5, 1)): < 0.1), 8 % floaters — large, faint blobs anywhere in
+    the volume — and NO spatial order in the arrays.  Against `make_room` this multiplies the records queued per tile (D)
+    and the records a pixel consumes before it saturates (D_f): the scene to tune the binning and the tail tiles on."""
+    sc = make_room(n, seed=seed, **kw)
+    rng = np.random.default_rng(seed + 7919)
+    scales = sc.scales.astype(np.float64) * np.exp(rng.normal(0.0, 0.75, (n, 1)))           # 0.5 (+) 0.75 -> sigma 0.9
+    stretch = np.exp(np.abs(rng.normal(0.0, 0.8, n)))
+    scales[:, 0] *= stretch                                                               # one in-plane axis (surfels: a tangent)
+    giant = rng.random(n) < 0.01
+    scales[giant] *= 10.0
+    opac = np.where(rng.random(n) < 0.4, 1.0 / (1.0 + np.exp(-rng.normal(-3.5, 1.0, n))), sc.opacities.astype(np.float64))
+    means = sc.means.astype(np.float64).copy()
+    fl = rng.random(n) < 0.08                                                             # floaters: anywhere in the volume
+    nf = int(fl.sum())
+    world = np.stack([rng.uniform(0, sc.extent[0], nf), rng.uniform(0, sc.extent[1], nf), rng.uniform(0, sc.extent[2], nf)], 1)
+    means[fl] = world @ MODEL_TO_WORLD[:3, :3]                                            # world -> model (M^-1 = M^T, row vectors)
+    scales[fl] = 0.06 * np.exp(rng.normal(0.0, 0.7, (nf, 3)))
+    opac[fl] = 1.0 / (1.0 + np.exp(-rng.normal(-2.5, 1.0, nf)))
+    order = rng.permutation(n)
+    f32 = lambda a: np.ascontiguousarray(a[order], np.float32)
+    return SceneArrays(f32(means), f32(scales), f32(sc.quats), f32(opac), f32(sc.sh), sc.sh_degree,
+                       sc.model_to_world, sc.extent, sc.rooms)
+
+
+def scene_from_arrays(arrays, model_to_world=None):
+    """SceneArrays for a loaded scene (sage_gs.ply: means, scales, quats, opacities, sh, degree): the world-space bounds
+    (2nd-98th percentile of the means: trained scenes carry floaters far outside) stand in for the room list that
+    `room_cameras` / `sweep_cameras` place their eye points in."""
+    means, scales, quats, opac, sh, deg = arrays
+    m2w = MODEL_TO_WORLD.copy() if model_to_world is None else np.asarray(model_to_world, float)
+    w = np.asarray(means, np.float64) @ m2w[:3, :3].T + m2w[:3, 3]
+    lo, hi = np.percentile(w, 2, axis=0), np.percentile(w, 98, axis=0)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    return SceneArrays(f32(means), f32(scales), f32(quats), f32(opac), f32(sh), int(deg), m2w,
+                       tuple(float(v) for v in (hi - lo)), ((float(lo[0]), float(lo[1]), float(hi[0]), float(hi[1])),))
+
+
 def cached_room(n, seed=1, cache_dir=None, **kw):
     """`make_room`, kept on disk between processes (the generator takes ~25 s for 3 M Gaussians; benchmarks and profiling
     runs that start many processes on one box load the arrays instead).  cache_dir=None -> $SGS_SCENE_CACHE or
@@ -260,7 +301,8 @@ def room_cameras(scene: SceneArrays, width=1920, height=1080, n_positions=4, n_y
     cams = []
     for p in range(n_positions):
         x0, y0, x1, y1 = rooms[(p * max(1, len(rooms) // n_positions)) % len(rooms)]
-        pos = (rng.uniform(x0 + 1.0, x1 - 1.0), rng.uniform(y0 + 1.0, y1 - 1.0), EYE_HEIGHT)
+        mx, my = min(1.0, 0.25 * (x1 - x0)), min(1.0, 0.25 * (y1 - y0))      # a metre from the walls (less in a small scene)
+        pos = (rng.uniform(x0 + mx, x1 - mx), rng.uniform(y0 + my, y1 - my), EYE_HEIGHT)
         for k in range(n_yaw):
             cams.append(Camera(width, height, fx, fy, cx, cy, view_from_yaw(pos, 2 * math.pi * k / n_yaw)))
     return cams
@@ -276,7 +318,8 @@ def sweep_cameras(scene: SceneArrays, width=3840, height=2160, n=360, position=N
     if position is None:
         rng = np.random.default_rng(seed + 2000)
         x0, y0, x1, y1 = (scene.rooms or ((0.0, 0.0, scene.extent[0], scene.extent[1]),))[0]
-        position = (rng.uniform(x0 + 1.0, x1 - 1.0), rng.uniform(y0 + 1.0, y1 - 1.0), EYE_HEIGHT)
+        mx, my = min(1.0, 0.25 * (x1 - x0)), min(1.0, 0.25 * (y1 - y0))
+        position = (rng.uniform(x0 + mx, x1 - mx), rng.uniform(y0 + my, y1 - my), EYE_HEIGHT)
     position = (float(position[0]), float(position[1]), float(position[2]) if len(position) > 2 else EYE_HEIGHT)
     return [Camera(width, height, fx, fy, cx, cy, view_from_yaw(position, 2 * math.pi * k / n)) for k in range(n)]
 

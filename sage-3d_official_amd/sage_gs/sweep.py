@@ -69,8 +69,11 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
             cams = cameras_for(tr["points"], resolution)
             for c0 in range(0, len(cams), chunk):
                 frames = renderer.render_batch(cams[c0:c0 + chunk], scene)            # [B,H,W,3] on the GPU
-                for k in range(frames.shape[0]):
-                    rgba = renderer.pack_rgba8(frames[k]).cpu().numpy()
+                # ONE pack and ONE device-to-host copy per chunk (the batch is contiguous: B stacked images are one tall image)
+                b, h, w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+                host = renderer.pack_rgba8(frames.reshape(b * h, w, 3)).cpu().numpy().reshape(b, h, w, 4)
+                for k in range(b):
+                    rgba = host[k]
                     if on_frame is not None:
                         on_frame(tr["trajectory_id"], c0 + k, rgba[:, :, :3])
                     Image.fromarray(rgba[:, :, :3]).save(os.path.join(tdir, names[c0 + k]), quality=quality)

@@ -52,6 +52,7 @@ def assert_frame_close(img, ref, margin, recheck, tol=TOL, what="frame", y0=0):
     pixel must match ONE of the resulting colours within the same tol.  `margin`/`img`/`ref` may be a band of the frame
     starting at pixel row y0 (recheck takes frame coordinates).  Returns the worst error; logs the flagged fraction."""
     img = np.asarray(img, np.float64); ref = np.asarray(ref, np.float64)
+    assert np.isfinite(img).all(), f"{what}: {int((~np.isfinite(img)).sum())} non-finite output value(s)"    # (a NaN compares False both ways below)
     err = np.abs(img - ref).max(axis=-1)
     safe = np.asarray(margin) >= MARGIN
     worst = float(err[safe].max()) if safe.any() else 0.0
@@ -59,7 +60,7 @@ def assert_frame_close(img, ref, margin, recheck, tol=TOL, what="frame", y0=0):
     n_flag = int((~safe).sum()); worst2 = 0.0
     if n_flag:
         # pixels inside the margin that agree with the nominal evaluation anyway need no second look
-        ys, xs = np.nonzero(~safe & (err >= tol))
+        ys, xs = np.nonzero(~safe & ~(err < tol))
         if len(ys):
             assert recheck is not None, f"{what}: {len(ys)} threshold-sensitive pixels differ and no two-sided oracle was supplied"
             best, leaves, capped = recheck(ys + y0, xs, img[ys, xs])

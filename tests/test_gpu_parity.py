@@ -1,6 +1,8 @@
 """Parity tests proper: the HIP path on a real MI355X, called through the C ABI (via the Python
 host side), against the oracle — same cases as the emulator run plus full-size scenes and
 size-independent properties at BASELINE.json's sizes."""
+import os
+
 import numpy as np
 import pytest
 
@@ -560,6 +562,43 @@ def test_ply_scene_against_the_oracle(drv, tmp_path):
             best, _, _ = aux["recheck"](ys, xs, img[ys, xs])
             assert best.max() < 1e-3
         assert img.max() > 0.2
+
+
+def test_ply_scene_at_full_size(drv, tmp_path):
+    """f-1 at the size of configs[2]: a 3 M-Gaussian scene (trained-3DGS statistics, SH degree 3: a 744-MB file) written to
+    a standard 3DGS PLY and read back; the loaded arrays go through `scenes.scene_from_arrays` + `ply.to_gaussians` (the
+    path of `bench.py --scene`) and the frame must equal the frame of the same arrays uploaded directly, bit for bit,
+    with identical N_v / D; against the arrays that were WRITTEN (an fp32 log/exp, logit/sigmoid round trip away) the
+    frame stays within the parity tolerance on all but the few pixels such a perturbation moves across a threshold."""
+    from sage_gs import ply, scenes
+    sc = scenes.make_trained_like(3_000_000, seed=2)
+    path = str(tmp_path / "scene_3m.ply")
+    ply.save_ply(path, *sc.as_tuple())
+    assert os.path.getsize(path) > 3_000_000 * 62 * 4
+    arrays = ply.load_ply(path)
+    assert arrays[5] == 3 and arrays[0].shape == (3_000_000, 3) and arrays[4].shape == (3_000_000, 16, 3)
+    loaded = scenes.scene_from_arrays(arrays)
+    assert np.allclose(loaded.extent, sc.extent, atol=0.5) and np.array_equal(loaded.model_to_world, scenes.MODEL_TO_WORLD)
+    cams = scenes.room_cameras(loaded, 1920, 1080, n_positions=2, n_yaw=8, seed=2)
+    g_file = drv.r.upload(ply.to_gaussians(arrays, "cuda:0", loaded.model_to_world))
+    a = [drv.r.render(cams[i], g_file, stats=True).clone() for i in (1, 11)]
+    st_a = dict(drv.r.last_stats)
+    g_file.free()
+    g_direct = drv.r.upload(scenes.to_gaussians(loaded, "cuda:0"))
+    b = [drv.r.render(cams[i], g_direct, stats=True).clone() for i in (1, 11)]
+    st_b = dict(drv.r.last_stats)
+    g_direct.free()
+    for x, y in zip(a, b):
+        assert bool((x == y).all())
+    assert st_a["n_visible"] == st_b["n_visible"] > 100_000 and st_a["d_total"] == st_b["d_total"] and st_a["d_fetched"] == st_b["d_fetched"]
+    g_orig = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    c = [drv.r.render(cams[i], g_orig).clone() for i in (1, 11)]
+    g_orig.free()
+    for x, y in zip(a, c):
+        d = (x - y).abs().max(dim=-1).values
+        assert float((d >= 1e-3).float().mean()) < 2e-3 and float(d.median()) < 1e-5
+    import json
+    print("[trained-like 3M @1080p] N_v", st_a["n_visible"], "D", st_a["d_total"], "D_f", st_a["d_fetched"], "max tile", st_a["max_tile_len"])
 
 
 def test_gscamera_adapter_against_the_oracle(drv):

@@ -107,3 +107,65 @@ def test_sharded_renderer_on_one_gpu(world, mode):
         assert p.exitcode == 0, f"rank process exited with {p.exitcode}"
     ok, notes = q.get(timeout=10)
     assert ok, notes
+
+
+def _nccl_worker(port, q):
+    """world size 1 on RCCL: communicator creation, a device all_reduce, ShardedRenderer on device tensors."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "sage-3d_official_amd"))
+    import torch
+    import torch.distributed as dist
+    from sage_gs import Renderer, scenes
+    from sage_gs.dist import ShardedRenderer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # exactly bench.py's call
+    try:
+        t = torch.full((4,), 3.0, device=dev)
+        dist.all_reduce(t)                                                     # a device collective on the communicator
+        torch.cuda.synchronize()
+        ok = bool((t == 3.0).all()) and dist.get_backend() == "nccl"
+        sc = scenes.make_room(60_000, seed=1)
+        cams = scenes.room_cameras(sc, 640, 480, n_positions=1, n_yaw=6, seed=1)
+        r = Renderer(dev)
+        scene = r.upload(scenes.to_gaussians(sc, dev))
+        whole = [r.render(c, scene).clone() for c in cams]
+        notes = []
+        for out in ("float32", "rgba8"):
+            sr = ShardedRenderer(r, 480, 640, batch=4, balance=True, output=out)
+            f = sr.render(cams[0], scene)
+            want = [r.pack_rgba8(w) for w in whole] if out == "rgba8" else whole
+            ok = ok and bool((f == want[0]).all())
+            for c0 in (0, 4):                                                  # two batches: the second one re-cuts the bands
+                ids = list(range(c0, min(6, c0 + 4)))
+                g = sr.render_batch([cams[i] for i in ids], scene)
+                sr.finish()
+                for j, i in enumerate(ids):
+                    same = bool((g.frame(j) == want[i]).all())
+                    ok = ok and same
+                    if not same:
+                        notes.append(f"{out} cam {i} differs")
+        dist.barrier()
+        torch.cuda.synchronize()
+        q.put((ok, notes))
+        scene.free(); r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_world_size_one_smoke():
+    """The "nccl" (= RCCL) branch of bench.py / sage_gs.dist has no multi-GPU box to run on here; at world size 1 at least
+    communicator creation, a device-tensor all_reduce, the cost all-reduce of the balanced bands and the ShardedRenderer
+    calls execute on ROCm, with frames identical to the un-sharded ones."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, f"the RCCL process exited with {p.exitcode}"
+    ok, notes = q.get(timeout=10)
+    assert ok, notes
