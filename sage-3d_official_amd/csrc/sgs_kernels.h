@@ -802,26 +802,38 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
 }
 
 // The big-rect splats (k_preprocess's list), dealt round-robin to the workgroups; every thread of the
-// workgroup takes a share of each rect.  Same callback contract as bin_walk.
+// workgroup takes a share of each rect.  Same callback contract as bin_walk.  The workgroup first fetches the records
+// of up to SGS_BIN_THREADS of its rects in ONE round of loads (list entry -> record: two dependent global loads, ~3 us)
+// and then walks them out of LDS: fetched one rect at a time that chain was paid per rect — on a scene with trained-3DGS
+// statistics (thousands of splats of hundreds of tiles each) it was most of both binning kernels (r03j: count 192 us,
+// emit 344 us at D = 29 M).  Must be called by all threads.
 template <class F>
 __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* __restrict__ binrec,
                                              const unsigned* __restrict__ big_list, unsigned n_big,
-                                             int wr0, int wr1, F&& f) {
+                                             int wr0, int wr1, uint4* s_big, F&& f) {
     n_big = min(n_big, (unsigned)SGS_BIG_CAP);
-    for (unsigned i = bin_b(P); i < n_big; i += bin_B(P)) {
-        const uint4 br = binrec[big_list[i]];
-        const unsigned key = br.x, r01 = br.y, r23 = br.z, slot = br.w;
-        const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
-        const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-        if (yb <= ya) continue;                              // workgroup-uniform
-        const unsigned total = w * (unsigned)(yb - ya);
-        const float rw = 1.0f / (float)w;
-        for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
-            // k / w without an integer divide: exact for k < 2^21 (tests/test_emu_parity.py)
-            const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
-            unsigned tl[4] = {((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), 0u, 0u, 0u};
-            f(tl, 1u, key, slot);
+    const unsigned B = bin_B(P), b = bin_b(P);
+    const unsigned mine = n_big > b ? (n_big - b + B - 1u) / B : 0u;      // rects b, b + B, b + 2B, ... (uniform)
+    for (unsigned r0 = 0; r0 < mine; r0 += SGS_BIN_THREADS) {
+        const unsigned nr = min((unsigned)SGS_BIN_THREADS, mine - r0);
+        if (threadIdx.x < nr) s_big[threadIdx.x] = binrec[big_list[b + (r0 + threadIdx.x) * B]];
+        __syncthreads();
+        for (unsigned j = 0; j < nr; ++j) {
+            const uint4 br = s_big[j];
+            const unsigned key = br.x, r01 = br.y, r23 = br.z, slot = br.w;
+            const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
+            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
+            if (yb <= ya) continue;                              // workgroup-uniform
+            const unsigned total = w * (unsigned)(yb - ya);
+            const float rw = 1.0f / (float)w;
+            for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
+                // k / w without an integer divide: exact for k < 2^21 (tests/test_emu_parity.py)
+                const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
+                unsigned tl[4] = {((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), 0u, 0u, 0u};
+                f(tl, 1u, key, slot);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -845,6 +857,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
     SGS_DYNAMIC_LDS(unsigned, s_cnt);                // P.win_tiles counters
     __shared__ unsigned s_nlist;
     __shared__ LiveChunks lc;
+    __shared__ uint4 s_big[SGS_BIN_THREADS];          // the records of this workgroup's big rects, a round at a time
     const int tid = threadIdx.x;
     const unsigned xcd = xcc_id();
     const unsigned n_live = st->n_live;
@@ -869,7 +882,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
             __syncthreads();
             SGS_BPROF(bt_walk);
         }
-        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
+        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1, s_big,
                      [&](const unsigned* tl, unsigned, unsigned, unsigned) { atomicAdd(&s_cnt[tl[0]], 1u); });
         __syncthreads();
         SGS_BPROF(bt_big);
@@ -939,6 +952,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
     const FrameStatus* __restrict__ st = S.st;
     SGS_DYNAMIC_LDS(unsigned, s_next);               // P.win_tiles write cursors
     __shared__ LiveChunks lc;
+    __shared__ uint4 s_big[SGS_BIN_THREADS];
     const int tid = threadIdx.x;
     {   // k_tile_scan has consumed the band's counters: zero again for the next frame (no per-frame memset), also
         // when this frame overflowed
@@ -967,7 +981,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
             bin_walk<true>(P, binrec, lc, wr0, wr1, s_next, rec);
             __syncthreads();
         }
-        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1,
+        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1, s_big,
                      [&](const unsigned* tl, unsigned, unsigned okey, unsigned oslot) {
                          rec[atomicAdd(&s_next[tl[0]], 1u)] = ((unsigned long long)okey << 32) | oslot;
                      });
