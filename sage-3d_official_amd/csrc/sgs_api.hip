@@ -62,9 +62,13 @@ struct Lane {
     unsigned long long* tile_prof = nullptr;         // profiling build: 8 words per tile
     unsigned long long* bin_prof = nullptr;          // profiling build: 8 words per binning workgroup
     // binning scratch: per-workgroup (tile, base) lists
-    int64_t blk_list_cap = 0;
-    uint2* blk_list = nullptr;
+    uint2* blk_list = nullptr;                       // per level-1 binning workgroup: (super-tile, base) of the super-tiles it touched
     unsigned* blk_len = nullptr;
+    // two-level binning: super-tile sub-counters / offsets (SGS_WT super-tiles at most), the level-2 job table and the jobs' bases
+    unsigned *stile_count = nullptr, *stile_offset = nullptr;
+    uint4* jobs = nullptr;
+    unsigned* job_base = nullptr;
+    int64_t job_cap = 0;
     // per-record scratch
     int64_t rec_cap = 0;
     unsigned long long *rec = nullptr;                   // tile queues of (depth bits << 32 | slot) records
@@ -87,6 +91,7 @@ struct sgs_ctx {
     int group = 4, group_lanes = 2;          // SGS_GROUP x SGS_GROUP_LANES <= kMaxLanes: sgs_render_batch* issues `group` frames per
                                              // set of launches (blockIdx.y = frame), groups rotating over `group_lanes` streams
     int last_lane = 0;
+    int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (SGS_EXP_GRID_ENV)
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
     int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
                                              // 64-KB window: binning alone 380 -> 305 us at 3840x2160, but such workgroups overlap worse
@@ -154,18 +159,17 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     if ((rc = grow(ctx, L.binrec, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.live_list, (size_t)chunks)) != SGS_OK) return rc;
     if (!L.big_list && (rc = grow(ctx, L.big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * SGS_MAX_WINDOWS * 2)) != SGS_OK) return rc;    // list lengths | XCD ids
+    if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * 2)) != SGS_OK) return rc;                      // list lengths | XCD ids
+    if (!L.blk_list && (rc = grow(ctx, L.blk_list, (size_t)SGS_BIN_BLOCKS * SGS_WT)) != SGS_OK) return rc;
+    if (!L.stile_count) {
+        if ((rc = grow(ctx, L.stile_count, (size_t)SGS_WT * SGS_XCDS)) != SGS_OK) return rc;
+        if ((rc = grow(ctx, L.stile_offset, (size_t)SGS_WT * SGS_XCDS + 1)) != SGS_OK) return rc;
+        // k_bin_emit zeroes every count k_stile_scan has consumed, so one memset at allocation suffices (see ensure_tiles)
+        SGS_HIP(ctx, hipMemset(L.stile_count, 0, (size_t)SGS_WT * SGS_XCDS * sizeof(unsigned)));
+        SGS_HIP(ctx, hipStreamSynchronize(nullptr));
+    }
     if ((rc = grow(ctx, L.bin_prof, (size_t)SGS_BIN_BLOCKS * 8)) != SGS_OK) return rc;
     L.splat_cap = cap;
-    return SGS_OK;
-}
-
-int ensure_blk_list(sgs_ctx* ctx, Lane& L, int n_windows, int win_tiles) {
-    const int64_t need = (int64_t)SGS_BIN_BLOCKS * n_windows * win_tiles;
-    if (need <= L.blk_list_cap) return SGS_OK;
-    int rc;
-    if ((rc = grow(ctx, L.blk_list, (size_t)need)) != SGS_OK) return rc;
-    L.blk_list_cap = need;
     return SGS_OK;
 }
 
@@ -176,7 +180,7 @@ int ensure_tiles(sgs_ctx* ctx, Lane& L, int tiles) {
     if ((rc = grow(ctx, L.tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_prof, (size_t)tiles * SGS_PROF_WORDS)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_order, (size_t)tiles)) != SGS_OK) return rc;
-    // k_bin_emit zeroes every count k_tile_scan has consumed, so one memset at allocation suffices
+    // k_expand<true> zeroes every count k_tile_scan has consumed, so one memset at allocation suffices
     SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
     // (hipMemset of device memory runs on the NULL stream and may return before it has run; the frames use non-blocking
     //  streams that do not order with it — an unfinished clear would land in the middle of a frame's counting)
@@ -193,6 +197,12 @@ int ensure_records(sgs_ctx* ctx, Lane& L) {
     if ((rc = grow(ctx, L.rec, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.alt, (size_t)cap)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.part, (size_t)cap)) != SGS_OK) return rc;
+    // level-2 jobs: the super-tile queues (cap / 2 records of 16 bytes, in `alt`) in segments of SGS_SEG, plus one ragged
+    // segment per super-tile
+    const int64_t jcap = cap / 2 / SGS_SEG + SGS_WT + 1;
+    if ((rc = grow(ctx, L.jobs, (size_t)jcap)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.job_base, (size_t)jcap * (SGS_ST * SGS_ST + 1))) != SGS_OK) return rc;
+    L.job_cap = jcap;
     L.rec_cap = cap;
     return SGS_OK;
 }
@@ -260,12 +270,10 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
             }
     }
     const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
-    if (gx > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "width %d exceeds %d tiles per row", cam->width, SGS_WT);
     if (gy_frame > SGS_MAX_ROWS) SGS_FAIL(ctx, SGS_ERR_INVALID, "height %d exceeds %d tile rows", cam->height, SGS_MAX_ROWS);
-    const int win_tiles = (row_end - row_begin) * gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;
-    const int win_rows = std::max(1, win_tiles / gx);
-    if ((row_end - row_begin + win_rows - 1) / win_rows > SGS_MAX_WINDOWS)
-        SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d binning windows", row_end - row_begin, gx, SGS_MAX_WINDOWS);
+    // level 1 of the binning keeps one counter per super-tile of the band in LDS
+    const int64_t ns = (int64_t)((gx + SGS_ST - 1) / SGS_ST) * (((row_end + SGS_ST - 1) / SGS_ST) - row_begin / SGS_ST);
+    if (ns > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d super-tiles", row_end - row_begin, gx, SGS_WT);
     return SGS_OK;
 }
 
@@ -292,10 +300,9 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
     P.n_ranges = (int32_t)((scene->n + SGS_RANGE - 1) / SGS_RANGE);
-    P.win_tiles = (row_end - row_begin) * P.gx > SGS_WT ? ctx->win_tiles_max : SGS_WT;   // 4K frames: two 64-KB windows, not four
-    P.win_rows = std::max(1, P.win_tiles / P.gx);
-    P.n_windows = (row_end - row_begin + P.win_rows - 1) / P.win_rows;
+    P.win_tiles = SGS_WT; P.win_rows = std::max(1, P.gy); P.n_windows = 1;       // (one window of super-tiles: sgs_kernels.h, level 1)
     P.rec_capacity = L.rec_cap;
+    P.job_capacity = (int32_t)std::min<int64_t>(L.job_cap, 0x7fffffff);
     P.flags = cfg.flags;
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
         const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
@@ -340,12 +347,12 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
         if ((rc = ensure_records(ctx, A)) != SGS_OK) return rc;
         FrameSlot& S = G.s[f];
         fill_params(S.P, ctx, A, scene, &cams[f], cfg, row_begin, row_end);
-        if ((rc = ensure_blk_list(ctx, A, std::max(1, S.P.n_windows), S.P.win_tiles)) != SGS_OK) return rc;
         if ((S.P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, A)) != SGS_OK) return rc;
         S.splats = A.splats; S.vismask = A.vismask; S.bigmask = A.bigmask; S.big_list = A.big_list; S.binrec = A.binrec;
         S.live_list = A.live_list;
         S.tile_count = A.tile_count; S.tile_offset = A.tile_offset; S.tile_order = A.tile_order;
         S.blk_list = A.blk_list; S.blk_len = A.blk_len;
+        S.stile_count = A.stile_count; S.stile_offset = A.stile_offset; S.jobs = A.jobs; S.job_base = A.job_base;
         S.rec = A.rec; S.alt = A.alt; S.part = A.part; S.sorted_out = A.sorted_out;
         S.tile_prof = A.tile_prof; S.bin_prof = A.bin_prof;
         S.out_rgb = outs[f]; S.out_aux = out_aux; S.st = ctx->d_status + slot0 + f;
@@ -383,17 +390,22 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
-    if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks * (unsigned)P.n_windows, F), dim3(SGS_BIN_THREADS),
-                           (size_t)P.win_tiles * sizeof(unsigned), stream, G);
+    // binning, level 1: splats -> super-tile queues (count, scan + level-2 job list, emit)
+    const int gxs = (gx + SGS_ST - 1) / SGS_ST, ns = gxs * ((row_end + SGS_ST - 1) / SGS_ST - row_begin / SGS_ST);
+    const size_t win_bytes = (size_t)((std::max(ns, 1) + 127) / 128) * 128 * sizeof(unsigned);
+    const bool bin = P.n_ranges > 0 && ns > 0;
+    if (bin) hipLaunchKernelGGL(sgs::k_bin_count, dim3(bin_blocks, F), dim3(SGS_BIN_THREADS), win_bytes, stream, G);
+    hipLaunchKernelGGL(sgs::k_stile_scan, dim3(1, F), dim3(SGS_SSCAN_THREADS), 0, stream, G);
+    if (bin) hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks, F), dim3(SGS_BIN_THREADS), win_bytes, stream, G);
+    if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
+
+    // level 2: super-tile queues -> tile queues (count, scan of the tile counters + render order, emit)
+    const unsigned exp_grid = (unsigned)std::min<int64_t>(ctx->exp_grid, (int64_t)ns + (scene->n + SGS_SEG - 1) / SGS_SEG);
+    if (bin) hipLaunchKernelGGL((sgs::k_expand<false>), dim3(std::max(1u, exp_grid), F), dim3(SGS_EXP_THREADS), 0, stream, G);
     // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
     const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups, F), dim3(SGS_SCAN_THREADS), 0, stream, G);
-    if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
-
-    if (P.n_ranges > 0 && P.n_windows > 0)
-        hipLaunchKernelGGL(sgs::k_bin_emit, dim3(bin_blocks * (unsigned)P.n_windows, F), dim3(SGS_BIN_THREADS),
-                           (size_t)P.win_tiles * sizeof(unsigned), stream, G);
+    if (bin) hipLaunchKernelGGL((sgs::k_expand<true>), dim3(std::max(1u, exp_grid), F), dim3(SGS_EXP_THREADS), 0, stream, G);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
 
     const unsigned ntiles = (unsigned)((row_end - row_begin) * gx);
@@ -519,6 +531,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("hipStreamSynchronize", e);
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
     if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
+    if (const char* env = getenv("SGS_EXP_GRID")) ctx->exp_grid = std::min(65535, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_GROUP")) ctx->group = std::min(std::min(kMaxLanes, SGS_MAX_GROUP), std::max(1, atoi(env)));
@@ -538,7 +551,8 @@ int sgs_destroy(sgs_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (Lane& L : ctx->lanes) {
         void* bufs[] = {L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, L.live_list, L.tile_count, L.tile_offset, L.tile_order,
-                        L.tile_prof, L.bin_prof, L.blk_list, L.blk_len, L.rec, L.alt, L.part, L.sorted_out};
+                        L.tile_prof, L.bin_prof, L.blk_list, L.blk_len, L.rec, L.alt, L.part, L.sorted_out,
+                        L.stile_count, L.stile_offset, L.jobs, L.job_base};
         for (void* b : bufs) if (b) (void)hipFree(b);
         if (L.stream) (void)hipStreamDestroy(L.stream);
         if (L.fork) (void)hipEventDestroy(L.fork);

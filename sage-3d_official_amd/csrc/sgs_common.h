@@ -31,8 +31,13 @@
 #define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)
 #define SGS_XCDS 8                  // sub-queues per tile: one per XCD the binning workgroups run on
 #define SGS_MAX_ROWS 4096           // tile rows of a frame (65536 px): length of the per-row record counters
-#define SGS_BIG_RECT 128            // splats touching more tiles than this are expanded by a whole workgroup (a wave walks its
-                                    // chunk as long as its largest rect: 128 vs 256 takes 6 us off k_bin_emit; 64 floods the big list)
+#define SGS_ST 4                    // a super-tile is SGS_ST x SGS_ST tiles (64 x 64 px): level 1 of the binning
+#define SGS_ST_SHIFT 2
+#define SGS_SEG 1024                // records of a super-tile queue per level-2 job (four per thread)
+#define SGS_EXP_THREADS 256
+#define SGS_EXP_GRID 2048           // level-2 workgroups per launch (each loops over jobs b, b + grid, ...)
+#define SGS_BIG_RECT 128            // splats touching more SUPER-TILES than this are expanded by a whole workgroup (a wave walks its
+                                    // chunk as long as its largest rect)
 #define SGS_BIG_CAP 65536           // entries of the per-frame big-splat list (overflow falls back to the wave path)
 #define SGS_MAX_LIVE 512             // live-chunk list per pass (one sweep: 512 chunks = 32 K Gaussians per workgroup and pass); LDS is what
                                      // decides how many composite workgroups fit beside a binning workgroup on a CU
@@ -62,7 +67,9 @@ struct FrameParams {
     int32_t win_rows;               // tile rows per binning window = max(1, SGS_WT / gx)
     int32_t n_windows;              // ceil((row_end - row_begin) / win_rows)
     int32_t win_tiles;              // SGS_WT or SGS_WT_BIG: counters a binning workgroup keeps in (dynamic) LDS
-    int64_t rec_capacity;           // records the queues can hold
+    int64_t rec_capacity;           // records the tile queues can hold (the super-tile queues: half as many 16-byte records)
+    int32_t job_capacity;           // level-2 jobs the job table can hold
+    int32_t pad2_;
     uint32_t flags;
     int32_t row_stride, row_phase;  // interleaved tile rows: local row k of this call is frame row k * row_stride + row_phase
     int32_t cull_y0, cull_y1;       // pixel rows outside [cull_y0, cull_y1) cannot matter to this call (conservative)
@@ -82,7 +89,9 @@ struct alignas(128) FrameStatus {
     uint32_t d_total;               // D
     uint32_t overflow;              // D > rec_capacity: emit/sort/composite did nothing
     uint32_t max_tile_len;
-    uint32_t pad0_[12];
+    uint32_t ds_total;              // records in the super-tile queues (level 1 of the binning)
+    uint32_t n_jobs;                // level-2 jobs (k_stile_scan)
+    uint32_t pad0_[10];
     // line 1: counters that workgroups ADD to while others of the same kernel read line 0 (a device-scope atomic occupies
     // its line in the fabric for ~12 ns: on one line the readers queued behind the adders)
     uint32_t n_visible;             // N_v
@@ -109,6 +118,8 @@ struct FrameSlot {
     Splat* splats; unsigned long long* vismask; unsigned long long* bigmask; unsigned* big_list; uint4* binrec;
     unsigned* live_list;            // chunks (layout order) that passed k_chunk_cull; FrameStatus.n_live of them
     unsigned* tile_count; unsigned* tile_offset; uint4* tile_order; uint2* blk_list; unsigned* blk_len;
+    unsigned* stile_count; unsigned* stile_offset; uint4* jobs; unsigned* job_base;      // two-level binning: super-tile sub-counters / offsets,
+                                                                                        // level-2 jobs, their per-tile bases (+ XCD)
     unsigned long long* rec; unsigned long long* alt; unsigned long long* part; unsigned* sorted_out;
     unsigned long long* tile_prof; unsigned long long* bin_prof;
     // the frame's output and status word

@@ -399,7 +399,11 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                         } else { brect01 = 0u; brect23 = 0u; bnt = 0; }     // reaches no pixel: nothing to bin
                     } else { brect01 = 0u; brect23 = 0u; bnt = 0; }         // opacity below alpha_min: never blended
                 } else bnt = nt;
-                big = bnt > SGS_BIG_RECT;
+                if (bnt > 0) {   // what the binning kernels walk is the rect in SUPER-TILES (level 1 of the binning)
+                    const unsigned sx0 = (brect01 & 0xffffu) >> SGS_ST_SHIFT, sx1 = ((brect23 & 0xffffu) + SGS_ST - 1) >> SGS_ST_SHIFT;
+                    const unsigned sy0 = (brect01 >> 16) >> SGS_ST_SHIFT, sy1 = ((brect23 >> 16) + SGS_ST - 1) >> SGS_ST_SHIFT;
+                    big = (sx1 - sx0) * (sy1 - sy0) > (unsigned)SGS_BIG_RECT;
+                }
                 sx = (float)px; sy = (float)py;
                 const double idet = 1.0 / det;
                 ca = (float)(c * idet); cb = (float)(-b * idet); cc = (float)(a * idet);
@@ -634,7 +638,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
         tile_offset[(size_t)t_hi * SGS_XCDS] = total;      // end of the band's last queue (k_bin_emit never reads past it)
         st->d_total = total;
         st->max_tile_len = tmax;
-        st->overflow = (unsigned long long)total > (unsigned long long)P.rec_capacity ? 1u : 0u;
+        if ((unsigned long long)total > (unsigned long long)P.rec_capacity) st->overflow = 1u;      // (k_stile_scan may have set it already)
     }
 }
 
@@ -705,20 +709,43 @@ __device__ __forceinline__ void find_live_chunks(const FrameParams& P, const uns
     __syncthreads();
 }
 
-// Bins the records of the listed chunks that fall into tile rows [wr0, wr1) of the current window.
-//   EMIT == false: s_arr = per-tile counters of the window (LDS); counts every record.
-//   EMIT == true : s_arr = per-tile write cursors (LDS); writes depth<<32|slot records to `rec`.
-// One wave per chunk.  Neighbouring Gaussians cover the same tiles, so the wave walks the UNION of its
-// lanes' rects tile by tile and ballots "who covers this tile": one LDS atomic per (wave, tile) adds
-// popc(ballot) — instead of one same-address atomic per record — and in the emit every covering lane
-// stores at base + (its rank in the ballot), i.e. the wave writes one contiguous run per tile.
-// Only chunks whose lanes overlap heavily take this path (near-camera surfaces: 64 splats over the same
-// ~150 tiles); the others walk one rect per lane.
+// ---- level 1: splats -> SUPER-TILES (SGS_ST x SGS_ST tiles, 64 x 64 px) --------------------------------------------------
+// Binning is two-level.  A splat's tile rect covers a handful of tiles but one or two super-tiles, so the scattered,
+// LDS-atomic-per-record duplication runs on ~1/3 (small splats) to ~1/12 (large ones) of the records, against a window of
+// at most 8192 super-tile counters that is zeroed, swept and flushed in a fraction of the time the per-tile window took
+// (a 1080p frame has 510 super-tiles); what it queues per super-tile is the splat's 16-byte binning record itself.
+// Level 2 (k_expand) then hands every super-tile queue, in segments of SGS_SEG records, to workgroups that expand the
+// records to the 16 tiles of THEIR super-tile with wave ballots — no atomics per record, one global atomic per (segment,
+// tile) — and write each tile's records as contiguous runs.  (Per-tile binning in one level wrote 8-byte records one
+// by one: on a scene with trained-3DGS statistics, D = 28 M, count + emit took 480 us of a 790-us frame, r03j.)
+struct SuperGrid { int gxs, sr0, sr1, ns; };
+__device__ __forceinline__ SuperGrid super_grid(const FrameParams& P) {
+    SuperGrid g;
+    g.gxs = (P.gx + SGS_ST - 1) >> SGS_ST_SHIFT;
+    g.sr0 = P.row_begin >> SGS_ST_SHIFT; g.sr1 = (P.row_end + SGS_ST - 1) >> SGS_ST_SHIFT;     // rows of the band, in super-tiles
+    g.ns = max(0, g.sr1 - g.sr0) * g.gxs;
+    return g;
+}
+// a binning record's tile rect -> its super-tile rect, rows relative to the band's first super-row (empty rect: on = false)
+__device__ __forceinline__ bool super_rect(const SuperGrid& SG, const uint4& br, unsigned& x0, unsigned& x1, unsigned& y0, unsigned& y1) {
+    const unsigned tx0 = br.y & 0xffffu, tx1 = br.z & 0xffffu, ty0 = br.y >> 16, ty1 = br.z >> 16;
+    if (tx1 <= tx0 || ty1 <= ty0) return false;
+    x0 = tx0 >> SGS_ST_SHIFT; x1 = (tx1 + SGS_ST - 1) >> SGS_ST_SHIFT;
+    y0 = (ty0 >> SGS_ST_SHIFT) - (unsigned)SG.sr0; y1 = ((ty1 + SGS_ST - 1) >> SGS_ST_SHIFT) - (unsigned)SG.sr0;
+    return true;
+}
+
+// Bins the records of the listed chunks into the super-tiles of the band.
+//   EMIT == false: s_arr = per-super-tile counters (LDS); counts every record.
+//   EMIT == true : s_arr = per-super-tile write cursors (LDS); writes the 16-byte binning records to `srec`.
+// One wave per chunk.  Neighbouring Gaussians cover the same super-tiles, so when the lanes overlap heavily the wave
+// walks the UNION of its lanes' rects cell by cell and ballots "who covers this cell": one LDS atomic per (wave, cell)
+// adds popc(ballot) and, in the emit, the covering lanes store one contiguous run.  Otherwise every lane walks its own rect.
 #define SGS_WALK_TILES 8
 #define SGS_FLUSH_ROUNDS 8
 template <bool EMIT>
-__device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __restrict__ binrec, const LiveChunks& lc,
-                                         int wr0, int wr1, unsigned* s_arr, unsigned long long* __restrict__ rec) {
+__device__ __forceinline__ void bin_walk(const SuperGrid& SG, const uint4* __restrict__ binrec, const LiveChunks& lc,
+                                         unsigned* s_arr, uint4* __restrict__ srec) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const unsigned nlive = lc.n;
     // a wave's chunks are a chain of (list entry -> 16-B record load -> walk): the next chunk's records are requested
@@ -730,7 +757,7 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
         if (live_next) br_next = binrec[lc.chunk[wave] * SGS_WAVE + (unsigned)lane];
     }
     for (unsigned k = (unsigned)wave; k < nlive; k += (unsigned)nwaves) {
-        unsigned slot = 0, key = 0, x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
+        unsigned x0 = 0xffffu, x1 = 0, y0 = 0xffffu, y1 = 0;         // empty rect
         const uint4 br = br_next;
         const bool live = live_next;
         {
@@ -738,27 +765,21 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
             live_next = kn < nlive && ((lc.mask[min(kn, (unsigned)SGS_MAX_LIVE - 1u)] >> lane) & 1ull);
             if (live_next) br_next = binrec[lc.chunk[kn] * SGS_WAVE + (unsigned)lane];
         }
+        bool on = false;
         if (live) {
-            slot = br.w;
-            const int ya = max((int)(br.y >> 16), wr0), yb = min((int)(br.z >> 16), wr1);
-            if (yb > ya) {
-                key = br.x; x0 = br.y & 0xffffu; x1 = br.z & 0xffffu;
-                y0 = (unsigned)(ya - wr0); y1 = (unsigned)(yb - wr0);
-            }
+            unsigned a0, a1, b0, b1;
+            if (super_rect(SG, br, a0, a1, b0, b1)) { x0 = a0; x1 = a1; y0 = b0; y1 = b1; on = true; }
         }
-        const bool on = y1 > y0;
         const unsigned cnt = on ? (x1 - x0) * (y1 - y0) : 0u;
-        const unsigned long long r = ((unsigned long long)key << 32) | slot;
         const unsigned ux0 = wave_min(x0), uy0 = wave_min(y0), ux1 = wave_max(x1), uy1 = wave_max(y1);
-        if (ux1 <= ux0 || uy1 <= uy0) continue;                              // nothing in this window
+        if (ux1 <= ux0 || uy1 <= uy0) continue;                              // nothing to bin
         const unsigned area = (ux1 - ux0) * (uy1 - uy0), total = wave_sum(cnt);
         if (area * 16u <= total) {
-            // tile-major pays ~300 cycles per union tile here (a ballot -> scalar -> one-lane-atomic chain at ~1 wave per
-            // SIMD; thresholds of 8, 4 and 2 records per tile were measured and lose): worth it only when the lanes overlap
-            // heavily (>= 16 records per tile of the union rect)
+            // cell-major pays ~300 cycles per union cell (a ballot -> scalar -> one-lane-atomic chain): worth it only when the
+            // lanes overlap heavily (>= 16 records per cell of the union rect)
             for (unsigned ty = uy0; ty < uy1; ++ty) {
                 const bool row_on = on && ty >= y0 && ty < y1;
-                const unsigned row = ty * (unsigned)P.gx;
+                const unsigned row = ty * (unsigned)SG.gxs;
                 for (unsigned tx = ux0; tx < ux1; ++tx) {
                     const unsigned long long m = __ballot(row_on && tx >= x0 && tx < x1);
                     if (m == 0ull) continue;
@@ -769,48 +790,43 @@ __device__ __forceinline__ void bin_walk(const FrameParams& P, const uint4* __re
                         unsigned base = 0;
                         if (lane == leader) base = atomicAdd(&s_arr[row + tx], (unsigned)__popcll(m));
                         base = __shfl(base, leader);
-                        if ((m >> lane) & 1ull) rec[base + (unsigned)__popcll(m & lanemask_lt(lane))] = r;
+                        if ((m >> lane) & 1ull) srec[base + (unsigned)__popcll(m & lanemask_lt(lane))] = br;
                     }
                 }
             }
         } else if (on) {
-            // lane-major: every lane walks its own rect, SGS_WALK_TILES tiles per trip.  These kernels run ~1 wave per
-            // SIMD, so what a trip costs is the LENGTH of its dependent chain, not its instruction count: every tile's
-            // (row, column) comes from its own index (i + 0.5) / w — exact in fp32 for rects of up to 256 tiles — instead
-            // of stepping a shared (tx, row) pair, and the LDS atomics of a trip are all in flight together
-            // (measured: ~560 cycles per 4-tile trip with the stepped version).
+            // lane-major: every lane walks its own rect, SGS_WALK_TILES cells per trip; every cell's (row, column) comes from
+            // its own index (i + 0.5) / w — exact in fp32 for rects of up to 256 cells — and the LDS atomics of a trip are
+            // all in flight together
             const unsigned w = x1 - x0;
             const float rw = 1.0f / (float)w;
-            const unsigned origin = y0 * (unsigned)P.gx + x0;
+            const unsigned origin = y0 * (unsigned)SG.gxs + x0;
             for (unsigned i = 0; i < cnt; i += SGS_WALK_TILES) {
                 unsigned tl[SGS_WALK_TILES], dst[SGS_WALK_TILES];
 #pragma unroll
                 for (int u = 0; u < SGS_WALK_TILES; ++u) {
                     const unsigned iu = i + (unsigned)u;
                     const unsigned ty = (unsigned)(((float)iu + 0.5f) * rw);
-                    tl[u] = origin + ty * (unsigned)P.gx + (iu - ty * w);
+                    tl[u] = origin + ty * (unsigned)SG.gxs + (iu - ty * w);
                 }
 #pragma unroll
                 for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
                 if (EMIT) {
 #pragma unroll
-                    for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) rec[dst[u]] = r;
+                    for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) srec[dst[u]] = br;
                 }
             }
         }
     }
 }
 
-// The big-rect splats (k_preprocess's list), dealt round-robin to the workgroups; every thread of the
-// workgroup takes a share of each rect.  Same callback contract as bin_walk.  The workgroup first fetches the records
-// of up to SGS_BIN_THREADS of its rects in ONE round of loads (list entry -> record: two dependent global loads, ~3 us)
-// and then walks them out of LDS: fetched one rect at a time that chain was paid per rect — on a scene with trained-3DGS
-// statistics (thousands of splats of hundreds of tiles each) it was most of both binning kernels (r03j: count 192 us,
-// emit 344 us at D = 29 M).  Must be called by all threads.
+// The big-rect splats (k_preprocess's list: more than SGS_BIG_RECT super-tiles), dealt round-robin to the workgroups;
+// every thread of the workgroup takes a share of each rect.  The workgroup first fetches the records of up to
+// SGS_BIN_THREADS of its rects in ONE round of loads (list entry -> record: two dependent global loads, ~3 us) and then
+// walks them out of LDS.  Must be called by all threads.  f(cell, record).
 template <class F>
-__device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* __restrict__ binrec,
-                                             const unsigned* __restrict__ big_list, unsigned n_big,
-                                             int wr0, int wr1, uint4* s_big, F&& f) {
+__device__ __forceinline__ void bin_walk_big(const FrameParams& P, const SuperGrid& SG, const uint4* __restrict__ binrec,
+                                             const unsigned* __restrict__ big_list, unsigned n_big, uint4* s_big, F&& f) {
     n_big = min(n_big, (unsigned)SGS_BIG_CAP);
     const unsigned B = bin_B(P), b = bin_b(P);
     const unsigned mine = n_big > b ? (n_big - b + B - 1u) / B : 0u;      // rects b, b + B, b + 2B, ... (uniform)
@@ -820,31 +836,28 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const uint4* 
         __syncthreads();
         for (unsigned j = 0; j < nr; ++j) {
             const uint4 br = s_big[j];
-            const unsigned key = br.x, r01 = br.y, r23 = br.z, slot = br.w;
-            const unsigned x0 = r01 & 0xffffu, w = (r23 & 0xffffu) - x0;
-            const int ya = max((int)(r01 >> 16), wr0), yb = min((int)(r23 >> 16), wr1);
-            if (yb <= ya) continue;                              // workgroup-uniform
-            const unsigned total = w * (unsigned)(yb - ya);
+            unsigned x0, x1, y0, y1;
+            if (!super_rect(SG, br, x0, x1, y0, y1)) continue;   // workgroup-uniform
+            const unsigned w = x1 - x0, total = w * (y1 - y0);
             const float rw = 1.0f / (float)w;
             for (unsigned k = threadIdx.x; k < total; k += blockDim.x) {
                 // k / w without an integer divide: exact for k < 2^21 (tests/test_emu_parity.py)
                 const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
-                unsigned tl[4] = {((unsigned)(ya - wr0) + ty) * (unsigned)P.gx + x0 + (k - ty * w), 0u, 0u, 0u};
-                f(tl, 1u, key, slot);
+                f((y0 + ty) * (unsigned)SG.gxs + x0 + (k - ty * w), br);
             }
         }
         __syncthreads();
     }
 }
 
-// (~39 KB of LDS per workgroup: what a binning workgroup takes from a CU is what the composite workgroups of the
-// frames in flight cannot use)
+// (~15 KB of LDS per workgroup at 1080p: what a binning workgroup takes from a CU is what the composite workgroups of
+// the frames in flight cannot use)
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
     const unsigned long long* __restrict__ vismask = S.vismask; const unsigned long long* __restrict__ bigmask = S.bigmask;
-    const unsigned* __restrict__ big_list = S.big_list; unsigned* __restrict__ tile_count = S.tile_count;
+    const unsigned* __restrict__ big_list = S.big_list; unsigned* __restrict__ stile_count = S.stile_count;
     uint2* __restrict__ blk_list = S.blk_list; unsigned* __restrict__ blk_len = S.blk_len;
     FrameStatus* __restrict__ st = S.st; unsigned long long* prof = S.bin_prof;
     (void)prof;
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
 #else
 #define SGS_BPROF(acc) do { } while (0)
 #endif
-    SGS_DYNAMIC_LDS(unsigned, s_cnt);                // P.win_tiles counters
+    SGS_DYNAMIC_LDS(unsigned, s_cnt);                // one counter per super-tile of the band (rounded up to whole flush rounds)
     __shared__ unsigned s_nlist;
     __shared__ LiveChunks lc;
     __shared__ uint4 s_big[SGS_BIN_THREADS];          // the records of this workgroup's big rects, a round at a time
@@ -863,38 +876,30 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
     const unsigned n_live = st->n_live;
     const unsigned* __restrict__ live_list = S.live_list;
     const int n_sweeps = bin_sweeps(P, n_live);
+    const SuperGrid SG = super_grid(P);
     unsigned n_vis = 0;
     const unsigned b = bin_b(P);
     {
-        const int w = bin_w(P);
-        const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
-        // the counters this window can touch, rounded up to whole flush rounds (a band or a small frame spans far
-        // fewer than the window's capacity)
-        const int used = min(P.win_tiles, (((wr1 - wr0) * P.gx + 127) / 128) * 128);
+        const int used = ((SG.ns + 127) / 128) * 128;
         for (int i = tid; i < used; i += SGS_BIN_THREADS) s_cnt[i] = 0;
         if (tid == 0) s_nlist = 0;
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, bigmask, live_list, n_live, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
             SGS_BPROF(bt_find);
-            if (w == 0) n_vis += lc.n_vis;
-            bin_walk<false>(P, binrec, lc, wr0, wr1, s_cnt, nullptr);
+            n_vis += lc.n_vis;
+            bin_walk<false>(SG, binrec, lc, s_cnt, nullptr);
             __syncthreads();
             SGS_BPROF(bt_walk);
         }
-        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1, s_big,
-                     [&](const unsigned* tl, unsigned, unsigned, unsigned) { atomicAdd(&s_cnt[tl[0]], 1u); });
+        bin_walk_big(P, SG, binrec, big_list, st->n_big, s_big, [&](unsigned cell, const uint4&) { atomicAdd(&s_cnt[cell], 1u); });
         __syncthreads();
         SGS_BPROF(bt_big);
-        // flush: one device-scope atomic per touched tile — its return value is our base in the tile's sub-queue.
-        // Every wave sweeps a 1/8 of the window's counters 64 at a time; the touched ones are compacted with a
-        // ballot straight into the workgroup's (tile, base) list (no LDS list of touched tiles: LDS is what limits
-        // how many composite workgroups share the CU with this kernel).
-        uint2* out = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
+        // flush: one device-scope atomic per touched super-tile — its return value is our base in that super-tile's
+        // sub-queue.  The touched counters are compacted with a ballot straight into the workgroup's (cell, base) list.
+        uint2* out = blk_list + (size_t)b * SGS_WT;
         {
             const int lane = tid & 63, wave = tid >> 6;
-            // waves interleave slabs of SGS_FLUSH_ROUNDS x 64 counters; a trip's atomics (device scope, ~1 us each way)
-            // are all in flight together: at 1080p a wave makes 2 trips instead of 8 round trips in sequence
             for (int i0 = wave * (SGS_FLUSH_ROUNDS * 64); i0 < used; i0 += (SGS_BIN_THREADS / 64) * (SGS_FLUSH_ROUNDS * 64)) {
                 unsigned tl[SGS_FLUSH_ROUNDS], c[SGS_FLUSH_ROUNDS], pre[SGS_FLUSH_ROUNDS], base[SGS_FLUSH_ROUNDS];
                 unsigned tot = 0;
@@ -913,10 +918,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
 #pragma unroll
                 for (int u = 0; u < SGS_FLUSH_ROUNDS; ++u) {
                     base[u] = 0;
-                    if (c[u] != 0u) {
-                        s_cnt[tl[u]] = 0;                             // ready for the next window
-                        base[u] = atomicAdd(&tile_count[((size_t)wr0 * P.gx + tl[u]) * SGS_XCDS + xcd], c[u]);
-                    }
+                    if (c[u] != 0u) base[u] = atomicAdd(&stile_count[(size_t)tl[u] * SGS_XCDS + xcd], c[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < SGS_FLUSH_ROUNDS; ++u)
@@ -926,19 +928,68 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
         __syncthreads();
         const unsigned nl = s_nlist;
         if (tid == 0) {
-            blk_len[b * SGS_MAX_WINDOWS + w] = nl;
-            blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + b * SGS_MAX_WINDOWS + w] = xcd;   // k_bin_emit must use the same sub-queue
-            if (w == 0 && n_vis) atomicAdd(&st->n_visible, n_vis);    // one per workgroup
+            blk_len[b] = nl;
+            blk_len[SGS_BIN_BLOCKS + b] = xcd;                        // k_bin_emit must use the same sub-queue
+            if (n_vis) atomicAdd(&st->n_visible, n_vis);              // one per workgroup
         }
         __syncthreads();
         SGS_BPROF(bt_flush);
     }
 #ifdef SGS_TILE_PROF
-    if (tid == 0 && prof && bin_w(P) == 0) {
+    if (tid == 0 && prof) {
         unsigned long long* o = prof + (size_t)b * 8;
         o[0] = lc.n; o[1] = bt_find; o[2] = bt_walk; o[3] = bt_flush; o[4] = s_nlist; o[5] = n_vis; o[6] = clock64() - bt0; o[7] = bt_big;
     }
 #endif
+}
+
+// Exclusive scan of the super-tile sub-counters (one workgroup: at most 8192 super-tiles), the total, and the level-2
+// work list: super-tile s with c records becomes ceil(c / SGS_SEG) jobs (super-tile, first record, records).
+#define SGS_SSCAN_THREADS 1024
+__global__ __launch_bounds__(SGS_SSCAN_THREADS) void k_stile_scan(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const unsigned* __restrict__ stile_count = S.stile_count; unsigned* __restrict__ stile_offset = S.stile_offset;
+    uint4* __restrict__ jobs = S.jobs; FrameStatus* __restrict__ st = S.st;
+    constexpr int NW = SGS_SSCAN_THREADS / SGS_WAVE;
+    __shared__ unsigned s_wr[NW], s_wj[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const SuperGrid SG = super_grid(P);
+    const int per = (SG.ns + SGS_SSCAN_THREADS - 1) / SGS_SSCAN_THREADS;       // consecutive super-tiles per thread (<= 8)
+    const int s0 = tid * per, s1 = min(SG.ns, s0 + per);
+    unsigned rsum = 0, jsum = 0;
+    for (int s = s0; s < s1; ++s) {
+        const uint4* cp = reinterpret_cast<const uint4*>(stile_count + (size_t)s * SGS_XCDS);
+        const uint4 a = cp[0], bq = cp[1];
+        const unsigned c = a.x + a.y + a.z + a.w + bq.x + bq.y + bq.z + bq.w;
+        rsum += c; jsum += (c + SGS_SEG - 1) / SGS_SEG;
+    }
+    const unsigned ri = wave_incl_scan(rsum, lane), ji = wave_incl_scan(jsum, lane);
+    if (lane == 63) { s_wr[wave] = ri; s_wj[wave] = ji; }
+    __syncthreads();
+    unsigned rbase = ri - rsum, jbase = ji - jsum, rtot = 0, jtot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { rbase += w < wave ? s_wr[w] : 0u; jbase += w < wave ? s_wj[w] : 0u; rtot += s_wr[w]; jtot += s_wj[w]; }
+    const bool fits = (unsigned long long)rtot <= (unsigned long long)(P.rec_capacity >> 1) && jtot <= (unsigned)P.job_capacity;
+    for (int s = s0; s < s1; ++s) {
+        const uint4* cp = reinterpret_cast<const uint4*>(stile_count + (size_t)s * SGS_XCDS);
+        const uint4 a = cp[0], bq = cp[1];
+        unsigned run = rbase;
+        uint4 o0, o1;
+        o0.x = run; run += a.x; o0.y = run; run += a.y; o0.z = run; run += a.z; o0.w = run; run += a.w;
+        o1.x = run; run += bq.x; o1.y = run; run += bq.y; o1.z = run; run += bq.z; o1.w = run; run += bq.w;
+        uint4* op = reinterpret_cast<uint4*>(stile_offset + (size_t)s * SGS_XCDS);
+        op[0] = o0; op[1] = o1;
+        const unsigned c = run - rbase;
+        if (fits)
+            for (unsigned q = 0; q < c; q += SGS_SEG) jobs[jbase++] = uint4{(unsigned)s, rbase + q, min((unsigned)SGS_SEG, c - q), 0u};
+        rbase = run;
+    }
+    if (tid == 0) {
+        st->ds_total = rtot;
+        st->n_jobs = fits ? jtot : 0u;
+        if (!fits) st->overflow = 1u;                 // the super-tile queues do not fit: nothing after this kernel runs (the caller grows them)
+    }
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G) {
@@ -946,18 +997,19 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
     const unsigned long long* __restrict__ vismask = S.vismask; const unsigned long long* __restrict__ bigmask = S.bigmask;
-    const unsigned* __restrict__ big_list = S.big_list; const unsigned* __restrict__ tile_offset = S.tile_offset;
+    const unsigned* __restrict__ big_list = S.big_list; const unsigned* __restrict__ stile_offset = S.stile_offset;
     const uint2* __restrict__ blk_list = S.blk_list; const unsigned* __restrict__ blk_len = S.blk_len;
-    unsigned long long* __restrict__ rec = S.rec; unsigned* __restrict__ tile_count = S.tile_count;
+    uint4* __restrict__ srec = reinterpret_cast<uint4*>(S.alt); unsigned* __restrict__ stile_count = S.stile_count;
     const FrameStatus* __restrict__ st = S.st;
-    SGS_DYNAMIC_LDS(unsigned, s_next);               // P.win_tiles write cursors
+    SGS_DYNAMIC_LDS(unsigned, s_next);               // write cursors, one per super-tile
     __shared__ LiveChunks lc;
     __shared__ uint4 s_big[SGS_BIN_THREADS];
     const int tid = threadIdx.x;
-    {   // k_tile_scan has consumed the band's counters: zero again for the next frame (no per-frame memset), also
-        // when this frame overflowed
-        uint4* z = reinterpret_cast<uint4*>(tile_count + (size_t)P.row_begin * P.gx * SGS_XCDS);
-        const unsigned nz = (unsigned)((P.row_end - P.row_begin) * P.gx) * (SGS_XCDS / 4);
+    const SuperGrid SG = super_grid(P);
+    {   // k_stile_scan has consumed the counters: zero again for the next frame (no per-frame memset), also when this
+        // frame overflowed
+        uint4* z = reinterpret_cast<uint4*>(stile_count);
+        const unsigned nz = (unsigned)SG.ns * (SGS_XCDS / 4);
         for (unsigned i = blockIdx.x * SGS_BIN_THREADS + tid; i < nz; i += gridDim.x * SGS_BIN_THREADS) z[i] = uint4{0u, 0u, 0u, 0u};
     }
     if (st->overflow) return;
@@ -966,26 +1018,121 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
     const unsigned* __restrict__ live_list = S.live_list;
     const int n_sweeps = bin_sweeps(P, n_live);
     {
-        const int w = bin_w(P);
-        const unsigned xcd = blk_len[SGS_BIN_BLOCKS * SGS_MAX_WINDOWS + b * SGS_MAX_WINDOWS + w];   // the XCD k_bin_count ran (b, w) on
-        const int wr0 = P.row_begin + w * P.win_rows, wr1 = min(P.row_end, wr0 + P.win_rows);
-        const unsigned nl = blk_len[b * SGS_MAX_WINDOWS + w];
-        const uint2* in = blk_list + ((size_t)b * P.n_windows + w) * P.win_tiles;
+        const unsigned xcd = blk_len[SGS_BIN_BLOCKS + b];              // the XCD k_bin_count ran workgroup b on
+        const unsigned nl = blk_len[b];
+        const uint2* in = blk_list + (size_t)b * SGS_WT;
         for (unsigned i = tid; i < nl; i += SGS_BIN_THREADS) {
             const uint2 e = in[i];
-            s_next[e.x] = tile_offset[((size_t)wr0 * P.gx + e.x) * SGS_XCDS + xcd] + e.y;
+            s_next[e.x] = stile_offset[(size_t)e.x * SGS_XCDS + xcd] + e.y;
         }
         __syncthreads();
         for (int sw = 0; sw < n_sweeps; sw += SGS_SWEEPS_PER_PASS) {
             find_live_chunks(P, vismask, bigmask, live_list, n_live, lc, sw, min(n_sweeps, sw + SGS_SWEEPS_PER_PASS));
-            bin_walk<true>(P, binrec, lc, wr0, wr1, s_next, rec);
+            bin_walk<true>(SG, binrec, lc, s_next, srec);
             __syncthreads();
         }
-        bin_walk_big(P, binrec, big_list, st->n_big, wr0, wr1, s_big,
-                     [&](const unsigned* tl, unsigned, unsigned okey, unsigned oslot) {
-                         rec[atomicAdd(&s_next[tl[0]], 1u)] = ((unsigned long long)okey << 32) | oslot;
-                     });
+        bin_walk_big(P, SG, binrec, big_list, st->n_big, s_big,
+                     [&](unsigned cell, const uint4& br) { srec[atomicAdd(&s_next[cell], 1u)] = br; });
         __syncthreads();
+    }
+}
+
+// ---- level 2: super-tile queues -> tile queues -----------------------------------------------------------------------------
+// Job j = SGS_SEG consecutive records of one super-tile's queue, four per thread.  Every record covers some of the
+// super-tile's 16 tiles (its tile rect, clipped); for tile t the covering lanes of a wave find each other with ONE ballot:
+//   EMIT == false: the ballots' popcounts are summed per tile over the workgroup and added to the tile's sub-counter with
+//                  one global atomic per tile — its return value is the job's base in that tile's sub-queue (job_base);
+//   EMIT == true : the same ballots give every covering lane its rank: the records of (wave, slot, tile) are stored as one
+//                  contiguous run at  tile offset + job base + (what the job's earlier waves and slots put into the tile).
+// No per-record atomics, and the 8-byte records reach HBM in runs instead of one by one.
+template <bool EMIT>
+__global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) {
+    const FrameSlot& S = G.s[blockIdx.y];
+    const FrameParams& P = S.P;
+    const uint4* __restrict__ srec = reinterpret_cast<const uint4*>(S.alt); const uint4* __restrict__ jobs = S.jobs;
+    unsigned* __restrict__ tile_count = S.tile_count; const unsigned* __restrict__ tile_offset = S.tile_offset;
+    unsigned* __restrict__ job_base = S.job_base; unsigned long long* __restrict__ rec = S.rec;
+    const FrameStatus* __restrict__ st = S.st;
+    constexpr int NW = SGS_EXP_THREADS / SGS_WAVE, NT = SGS_ST * SGS_ST, R = SGS_SEG / SGS_EXP_THREADS;
+    __shared__ unsigned s_wc[NW][NT];                // records per (wave, tile) of this job
+    __shared__ unsigned s_base[NT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (EMIT) {   // k_tile_scan has consumed the band's tile counters: zero again for the next frame, also when this frame overflowed
+        uint4* z = reinterpret_cast<uint4*>(tile_count + (size_t)P.row_begin * P.gx * SGS_XCDS);
+        const unsigned nz = (unsigned)((P.row_end - P.row_begin) * P.gx) * (SGS_XCDS / 4);
+        for (unsigned i = blockIdx.x * SGS_EXP_THREADS + tid; i < nz; i += gridDim.x * SGS_EXP_THREADS) z[i] = uint4{0u, 0u, 0u, 0u};
+    }
+    if (st->overflow) return;
+    const SuperGrid SG = super_grid(P);
+    const unsigned n_jobs = st->n_jobs;
+    const unsigned my_xcd = xcc_id();
+    for (unsigned job = blockIdx.x; job < n_jobs; job += gridDim.x) {
+        const uint4 J = jobs[job];
+        const unsigned scell = J.x, qb = J.y, cnt = J.z;
+        const unsigned tx0 = (scell % (unsigned)SG.gxs) << SGS_ST_SHIFT;
+        const unsigned ty0 = (scell / (unsigned)SG.gxs + (unsigned)SG.sr0) << SGS_ST_SHIFT;     // the super-tile's first tile (owned rows)
+        // which of the 16 tiles each of my records covers (bit ly * 4 + lx)
+        unsigned cover[R]; unsigned long long rv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const unsigned i = (unsigned)tid + (unsigned)(r * SGS_EXP_THREADS);
+            cover[r] = 0u; rv[r] = 0ull;
+            if (i < cnt) {
+                const uint4 br = srec[qb + i];
+                rv[r] = ((unsigned long long)br.x << 32) | br.w;
+                const unsigned x0 = br.y & 0xffffu, x1 = br.z & 0xffffu, y0 = br.y >> 16, y1 = br.z >> 16;
+                unsigned xm = 0u, ym = 0u;
+#pragma unroll
+                for (int l = 0; l < SGS_ST; ++l) {
+                    xm |= (tx0 + (unsigned)l >= x0 && tx0 + (unsigned)l < x1) ? 1u << l : 0u;
+                    ym |= (ty0 + (unsigned)l >= y0 && ty0 + (unsigned)l < y1) ? 1u << l : 0u;
+                }
+#pragma unroll
+                for (int l = 0; l < SGS_ST; ++l) cover[r] |= ((ym >> l) & 1u) ? xm << (SGS_ST * l) : 0u;
+            }
+        }
+        // per (wave, tile) counts; lane t < 16 of every wave keeps tile t's
+        unsigned mine = 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            unsigned c = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot((cover[r] >> t) & 1u));
+            mine = lane == t ? c : mine;
+        }
+        if (lane < NT) s_wc[wave][lane] = mine;
+        __syncthreads();
+        if (tid < NT) {
+            const unsigned tile = (ty0 + (unsigned)(tid >> SGS_ST_SHIFT)) * (unsigned)P.gx + tx0 + (unsigned)(tid & (SGS_ST - 1));
+            unsigned tot = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += s_wc[w][tid];
+            if (!EMIT) {
+                // (a tile outside the grid / the band has no covering record: tot == 0 and nothing is touched)
+                const unsigned base = tot ? atomicAdd(&tile_count[(size_t)tile * SGS_XCDS + my_xcd], tot) : 0u;
+                job_base[(size_t)job * (NT + 1) + tid] = base;
+                if (tid == 0) job_base[(size_t)job * (NT + 1) + NT] = my_xcd;       // the emit must use the same sub-queue
+            } else {
+                const unsigned xcd = job_base[(size_t)job * (NT + 1) + NT];
+                s_base[tid] = tot ? tile_offset[(size_t)tile * SGS_XCDS + xcd] + job_base[(size_t)job * (NT + 1) + tid] : 0u;
+            }
+        }
+        if (EMIT) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                unsigned pos = s_base[t];
+                for (int w = 0; w < wave; ++w) pos += s_wc[w][t];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const bool hit = (cover[r] >> t) & 1u;
+                    const unsigned long long m = __ballot(hit);
+                    if (hit) rec[pos + (unsigned)__popcll(m & lanemask_lt(lane))] = rv[r];
+                    pos += (unsigned)__popcll(m);
+                }
+            }
+        }
+        __syncthreads();                              // s_wc / s_base are rewritten by the next job
     }
 }
 
