@@ -1666,11 +1666,54 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     // buckets cut from that sliver hold a handful of records each — the bucket-local rank below is then one or two trips
     // instead of ten, and a bucket too long for one batch (the slow paths) all but disappears.  Any monotone map is correct:
     // bucket(key) = 0 at or below klo, (key - klo) >> ksh above it, capped at SGS_NB - 1.
-    unsigned klo = 0u, ksh = 0u;
+    // A LONG queue (n > SGS_QCAP: it stays in HBM) whose FRONT bucket is still longer than one batch — a 640x480 frame's tile
+    // sees nine times the scene area of a 1080p tile: queues of 10-60 k records, hundreds per bucket — is partitioned again,
+    // over the key range of that bucket alone (refinement, below): keys under kdone are consumed and ignored from then on,
+    // everything behind the refined range collects in the last bucket until its turn comes.
+    unsigned klo = 0u, ksh = 0u, kdone = 0u, pbase = 0u;        // pbase: queue position of the current partition's first bucket
 #define SGS_BUCKET_OF(key) ((key) <= klo ? 0u : min((unsigned)(SGS_NB - 1), ((key) - klo) >> ksh))
     if (tid < 2) { s_any[tid] = 0; s_hyper[tid] = 0; }
     if (tid < 64) reinterpret_cast<unsigned*>(&s_ball[0][0][0])[tid] = 0u;   // both parities: 2 x 4 quadrants x 4 x 64 bits
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
+    // exclusive scan of the SGS_NB bucket counts in s_bcnt (-> cursors, positions from pbase) + ordered compaction of the
+    // non-empty buckets; all threads, ends with a barrier
+    auto scan_buckets = [&]() {
+        const unsigned c = s_bcnt[tid];
+        const unsigned incl = wave_incl_scan(c, lane);
+        const unsigned long long nem = __ballot(c != 0u);
+        if (lane == 63) s_wsum[wave] = incl;
+        if (lane == 0) s_wne[wave] = (unsigned)__popcll(nem);
+        __syncthreads();
+        unsigned ex = pbase + incl - c, nb = 0;
+        n_ne = 0;
+        for (int w = 0; w < 4; ++w) { if (w < wave) { ex += s_wsum[w]; nb += s_wne[w]; } n_ne += s_wne[w]; }
+        s_bcnt[tid] = ex;                             // scatter cursor
+        if (c != 0u) {
+            const unsigned p = nb + (unsigned)__popcll(nem & lanemask_lt(lane));
+            s_ne_end[p] = ex + c; s_ne_bkt[p] = (unsigned short)tid;
+        }
+        __syncthreads();
+    };
+    // long queues: the histogram of the records not yet consumed (key >= kdone) under the current (klo, ksh); all threads
+    auto long_histogram = [&]() {
+        s_bcnt[tid] = 0;
+        __syncthreads();
+        for (unsigned i0 = 0; i0 < n; i0 += 1024) {                 // four loads in flight per lane
+            unsigned long long x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                x[r] = i < n ? rec[beg + i] : ~0ull;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned key = (unsigned)(x[r] >> 32);
+                if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone) atomicAdd(&s_bcnt[SGS_BUCKET_OF(key)], 1u);
+            }
+        }
+        __syncthreads();
+        scan_buckets();
+    };
     {
         unsigned long long rq[4];                      // the queue (n <= SGS_QCAP), or its first SGS_QCAP records: a sample of its depths
 #pragma unroll
@@ -1715,38 +1758,9 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 for (int r = 0; r < 4; ++r)
                     if ((unsigned)tid + 256u * (unsigned)r < n)
                         atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(rq[r] >> 32))], 1u);
-            } else {
-                for (unsigned i0 = 0; i0 < n; i0 += 1024) {                 // four loads in flight per lane
-                    unsigned long long x[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
-                        x[r] = i < n ? rec[beg + i] : ~0ull;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (i0 + (unsigned)tid + 256u * (unsigned)r < n)
-                            atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(x[r] >> 32))], 1u);
-                }
-            }
-            __syncthreads();
-            {
-                // exclusive scan of the 256 counts + ordered compaction of the non-empty buckets
-                const unsigned c = s_bcnt[tid];
-                const unsigned incl = wave_incl_scan(c, lane);
-                const unsigned long long nem = __ballot(c != 0u);
-                if (lane == 63) s_wsum[wave] = incl;
-                if (lane == 0) s_wne[wave] = (unsigned)__popcll(nem);
                 __syncthreads();
-                unsigned ex = incl - c, nb = 0;
-                for (int w = 0; w < 4; ++w) { if (w < wave) { ex += s_wsum[w]; nb += s_wne[w]; } n_ne += s_wne[w]; }
-                s_bcnt[tid] = ex;                             // scatter cursor
-                if (c != 0u) {
-                    const unsigned p = nb + (unsigned)__popcll(nem & lanemask_lt(lane));
-                    s_ne_end[p] = ex + c; s_ne_bkt[p] = (unsigned short)tid;
-                }
-            }
-            __syncthreads();
+                scan_buckets();
+            } else long_histogram();
             if (in_lds) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1771,6 +1785,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     bool tile_done = false;
     unsigned e_next = 0, lo = 0;         // next non-empty bucket (index into s_ne_*) / its queue position
     unsigned win_lo = 0, win_hi = in_lds ? n : 0u;   // queue range resident in s_q (the whole queue when it fits)
+    unsigned n_refine = 0u, no_refine_at = 0xffffffffu;
     while (lo < n && (!tile_done || full_sort)) {
         unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
@@ -1789,6 +1804,44 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             e1 = e0 + (fit ? fit - 1u : 0u);
             hi = s_ne_end[e1];
             e_next = e1 + 1;
+        }
+        if (parted && !in_lds && e1 == e0 && hi - lo > (unsigned)SGS_BATCH && n_refine < 6u && lo != no_refine_at) {
+            // REFINEMENT: the front bucket of a long queue holds more than one batch.  One pass finds the key range of
+            // that bucket's records, a second one partitions the queue over it — 256 buckets across what was one —
+            // instead of sorting the whole bucket (the rank-sort / HBM-radix paths below, kept for the bucket whose keys
+            // are all equal).
+            const unsigned g = s_ne_bkt[e0];
+            unsigned kmn = 0xffffffffu, kmx = 0u;
+            for (unsigned i0 = 0; i0 < n; i0 += 1024) {
+                unsigned long long x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                    x[r] = i < n ? rec[beg + i] : ~0ull;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned key = (unsigned)(x[r] >> 32);
+                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && SGS_BUCKET_OF(key) == g) {
+                        kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
+                    }
+                }
+            }
+            kmn = wave_min(kmn); kmx = wave_max(kmx);
+            __syncthreads();                          // (s_kmn / s_kmx: everyone is past their last use)
+            if (lane == 0) { s_kmn[wave] = kmn; s_kmx[wave] = kmx; }
+            __syncthreads();
+            kmn = min(min(s_kmn[0], s_kmn[1]), min(s_kmn[2], s_kmn[3])); kmx = max(max(s_kmx[0], s_kmx[1]), max(s_kmx[2], s_kmx[3]));
+            if (kmx > kmn) {
+                const unsigned span = kmx - kmn;
+                kdone = kmn; klo = kmn; ksh = span < (unsigned)SGS_NB ? 0u : 24u - (unsigned)__clz((int)span);
+                pbase = lo;
+                long_histogram();
+                e_next = 0; win_lo = lo; win_hi = lo;     // nothing of the new partition is resident
+                ++n_refine;
+                continue;
+            }
+            no_refine_at = lo;                        // all keys equal: the sorting paths order them by index
         }
         const unsigned cnt = hi - lo;
         const unsigned* gv = nullptr;    // the group's slots in (depth, index) order
@@ -1813,8 +1866,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const unsigned bk = SGS_BUCKET_OF((unsigned)(x[r] >> 32));
-                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && bk >= b0 && bk <= b1)
+                    const unsigned key = (unsigned)(x[r] >> 32), bk = SGS_BUCKET_OF(key);
+                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && bk >= b0 && bk <= b1)
                         s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
                 }
             }
@@ -1844,7 +1897,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             unsigned bbeg = win_lo, blen = 0;
             if (parted && have) {
                 const unsigned bk = SGS_BUCKET_OF((unsigned)(mine >> 32));
-                bbeg = bk ? s_bcnt[bk - 1] : 0u;            // cursors after the scatter = bucket ends = next bucket's start
+                bbeg = bk ? s_bcnt[bk - 1] : pbase;         // cursors after the scatter = bucket ends = next bucket's start
                 blen = s_bcnt[bk] - bbeg;
             }
             if (parted && __ballot(blen * 2u > cnt || blen > SGS_RANK_BUCKET_MAX) == 0ull) {
@@ -1946,8 +1999,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 bool take = false;
                 if (i < n) {
                     x = rec[beg + i];
-                    const unsigned bk = SGS_BUCKET_OF((unsigned)(x >> 32));
-                    take = bk >= g0 && bk <= g1;
+                    const unsigned key = (unsigned)(x >> 32), bk = SGS_BUCKET_OF(key);
+                    take = key >= kdone && bk >= g0 && bk <= g1;
                 }
                 const unsigned long long m = __ballot(take);
                 unsigned base = 0;

@@ -370,14 +370,16 @@ def case_sort_classes(drv, sizes=(700, 2500, 6000, 9500)):
 
 
 def case_big_depth_bucket(drv, n_slab=3000):
-    """Thousands of splats inside one depth bucket of one tile (a wall facing the camera, 2 cm thick, in a queue that spans
-    1-12 m: the composite cuts 256 buckets from the queue's own depth range, ~3 cm each here): the bucket exceeds the LDS
-    group capacity and is sorted through HBM; includes a long run of equal depths."""
+    """Thousands of splats of one tile inside a 2-cm slab of a queue that spans 1-12 m (a wall facing the camera), four fifths
+    of them at EXACTLY the same depth.  The composite cuts 256 depth buckets from the queue's own range (~3 cm each here), finds
+    the slab's bucket longer than one batch and partitions the queue again over that bucket's key range (refinement) — which
+    separates everything but the equal depths: that bucket exceeds the LDS capacity, cannot be refined and is sorted through
+    HBM, its run of equal keys ordered by index."""
     rng = np.random.default_rng(8)
     n = n_slab + 500
     means = np.stack([rng.uniform(-0.1, 0.1, n), rng.uniform(-0.1, 0.1, n), rng.uniform(1.0, 12.0, n)], 1).astype(np.float32)
     means[:n_slab, 2] = rng.uniform(3.0, 3.02, n_slab).astype(np.float32)
-    means[100:170, 2] = 3.01                                   # 70 equal depths inside the slab
+    means[100:100 + (4 * n_slab) // 5, 2] = 3.01               # four fifths of the slab at one depth (the tight bin rects drop some per tile)
     perm = rng.permutation(n); means = means[perm]
     scales = np.full((n, 3), 2.0, np.float32) * means[:, 2:3]      # broad: alpha stays clear of the 1/255 cut-off
     quats = rng.normal(size=(n, 4)).astype(np.float32)
