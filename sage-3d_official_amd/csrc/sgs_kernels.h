@@ -1486,18 +1486,18 @@ __device__ __forceinline__ float sgs_edge_min(float e, float d0, float d1, float
     const float t = __builtin_amdgcn_fmed3f(k * e, d0, d1);
     return (P_ * e + B_ * t) * e + (R_ * t) * t;
 }
-__device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float k, float Cp, float qmax) {
-    // rx, ry: splat centre relative to the tile's first pixel; quadrant pixel centres span [0,7] / [8,15].
+__device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float A, float k, float Cp, float qmax, const float4* lrect) {
+    // rx, ry: splat centre relative to the tile's first pixel; lrect[q] = (x first, x last, y first, y last): the rectangle of
+    // quadrant q's pixel centres that are still LIVE, in tile pixels — the whole quadrant ([0,7] / [8,15]) at first.
     // The record holds the completed square A (dx + k dy)^2 + C' dy^2: B = 2 A k, C = A k^2 + C'.
     const float Ak = A * k, B = 2.0f * Ak, C = __builtin_fmaf(Ak, k, Cp);
     const float kv = -Ak * SGS_RCP(C), kh = -k;        // the edge minimisers -B e / 2C and -B e / 2A (an ulp off changes the minimum by O(ulp^2))
-    const float xs[4] = {0.0f - rx, 7.0f - rx, 8.0f - rx, 15.0f - rx};
-    const float ys[4] = {0.0f - ry, 7.0f - ry, 8.0f - ry, 15.0f - ry};
     const float aB = fabsf(B);
     unsigned bits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float xa = xs[2 * (q & 1)], xb = xs[2 * (q & 1) + 1], ya = ys[2 * (q >> 1)], yb = ys[2 * (q >> 1) + 1];
+        const float4 lr = lrect[q];
+        const float xa = lr.x - rx, xb = lr.y - rx, ya = lr.z - ry, yb = lr.w - ry;
         // (coordinates are relative to the centre: it lies between two edges when they straddle 0)
         const bool in_x = xa <= 0.0f && xb >= 0.0f, in_y = ya <= 0.0f && yb >= 0.0f;
         // q2 is convex with its minimum at the centre, so over a rectangle that does not hold the centre it is least on an
@@ -1517,9 +1517,28 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits(float rx, float ry, float 
     return bits;
 }
 // (the record holds the roots a = sqrt(A), a k, c = +-sqrt(|C'|); the test's own slack of ~130 ulps covers these conversions)
-__device__ __forceinline__ unsigned sgs_quadrant_hits_roots(float rx, float ry, float a, float ak, float c, float qmax) {
+__device__ __forceinline__ unsigned sgs_quadrant_hits_roots(float rx, float ry, float a, float ak, float c, float qmax, const float4* lrect) {
     const float k = a > 0.0f ? ak * SGS_RCP(a) : 0.0f;
-    return sgs_quadrant_hits(rx, ry, a * a, k, c * fabsf(c), qmax);
+    return sgs_quadrant_hits(rx, ry, a * a, k, c * fabsf(c), qmax, lrect);
+}
+// the axis-aligned extent (hx, hy around the centre) against the four live rectangles: the cheap test in front of the exact one
+__device__ __forceinline__ unsigned sgs_quadrant_extent(float rx, float ry, float hx, float hy, const float4* lrect) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 lr = lrect[q];
+        bits |= (rx - hx <= lr.y && rx + hx >= lr.x && ry - hy <= lr.w && ry + hy >= lr.z) ? 1u << q : 0u;     // (an empty rect: first > last)
+    }
+    return bits;
+}
+// the rectangle of a quadrant's live pixels from the wave's ballot (lane = 8 row + column): (first col, last col, first row, last row)
+__device__ __forceinline__ float4 sgs_live_rect(unsigned long long m, float x0, float y0) {
+    if (m == 0ull) return make_float4(1.0e30f, -1.0e30f, 1.0e30f, -1.0e30f);        // empty: nothing can reach it
+    unsigned long long c = m | (m >> 32); c |= c >> 16; c |= c >> 8;                // OR of the 8 rows -> live columns
+    const unsigned cols = (unsigned)c & 0xffu;
+    const int ca = __ffsll((long long)cols) - 1, cb = 31 - __clz((int)cols);
+    const int ra = (__ffsll((long long)m) - 1) >> 3, rb = (63 - __clzll((long long)m)) >> 3;
+    return make_float4(x0 + (float)ca, x0 + (float)cb, y0 + (float)ra, y0 + (float)rb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1552,6 +1571,9 @@ __device__ __forceinline__ unsigned sgs_quadrant_hits_roots(float rx, float ry, 
 #endif
 #ifndef SGS_QCAP
 #define SGS_QCAP 1024                 // queues up to this long live entirely in LDS; also the rank sort's hard cap
+#endif
+#ifndef SGS_PASS_R
+#define SGS_PASS_R 4                  // records per lane and trip of a pass over a long queue (loads in flight: the passes are latency-bound)
 #endif
 #define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
 
@@ -1607,6 +1629,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_hyper[2];                   // the batch holds a splat with an indefinite conic: exact trips (by parity)
+    // the rectangle of every quadrant's pixels that are still live (tile pixels; written by the quadrant's wave after each
+    // batch): a tile that keeps consuming batches for a few pixels that never saturate — a gap in the scene, a window —
+    // then stages and walks only the splats that can reach THOSE pixels, not the whole 8x8 quadrant
+    __shared__ float4 s_lrect[4];
     __shared__ unsigned s_used[4];
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
@@ -1673,6 +1699,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     unsigned klo = 0u, ksh = 0u, kdone = 0u, pbase = 0u;        // pbase: queue position of the current partition's first bucket
 #define SGS_BUCKET_OF(key) ((key) <= klo ? 0u : min((unsigned)(SGS_NB - 1), ((key) - klo) >> ksh))
     if (tid < 2) { s_any[tid] = 0; s_hyper[tid] = 0; }
+    {
+        const unsigned long long im = __ballot(inside);
+        if (lane == 0) s_lrect[wave] = sgs_live_rect(im, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));
+    }
     if (tid < 64) reinterpret_cast<unsigned*>(&s_ball[0][0][0])[tid] = 0u;   // both parities: 2 x 4 quadrants x 4 x 64 bits
     unsigned n_ne = 0;                                   // non-empty buckets (uniform)
     // exclusive scan of the SGS_NB bucket counts in s_bcnt (-> cursors, positions from pbase) + ordered compaction of the
@@ -1698,15 +1728,15 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     auto long_histogram = [&]() {
         s_bcnt[tid] = 0;
         __syncthreads();
-        for (unsigned i0 = 0; i0 < n; i0 += 1024) {                 // four loads in flight per lane
-            unsigned long long x[4];
+        for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {                 // SGS_PASS_R loads in flight per lane
+            unsigned long long x[SGS_PASS_R];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < SGS_PASS_R; ++r) {
                 const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
                 x[r] = i < n ? rec[beg + i] : ~0ull;
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < SGS_PASS_R; ++r) {
                 const unsigned key = (unsigned)(x[r] >> 32);
                 if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone) atomicAdd(&s_bcnt[SGS_BUCKET_OF(key)], 1u);
             }
@@ -1812,15 +1842,15 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             // are all equal).
             const unsigned g = s_ne_bkt[e0];
             unsigned kmn = 0xffffffffu, kmx = 0u;
-            for (unsigned i0 = 0; i0 < n; i0 += 1024) {
-                unsigned long long x[4];
+            for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {
+                unsigned long long x[SGS_PASS_R];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < SGS_PASS_R; ++r) {
                     const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
                     x[r] = i < n ? rec[beg + i] : ~0ull;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < SGS_PASS_R; ++r) {
                     const unsigned key = (unsigned)(x[r] >> 32);
                     if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && SGS_BUCKET_OF(key) == g) {
                         kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
@@ -1857,15 +1887,15 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             const unsigned ew = e1 + wfit;
             const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[ew];
             win_lo = lo; win_hi = s_ne_end[ew];
-            for (unsigned i0 = 0; i0 < n; i0 += 1024) {
-                unsigned long long x[4];
+            for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {
+                unsigned long long x[SGS_PASS_R];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < SGS_PASS_R; ++r) {
                     const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
                     x[r] = i < n ? rec[beg + i] : ~0ull;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+                for (int r = 0; r < SGS_PASS_R; ++r) {
                     const unsigned key = (unsigned)(x[r] >> 32), bk = SGS_BUCKET_OF(key);
                     if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && bk >= b0 && bk <= b1)
                         s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
@@ -1931,11 +1961,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;      // centre relative to the tile
                 SGS_STAGE(rank, nA, nB, nC, rx, ry)
                 if (qmax > 0.0f) {
-                    const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
-                    const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
-                    unsigned qb4 = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
-                                   ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax);
+                    unsigned qb4 = sgs_quadrant_extent(rx, ry, hx, hy, s_lrect);       // the live pixels of each quadrant
+                    if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax, s_lrect);
                     SGS_PROF_STAGED(qb4)
                     unsigned* bw = reinterpret_cast<unsigned*>(&s_ball[par][0][0]);      // [q][rank/64] as 2 x 32-bit
                     const unsigned word = rank >> 5, bit = 1u << (rank & 31u);
@@ -1955,8 +1982,12 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             const unsigned base = lo, m = cnt;
             const bool hyper = s_hyper[par] != 0u;           // (uniform)
             SGS_BLEND_WAVE_LIST()
-            const bool still_live = __ballot(Tm > 0.0f) != 0ull;
-            if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
+            const unsigned long long live_m = __ballot(Tm > 0.0f);
+            const bool still_live = live_m != 0ull;
+            if (lane == 0) {
+                if (still_live) atomicOr(&s_any[par], 1u);
+                s_lrect[wave] = sgs_live_rect(live_m, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));   // (read after the barrier)
+            }
             __syncthreads();
             tile_done = s_any[par] == 0u;
             if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;    // consumed: ready for the batch after next
@@ -2044,11 +2075,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                     const float rx = nA.x - tile_fx, ry = nA.y - tile_fy;          // centre relative to the tile
                     SGS_STAGE((unsigned)tid, nA, nB, nC, rx, ry)
                     if (qmax > 0.0f) {
-                        const bool x_lo = rx - hx <= 7.0f && rx + hx >= 0.0f, x_hi = rx - hx <= 15.0f && rx + hx >= 8.0f;
-                        const bool y_lo = ry - hy <= 7.0f && ry + hy >= 0.0f, y_hi = ry - hy <= 15.0f && ry + hy >= 8.0f;
-                        qbits = (unsigned)(x_lo && y_lo) | ((unsigned)(x_hi && y_lo) << 1) |
-                                ((unsigned)(x_lo && y_hi) << 2) | ((unsigned)(x_hi && y_hi) << 3);
-                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax);
+                        qbits = sgs_quadrant_extent(rx, ry, hx, hy, s_lrect);
+                        if (qbits && !loose_cull) qbits &= sgs_quadrant_hits_roots(rx, ry, nA.z, nA.w, nB.x, qmax, s_lrect);
                     }
                 }
 #pragma unroll
@@ -2060,8 +2088,12 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 if (tid == 0) { s_any[par ^ 1u] = 0; s_hyper[par ^ 1u] = 0; }   // the other parity's flags: all their readers are past
                 const bool hyper = s_hyper[par] != 0u;       // (uniform)
                 SGS_BLEND_WAVE_SCAN()
-                const bool still_live = __ballot(Tm > 0.0f) != 0ull;
-                if (lane == 0 && still_live) atomicOr(&s_any[par], 1u);
+                const unsigned long long live_m = __ballot(Tm > 0.0f);
+                const bool still_live = live_m != 0ull;
+                if (lane == 0) {
+                    if (still_live) atomicOr(&s_any[par], 1u);
+                    s_lrect[wave] = sgs_live_rect(live_m, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));
+                }
                 __syncthreads();                 // batch consumed by every wave, liveness posted
                 tile_done = s_any[par] == 0u;    // uniform
                 if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // (the single-batch path ORs into it)

@@ -12,7 +12,7 @@ cams = scenes.room_cameras(sc, W, H, 4, 64, seed=2)
 r = Renderer("cuda:0", record_capacity=96 << 20)
 gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
 out = {}
-for ci in (5, 20, 70, 140, 200):
+for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')]:
     r.render(cams[ci], gs, stats=True); d_f = r.last_stats["d_fetched"]      # (D_f is counted on request only)
     for _ in range(3):
         r.render(cams[ci], gs, timing=True)                                   # the kernels a sweep runs
