@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             hi = s_ne_end[e1];
             e_next = e1 + 1;
         }
-        if (parted && !in_lds && e1 == e0 && hi - lo > (unsigned)SGS_BATCH && n_refine < 6u && lo != no_refine_at) {
+        if (parted && !in_lds && e1 == e0 && hi - lo > (unsigned)SGS_BATCH && n_refine < 255u && lo != no_refine_at) {
             // REFINEMENT: the front bucket of a long queue holds more than one batch.  One pass finds the key range of
             // that bucket's records, a second one partitions the queue over it — 256 buckets across what was one —
             // instead of sorting the whole bucket (the rank-sort / HBM-radix paths below, kept for the bucket whose keys

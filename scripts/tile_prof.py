@@ -26,19 +26,19 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
           f"{100*emp.sum()/max(1,ev.sum()):.1f} %; lanes inside the cut-off {100*val.sum()/max(1,64*ev.sum()):.1f} %, of them on live pixels {100*use.sum()/max(1,val.sum()):.1f} %")
     print(f"     staged splats (single-batch groups): {stg.sum()/1e6:.2f}M, reaching at least one quadrant: {100*hit.sum()/max(1,stg.sum()):.1f} %  (D = {st['d_total']/1e6:.2f}M records, D_f = {st['d_fetched']/1e6:.2f}M)")
     # occupancy over the kernel's span: how many tiles (workgroups) are in flight
-    ev = np.concatenate([np.stack([rt0, np.ones_like(rt0)], 1), np.stack([rt1, -np.ones_like(rt0)], 1)])
-    ev = ev[np.argsort(ev[:, 0])]
-    act = np.cumsum(ev[:, 1]); dt = np.diff(ev[:, 0], append=ev[-1, 0]); span = ev[-1, 0] - ev[0, 0]
+    evs = np.concatenate([np.stack([rt0, np.ones_like(rt0)], 1), np.stack([rt1, -np.ones_like(rt0)], 1)])
+    evs = evs[np.argsort(evs[:, 0])]
+    act = np.cumsum(evs[:, 1]); dt = np.diff(evs[:, 0], append=evs[-1, 0]); span = evs[-1, 0] - evs[0, 0]
     peak = act.max()
     print(f"     workgroups in flight: peak {int(peak)}, time-average {float((act * dt).sum() / span):.0f}; share of the span with < 50 % of the peak: "
           f"{100 * dt[act < 0.5 * peak].sum() / span:.1f} %, < 90 %: {100 * dt[act < 0.9 * peak].sum() / span:.1f} %  (span {span / 100:.0f} us)")
-    q = np.quantile(rt1 - ev[0, 0], [0.5, 0.9, 0.99, 1.0]) / 100
-    print(f"     tiles finished by: 50 % {q[0]:.0f} us, 90 % {q[1]:.0f} us, 99 % {q[2]:.0f} us, all {q[3]:.0f} us; tiles started after 50 % of the span: {100 * (rt0 - ev[0, 0] > 0.5 * span).mean():.1f} %")
+    q = np.quantile(rt1 - evs[0, 0], [0.5, 0.9, 0.99, 1.0]) / 100
+    print(f"     tiles finished by: 50 % {q[0]:.0f} us, 90 % {q[1]:.0f} us, 99 % {q[2]:.0f} us, all {q[3]:.0f} us; tiles started after 50 % of the span: {100 * (rt0 - evs[0, 0] > 0.5 * span).mean():.1f} %")
     print(f"     single-batch path, cycle sums: rank (records resident -> ranked) {prank.sum()/1e6:.0f}M, barrier 1 {pbar1.sum()/1e6:.0f}M, stage (gather wait + extents + quadrant test) {pstage.sum()/1e6:.0f}M, barrier 2 {sort.sum()/1e6:.0f}M; partition {part.sum()/1e6:.0f}M; blend {blend.sum()/1e6:.0f}M; total {tot.sum()/1e6:.0f}M")
     print(f"     start of a tile, mean cycles: entry -> job arrived {pjob.mean():.0f}, -> records arrived {prec.mean():.0f}, -> partitioned {part.mean():.0f}  (p90: {np.quantile(pjob,0.9):.0f}, {np.quantile(prec,0.9):.0f}, {np.quantile(part,0.9):.0f})")
     order = np.argsort(-tot)[:5]
     for o in order:
-        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])}")
+        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])}")
     # by size class
     for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
         m = (n > lo) & (n <= hi)
