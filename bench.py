@@ -327,7 +327,8 @@ def main():
     if world == 1 and K < 64 and pipelined:
         K0, bf0 = K, batch_frames
         K, batch_frames = 100, None                       # (run_cameras reads both: the per-frame path)
-        dt100, _ = measure(run_cameras, min(W, 10), 100, False)
+        measure(run_cameras, 12, 12, False)               # (the per-frame path's own lanes and output ring, untimed)
+        dt100, _ = measure(run_cameras, max(W, 12), 100, False)
         K, batch_frames = K0, bf0
         value_100 = {"value": 100 / dt100, "unit": "frames/s", "steps": 100, "timed_region_ms": 1e3 * dt100,
                      "ms_per_step": 10.0 * dt100, "what": "the same sweep over 100 steps, frames pipelined on the library's lanes"}
@@ -400,7 +401,7 @@ def main():
             # K4 sort = D x 8 B x 2, K5 composite = 40 D_f + 12 P.  D = records actually queued.
             b_fused, b_k5, b_tight = 16 * D + 40 * Df + 12 * P, 40 * Df + 12 * P, stages["render"]["alg_bytes"]
             gbps = lambda b: b / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
-            traffic = valu_busy = lds_conf = valu = None
+            traffic = valu_busy = lds_conf = valu = lane_use = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tpath):
                 try:         # PMC passes (scripts/gpu_round_profile.sh) are only quoted for the pose set they were taken on
@@ -409,6 +410,7 @@ def main():
                         traffic = tj.get(dom)
                         valu_busy = tj.get("_valu_busy", {}).get(dom)
                         lds_conf = tj.get("_lds_bank_conflict_share", {}).get(dom)
+                        lane_use = tj.get("_lane_use")
                         vi = tj.get("_valu_insts", {}).get(dom)
                         if vi and ms_dom > 0:
                             valu = {"inst_per_launch": vi, "lane_ops_per_s": vi * 64.0 / (ms_dom * 1e-3),
@@ -428,13 +430,17 @@ def main():
                                  "builder_tight": {"bytes": b_tight, "formula": "8 D + 36 D_f + 12 P (the sort never writes records back)",
                                                    "frac": gbps(b_tight) / HBM_PEAK_GBPS}} if dom == "render" else None),
                 "traffic": traffic, "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf, "valu": valu,
+                "useful_lane_frac": (lane_use or {}).get("useful_lane_frac"), "lane_use": lane_use,
+                "stage_kernels": {"preprocess": "k_chunk_cull, k_preprocess", "count": "binning level 1 (splats -> super-tile queues): k_bin_count, k_stile_scan, k_bin_emit",
+                                  "emit": "binning level 2 (super-tile queues -> tile queues): k_expand<count>, k_tile_scan, k_expand<emit>",
+                                  "render": "k_tile_render (per-tile depth partition + lazy sort + composite)"},
                 "pmc_pose_set": pose_set if traffic is not None else None,
                 "stages": stages,
                 "frame_ms_alone": pct(frame_ms),
                 "gpu_ms_per_frame_in_flight": avg["ms_total"] if avg is not None else None,
                 "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
                 "events_on_every_nth_frame": max(1, args.event_stride),
-                "note": "the composite is VALU-issue-bound, not HBM-bound (valu.frac = share of the fp32 vector peak); ms_alone = a "
+                "note": "the composite is bound by VALU issue slots (one wave instruction per 4 cycles and SIMD; valu_busy), not by HBM; ms_alone = a "
                         "launch with nothing else running; ms_in_flight = HIP-event span inside the timed region, where frames "
                         "overlap (not a kernel duration: it includes waiting for the lane's previous kernel)"}
         if latency:

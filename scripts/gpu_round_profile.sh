@@ -4,7 +4,7 @@
 #   (frames in flight, and one frame at a time), PMC passes (counters in their own runs, --kernel-trace only) over the SAME
 #   pose sets, traffic.json keyed by pose set (bench.py quotes PMC figures only for the pose set they were taken on),
 #   the 4K sweep of BASELINE config 5.
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
@@ -12,10 +12,10 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json
 timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err; tail -c 300 $OUT/bench_k20.json
-echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
+echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
 trace() { # name args...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline "$@" > $OUT/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-lowres "$@" > $OUT/$name.log 2>&1
   local db=$(find $OUT/raw_$name -name "*.db" | head -1)
   python $ROOT/scripts/rocpd_stats.py $db > $OUT/kernel_stats_$name.csv
   python $ROOT/scripts/rocpd_timeline.py $db ${WIN:-0.04 0.34} > $OUT/timeline_$name.txt 2>/dev/null
@@ -29,7 +29,7 @@ pmc() { # set name flags... -- counters...
   local set=$1 name=$2; shift 2
   local flags=()
   while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-events --no-pipeline "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-pipeline "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
   mkdir -p $OUT/pmc_$set
   find $OUT/pmc_${set}_$name -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$set/$name.csv \;
   rm -rf $OUT/pmc_${set}_$name
@@ -43,6 +43,9 @@ passes() { # set skip flags...
   pmc $set grbm "$@" -- GRBM_GUI_ACTIVE
   python $ROOT/scripts/pmc_summary.py $OUT/pmc_$set $skip > $OUT/pmc_summary_$set.json
 }
+echo "== lane use of the composite (profiling build, the driver's first poses)"
+(cd $ROOT && make -s -C sage-3d_official_amd lib/libsage_gs_prof.so >/dev/null 2>&1; POSES=$(python -c "print(','.join(str((i*77)%256) for i in range(5,25)))") timeout 300 python scripts/tile_prof.py > $OUT/tile_prof_k20.txt 2>/dev/null; grep TOTAL $OUT/tile_prof_k20.txt | cut -c1-300)
+echo "== trained-like scene, bench line"; timeout 600 python $ROOT/bench.py --scene-kind trained --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trained_k20.json 2> $OUT/bench_trained.err; tail -c 200 $OUT/bench_trained_k20.json
 echo "== PMC passes (default pose set)"; passes default 10
 echo "== PMC passes (driver's pose set)"; passes k20 5 --steps 20 --warmup 5
 python - <<PY
@@ -53,7 +56,9 @@ for set_, log in (("default", "pmc_default_sq1.log"), ("k20", "pmc_k20_sq1.log")
     # the pose set the passes ran on, as bench.py itself names it (the JSON line of the profiled run)
     line = [l for l in open("$OUT/" + log) if l.startswith("{")][-1]
     tag = json.loads(line)["config"]["pose_set"]
-    stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess"], "count": ["sgs::k_bin_count", "sgs::k_tile_scan"], "emit": ["sgs::k_bin_emit"],
+    # (two-level binning: stage "count" = level 1, splats -> super-tile queues; stage "emit" = level 2, super-tile queues -> tile queues)
+    stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess"], "count": ["sgs::k_bin_count", "sgs::k_stile_scan", "sgs::k_bin_emit"],
+             "emit": ["sgs::k_expand<false>", "sgs::k_tile_scan", "sgs::k_expand<true>"],
              # the instantiation a sweep runs (no aux output, no D_f bookkeeping), however the profiler spells it
              "render": [k for k in d if k.startswith("sgs::k_tile_render<false") and not k.rstrip(">").endswith("true")]}
     t = {}
@@ -65,6 +70,12 @@ for set_, log in (("default", "pmc_default_sq1.log"), ("k20", "pmc_k20_sq1.log")
     t["_lds_bank_conflict_share"] = {s: max(d[k]["SQ_LDS_BANK_CONFLICT"] / max(1.0, d[k]["SQ_LDS_IDX_ACTIVE"]) for k in ks if k in d) for s, ks in stage.items()}
     t["_valu_insts"] = {s: sum(d[k]["SQ_INSTS_VALU"] for k in ks if k in d) for s, ks in stage.items()}   # wave instructions per launch
     t["_launches_averaged"] = {k: d[k].get("_launches") for ks in stage.values() for k in ks if k in d}
+    if set_ == "k20":
+        try:
+            tl = [l for l in open("$OUT/tile_prof_k20.txt") if l.startswith("TOTAL ")][-1]
+            t["_lane_use"] = json.loads(tl[6:])
+        except Exception:
+            pass
     out[tag] = t
 out["_note"] = ("per pose set (bench.py config.pose_set): HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from rocprofv3 --pmc (separate passes, "
                 "--kernel-trace only), FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM and this repo's own calibration (profiles/r01_hbm_calib_*.csv: "

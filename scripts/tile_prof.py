@@ -12,6 +12,7 @@ cams = scenes.room_cameras(sc, W, H, 4, 64, seed=2)
 r = Renderer("cuda:0", record_capacity=96 << 20)
 gs = r.upload(scenes.to_gaussians(sc, "cuda:0"))
 out = {}
+TOT = {'ev': 0.0, 'val': 0.0, 'use': 0.0, 'stg': 0.0, 'hit': 0.0}
 for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')]:
     r.render(cams[ci], gs, stats=True); d_f = r.last_stats["d_fetched"]      # (D_f is counted on request only)
     for _ in range(3):
@@ -20,6 +21,7 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     p = r.debug_buffer(100, np.uint64).reshape(-1, 24).astype(np.float64)
     n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, pjob, prec = p.T[:21]
     clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
+    for k_, v_ in (('ev', ev), ('val', val), ('use', use), ('stg', stg), ('hit', hit)): TOT[k_] += float(v_.sum())
     print(f"cam {ci}: render {st['ms']['render']*1e3:.0f} us  D={st['d_total']} D_f={st['d_fetched']} | tile-cycles sum: part {part.sum()/1e6:.1f}M sort {sort.sum()/1e6:.1f}M blend {blend.sum()/1e6:.1f}M total {tot.sum()/1e6:.1f}M | "
           f"groups/tile {ng.mean():.2f} batches/tile {nb.mean():.2f} | max tile total {tot.max()/1e3:.0f}k cyc (n={int(n[tot.argmax()])}) | span {(t0+tot).max()-t0.min():.0f} cyc")
     print(f"     blend evaluations (wave x splat): {ev.sum()/1e6:.2f}M = {ev.sum()/max(1,st['d_fetched']):.2f} per consumed record; no pixel inside the cut-off: "
@@ -44,3 +46,8 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
         m = (n > lo) & (n <= hi)
         if m.any():
             print(f"     n in ({lo},{hi}]: {m.sum()} tiles, mean cyc job {pjob[m].mean():.0f} rec {prec[m].mean():.0f} part {part[m].mean():.0f} rank {prank[m].mean():.0f} stage {pstage[m].mean():.0f} sort {sort[m].mean():.0f} blend {blend[m].mean():.0f} total {tot[m].mean():.0f}")
+
+# over all the poses: lanes of the blend's (wave, splat) evaluations inside the cut-off, and of those on a live pixel
+print("TOTAL " + json.dumps({"poses": os.environ.get('POSES', '5,20,70,140,200'), "evaluations": TOT['ev'],
+                             "lanes_inside_cutoff": TOT['val'] / max(1.0, 64 * TOT['ev']), "of_those_on_live_pixels": TOT['use'] / max(1.0, TOT['val']),
+                             "useful_lane_frac": TOT['use'] / max(1.0, 64 * TOT['ev']), "staged_reaching_a_quadrant": TOT['hit'] / max(1.0, TOT['stg'])}))
