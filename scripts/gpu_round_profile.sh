@@ -60,7 +60,7 @@ for set_, log in (("default", "pmc_default_sq1.log"), ("k20", "pmc_k20_sq1.log")
     stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess"], "count": ["sgs::k_bin_count", "sgs::k_stile_scan", "sgs::k_bin_emit"],
              "emit": ["sgs::k_expand<false>", "sgs::k_tile_scan", "sgs::k_expand<true>"],
              # the instantiation a sweep runs (no aux output, no D_f bookkeeping), however the profiler spells it
-             "render": [k for k in d if k.startswith("sgs::k_tile_render<false") and not k.rstrip(">").endswith("true")]}
+             "render": ["sgs::k_tile_render<false, false, false>"]}
     t = {}
     for s, ks in stage.items():
         t[s] = sum((2.0 * d[k]["FETCH_SIZE"] + d[k]["WRITE_SIZE"]) * 1024.0 for k in ks if k in d)
