@@ -176,12 +176,12 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
 int ensure_tiles(sgs_ctx* ctx, Lane& L, int tiles) {
     if (tiles <= L.tile_cap) return SGS_OK;
     int rc;
-    if ((rc = grow(ctx, L.tile_count, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.tile_offset, (size_t)tiles * SGS_XCDS + 1)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.tile_count, (size_t)tiles + 1)) != SGS_OK) return rc;          // level 2: one counter per tile
+    if ((rc = grow(ctx, L.tile_offset, (size_t)tiles + 1)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_prof, (size_t)tiles * SGS_PROF_WORDS)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.tile_order, (size_t)tiles)) != SGS_OK) return rc;
     // k_expand<true> zeroes every count k_tile_scan has consumed, so one memset at allocation suffices
-    SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles * SGS_XCDS + 1) * sizeof(unsigned)));
+    SGS_HIP(ctx, hipMemset(L.tile_count, 0, ((size_t)tiles + 1) * sizeof(unsigned)));
     // (hipMemset of device memory runs on the NULL stream and may return before it has run; the frames use non-blocking
     //  streams that do not order with it — an unfinished clear would land in the middle of a frame's counting)
     SGS_HIP(ctx, hipStreamSynchronize(nullptr));
@@ -201,7 +201,7 @@ int ensure_records(sgs_ctx* ctx, Lane& L) {
     // segment per super-tile
     const int64_t jcap = cap / 2 / SGS_SEG + SGS_WT + 1;
     if ((rc = grow(ctx, L.jobs, (size_t)jcap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.job_base, (size_t)jcap * (SGS_ST * SGS_ST + 1))) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.job_base, (size_t)jcap * (SGS_ST * SGS_ST))) != SGS_OK) return rc;
     L.job_cap = jcap;
     L.rec_cap = cap;
     return SGS_OK;
@@ -932,15 +932,15 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
     if (n <= 0 || !host_dst) return have;
     if (src) SGS_HIP(ctx, hipMemcpy(host_dst, src, (size_t)n, hipMemcpyDeviceToHost));
     if (what == SGS_BUF_TILE_OFFSETS) {
-        const size_t cnt = (size_t)ctx->last_T * SGS_XCDS + 1;
+        const size_t cnt = (size_t)ctx->last_T + 1;
         unsigned* tmp = (unsigned*)malloc(cnt * 4);
         if (!tmp) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
         hipError_t e = hipMemcpy(tmp, L.tile_offset, cnt * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) { free(tmp); SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e)); }
         // k_tile_scan writes the offsets of the band it rendered (and the band's end); outside it they are constant
-        const unsigned total = tmp[(size_t)ctx->last_t_hi * SGS_XCDS];
+        const unsigned total = tmp[(size_t)ctx->last_t_hi];
         for (int64_t i = 0; (i + 1) * 4 <= n; ++i)
-            ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i * SGS_XCDS];
+            ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i];
         free(tmp);
     }
     if (what == SGS_BUF_CHUNK_SKIPPED) {

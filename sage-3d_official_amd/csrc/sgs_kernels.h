@@ -269,7 +269,11 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                                                  FrameStatus* __restrict__ st, long long chunk, int lane) {
     const long long pos = chunk * SGS_WAVE + lane;      // position in the (Z-ordered) scene layout
 
+    // all three geometry rows of the chunk are requested at once (1-KiB rows; a live chunk nearly always has lanes that need
+    // the second and third): loading each one only behind the test that needs it made three dependent trips to HBM
     const float4 g0 = geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane];
+    const float4 g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
+    const float4 g2 = geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane];
     const double mx = g0.x, my = g0.y, mz = g0.z;
     const double tx = (double)P.view[0] * mx + (double)P.view[1] * my + (double)P.view[2] * mz + (double)P.view[3];
     const double ty = (double)P.view[4] * mx + (double)P.view[5] * my + (double)P.view[6] * mz + (double)P.view[7];
@@ -289,9 +293,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     // padded for fp32 rounding.  A Gaussian whose centre +- that bound misses the image band has an empty tile rect
     // in the exact computation too, so dropping it here changes nothing (the view matrix is rigid by contract).
     bool maybe = front;
-    float4 g1 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (front) {
-        g1 = geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane];
         const float smax = fmaxf(g1.x, fmaxf(g1.y, g1.z));
         const float inv = 1.0f / (float)tz;
         const float lx = P.clamp * (0.5f * (float)P.width / P.fx), ly = P.clamp * (0.5f * (float)P.height / P.fy);
@@ -305,7 +307,6 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         maybe = !(out_x || out_y);                   // (NaN anywhere keeps the Gaussian)
     }
     if (maybe) {
-        const float4 g2 = geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane];
         slot = __float_as_uint(g2.w);
         // S2: Sigma = R S S^T R^T
         const double qw0 = g1.w, qx0 = g2.x, qy0 = g2.y, qz0 = g2.z;
@@ -498,17 +499,16 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// S4: exclusive scan of the tile counts, D, the longest queue and the render order.  A tile has SGS_XCDS
-// sub-counters — one per XCD the binning workgroups run on — so that the records an XCD writes into a queue are
-// contiguous and its L2 can write-combine them; the queue of tile t is [offset[8t], offset[8t+8]).
+// S4: exclusive scan of the tile counts (ONE counter per tile: level 2 of the binning needs no per-XCD sub-queues, see
+// k_expand), D, the longest queue and the render order; the queue of tile t is [offset[t], offset[t+1]).
 //
 // One workgroup per 1024 tiles of the band, and NO communication between them: every workgroup reads ALL the band's
-// counters (256 KB at 1080p, L2-resident, every load coalesced and in flight together) and derives what it needs about the
+// counters (32 KB at 1080p, L2-resident, every load coalesced and in flight together) and derives what it needs about the
 // other workgroups' tiles itself — the records queued before its own tiles, and the tiles per length class before them
 // and overall — then writes the offsets and render-order entries of its own 1024 tiles (one per thread).  A single
-// workgroup doing all of it was bound by ONE CU's memory pipeline (24 us at 1080p, 90 us at 3840x2160; batching its
-// loads or aggregating its LDS atomics changed nothing); reading 8x what is needed on 8 CUs is the cheaper trade.
-// The counters are cleared by k_bin_emit (the next launch), not here: other workgroups may still be reading them.
+// workgroup doing all of it was bound by ONE CU's memory and LDS pipelines (24 us at 1080p, 90 us at 3840x2160 as a
+// kernel of its own in r01; 30 us as the tail of k_expand<false> in r03w: profiles/r03w_fused_scans_experiment.txt).
+// The counters are cleared by k_expand<true> (the next launch), not here: other workgroups may still be reading them.
 #define SGS_SCAN_THREADS 1024
 #define SGS_SCAN_SLABS 8
 // Per (wave, class) ONE LDS atomic instead of 64 serialised ones on the same address: neighbouring tiles have queues
@@ -549,22 +549,18 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
     for (int i = tid; i < SGS_SCAN_THREADS + 2; i += SGS_SCAN_THREADS) s_row[i] = 0;
     __syncthreads();
     unsigned sum_all = 0, sum_before = 0, mx = 0;
-    uint4 m0 = {0u, 0u, 0u, 0u}, m1 = m0;            // my tile's eight sub-counts
+    unsigned mine = 0;                                // my tile's count
     for (int t0 = t_lo, slab0 = 0; t0 < t_hi; t0 += SGS_SCAN_THREADS * SGS_SCAN_SLABS, slab0 += SGS_SCAN_SLABS) {
-        uint4 c0[SGS_SCAN_SLABS], c1[SGS_SCAN_SLABS];
+        unsigned cc[SGS_SCAN_SLABS];
 #pragma unroll
         for (int j = 0; j < SGS_SCAN_SLABS; ++j) {
             const int t = t0 + j * SGS_SCAN_THREADS + tid;
-            c0[j] = uint4{0u, 0u, 0u, 0u}; c1[j] = c0[j];
-            if (t < t_hi) {
-                const uint4* cp = reinterpret_cast<const uint4*>(tile_count + (size_t)t * SGS_XCDS);
-                c0[j] = cp[0]; c1[j] = cp[1];
-            }
+            cc[j] = t < t_hi ? tile_count[t] : 0u;
         }
 #pragma unroll
         for (int j = 0; j < SGS_SCAN_SLABS; ++j) {
             const int t = t0 + j * SGS_SCAN_THREADS + tid;
-            const unsigned c = c0[j].x + c0[j].y + c0[j].z + c0[j].w + c1[j].x + c1[j].y + c1[j].z + c1[j].w;
+            const unsigned c = cc[j];
             const bool before = slab0 + j < g;                         // slab k = the 1024 tiles of workgroup k (uniform)
             sum_all += c; sum_before += before ? c : 0u;
             mx = c > mx ? c : mx;
@@ -578,13 +574,13 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
                 if (lane == leader) { atomicAdd(&s_all[lc], (unsigned)__popcll(m)); if (before) atomicAdd(&s_before[lc], (unsigned)__popcll(m)); }
                 todo &= ~m;
             }
-            if (slab0 + j == g) { m0 = c0[j]; m1 = c1[j]; }
+            if (slab0 + j == g) mine = c;
         }
     }
     // records before my tiles, in the band; longest queue
     const unsigned wa = wave_sum(sum_all), wb = wave_sum(sum_before), wm = wave_max(mx);
     const int t = t_lo + g * SGS_SCAN_THREADS + tid;                   // my tile
-    const unsigned c = m0.x + m0.y + m0.z + m0.w + m1.x + m1.y + m1.z + m1.w;
+    const unsigned c = mine;
     const unsigned incl = wave_incl_scan(c, lane);
     if (lane == 63) s_wi[wave] = incl;
     if (lane == 0) { s_wa[wave] = wa; s_wb[wave] = wb; s_wm[wave] = wm; }
@@ -603,16 +599,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
         s_cur[tid] = first + s_before[tid];
     }
     __syncthreads();
-    if (t < t_hi) {
-        unsigned run = base + wbase + incl - c;
-        const unsigned begin = run;
-        uint4 o0, o1;
-        o0.x = run; run += m0.x; o0.y = run; run += m0.y; o0.z = run; run += m0.z; o0.w = run; run += m0.w;
-        o1.x = run; run += m1.x; o1.y = run; run += m1.y; o1.z = run; run += m1.z; o1.w = run;
-        uint4* op = reinterpret_cast<uint4*>(tile_offset + (size_t)t * SGS_XCDS);
-        op[0] = o0; op[1] = o1;
-        (void)begin;
-    }
+    if (t < t_hi) tile_offset[t] = base + wbase + incl - c;
     {
         const unsigned pos = class_take(s_cur, queue_class(c), t < t_hi, lane);
         // (tile, first record, queue length): all the composite's workgroup needs before it can fetch its queue
@@ -635,7 +622,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
         }
     }
     if (g == 0 && tid == 0) {
-        tile_offset[(size_t)t_hi * SGS_XCDS] = total;      // end of the band's last queue (k_bin_emit never reads past it)
+        tile_offset[t_hi] = total;                         // end of the band's last queue
         st->d_total = total;
         st->max_tile_len = tmax;
         if ((unsigned long long)total > (unsigned long long)P.rec_capacity) st->overflow = 1u;      // (k_stile_scan may have set it already)
@@ -1040,8 +1027,10 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
 // ---- level 2: super-tile queues -> tile queues -----------------------------------------------------------------------------
 // Job j = SGS_SEG consecutive records of one super-tile's queue, four per thread.  Every record covers some of the
 // super-tile's 16 tiles (its tile rect, clipped); for tile t the covering lanes of a wave find each other with ONE ballot:
-//   EMIT == false: the ballots' popcounts are summed per tile over the workgroup and added to the tile's sub-counter with
-//                  one global atomic per tile — its return value is the job's base in that tile's sub-queue (job_base);
+//   EMIT == false: the ballots' popcounts are summed per tile over the workgroup and added to the tile's counter with one
+//                  global atomic per tile — its return value is the job's base in that tile's queue (job_base).  (ONE counter
+//                  per tile: unlike level 1, whose records arrive one by one from everywhere and are kept contiguous per XCD
+//                  by sub-queues, a job writes each tile's records as one run whichever XCD it is on);
 //   EMIT == true : the same ballots give every covering lane its rank: the records of (wave, slot, tile) are stored as one
 //                  contiguous run at  tile offset + job base + (what the job's earlier waves and slots put into the tile).
 // No per-record atomics, and the 8-byte records reach HBM in runs instead of one by one.
@@ -1058,19 +1047,23 @@ __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) 
     __shared__ unsigned s_base[NT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (EMIT) {   // k_tile_scan has consumed the band's tile counters: zero again for the next frame, also when this frame overflowed
-        uint4* z = reinterpret_cast<uint4*>(tile_count + (size_t)P.row_begin * P.gx * SGS_XCDS);
-        const unsigned nz = (unsigned)((P.row_end - P.row_begin) * P.gx) * (SGS_XCDS / 4);
-        for (unsigned i = blockIdx.x * SGS_EXP_THREADS + tid; i < nz; i += gridDim.x * SGS_EXP_THREADS) z[i] = uint4{0u, 0u, 0u, 0u};
+        unsigned* z = tile_count + (size_t)P.row_begin * P.gx;
+        const unsigned nz = (unsigned)((P.row_end - P.row_begin) * P.gx);
+        for (unsigned i = blockIdx.x * SGS_EXP_THREADS + tid; i < nz; i += gridDim.x * SGS_EXP_THREADS) z[i] = 0u;
     }
     if (st->overflow) return;
     const SuperGrid SG = super_grid(P);
     const unsigned n_jobs = st->n_jobs;
-    const unsigned my_xcd = xcc_id();
     for (unsigned job = blockIdx.x; job < n_jobs; job += gridDim.x) {
         const uint4 J = jobs[job];
         const unsigned scell = J.x, qb = J.y, cnt = J.z;
         const unsigned tx0 = (scell % (unsigned)SG.gxs) << SGS_ST_SHIFT;
         const unsigned ty0 = (scell / (unsigned)SG.gxs + (unsigned)SG.sr0) << SGS_ST_SHIFT;     // the super-tile's first tile (owned rows)
+        // slot r of this wave holds the records r * 256 + wave * 64 + (0..63) of the job: a short job (every super-tile's
+        // last one) leaves whole slots empty, and their ballots are skipped (wave-uniform)
+        bool slot_on[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) slot_on[r] = (unsigned)(r * SGS_EXP_THREADS + wave * SGS_WAVE) < cnt;
         // which of the 16 tiles each of my records covers (bit ly * 4 + lx)
         unsigned cover[R]; unsigned long long rv[R];
 #pragma unroll
@@ -1097,7 +1090,7 @@ __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) 
         for (int t = 0; t < NT; ++t) {
             unsigned c = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) c += (unsigned)__popcll(__ballot((cover[r] >> t) & 1u));
+            for (int r = 0; r < R; ++r) if (slot_on[r]) c += (unsigned)__popcll(__ballot((cover[r] >> t) & 1u));
             mine = lane == t ? c : mine;
         }
         if (lane < NT) s_wc[wave][lane] = mine;
@@ -1109,12 +1102,9 @@ __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) 
             for (int w = 0; w < NW; ++w) tot += s_wc[w][tid];
             if (!EMIT) {
                 // (a tile outside the grid / the band has no covering record: tot == 0 and nothing is touched)
-                const unsigned base = tot ? atomicAdd(&tile_count[(size_t)tile * SGS_XCDS + my_xcd], tot) : 0u;
-                job_base[(size_t)job * (NT + 1) + tid] = base;
-                if (tid == 0) job_base[(size_t)job * (NT + 1) + NT] = my_xcd;       // the emit must use the same sub-queue
+                job_base[(size_t)job * NT + tid] = tot ? atomicAdd(&tile_count[tile], tot) : 0u;
             } else {
-                const unsigned xcd = job_base[(size_t)job * (NT + 1) + NT];
-                s_base[tid] = tot ? tile_offset[(size_t)tile * SGS_XCDS + xcd] + job_base[(size_t)job * (NT + 1) + tid] : 0u;
+                s_base[tid] = tot ? tile_offset[tile] + job_base[(size_t)job * NT + tid] : 0u;
             }
         }
         if (EMIT) {
@@ -1125,6 +1115,7 @@ __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) 
                 for (int w = 0; w < wave; ++w) pos += s_wc[w][t];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
+                    if (!slot_on[r]) continue;
                     const bool hit = (cover[r] >> t) & 1u;
                     const unsigned long long m = __ballot(hit);
                     if (hit) rec[pos + (unsigned)__popcll(m & lanemask_lt(lane))] = rv[r];

@@ -232,6 +232,11 @@ static inline unsigned long long clock64() { return 0; }
 #define __builtin_amdgcn_s_setprio(p_) ((void)0)
 #define __builtin_amdgcn_s_getreg(reg_) (blockIdx.x & 7u)      /* emulated XCC id */
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <class T> static inline T __hip_atomic_load(const T* p, int, int) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+// device- / workgroup-scope fences: workgroups are OS threads here
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // callers pass wave-uniform values
