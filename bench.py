@@ -35,6 +35,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
+# (sage_gs sets this on import as well — here before anything can initialise the HIP runtime: the library's three lane streams
+#  must not share a hardware queue, sage_gs/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_LANE_OPS = 78.6e12    # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the 157 TFLOP/s fp32 peak counts an FMA twice)

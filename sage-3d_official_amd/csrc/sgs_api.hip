@@ -327,10 +327,14 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
 //     launches were ~40 us, as long as a light band of tile rows takes on the GPU).
 int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
                   int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
-                  float* out_aux, bool pipelined, bool in_batch, int set0) {
+                  float* out_aux, bool pipelined, bool in_batch, int set0, int stream_lane = -1) {
     int rc;
     const sgs_camera* cam = cams;                 // resolution / rows are the group's
-    Lane& L = ctx->lanes[set0];                   // the group's stream is its first lane's
+    // The stream: a pipelined frame's own lane's; a batch's groups rotate over the streams of lanes 0 .. group_lanes-1 — the
+    // SAME streams single pipelined frames use.  (r03y: the groups used to run on the streams of lanes 0 and 4; a process that
+    // had issued one batch and then pipelined single frames owned four lane streams + the caller's, the runtime maps streams onto
+    // four hardware queues, two lanes shared one and the sweep was 11 % slower — 4180 vs 3750 frames/s — for the rest of the process.)
+    Lane& L = ctx->lanes[stream_lane >= 0 ? stream_lane : set0];
     hipStream_t stream = caller_stream;
     if (pipelined) {
         if ((rc = ensure_lane_stream(ctx, L)) != SGS_OK) return rc;
@@ -382,7 +386,10 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
     const unsigned F = (unsigned)nf;
-    const unsigned bin_blocks = (unsigned)std::min<int64_t>(ctx->bin_grid, P.n_ranges);
+    // the binning grids are sized per LAUNCH: the frames of a group share them (a group of four band frames with 512 + 2048
+    // workgroups EACH spent its time starting workgroups that found a chunk or a job apiece: 0.047 -> 0.041 ms per frame
+    // of a 3-row band, 0.057 -> 0.051 of an 18-row one, r03y)
+    const unsigned bin_blocks = (unsigned)std::min<int64_t>(std::max(32, ctx->bin_grid / nf), P.n_ranges);
     if (P.n_chunks > 0) {
         hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), F),
                            dim3(SGS_CULL_THREADS), 0, stream, G);
@@ -400,7 +407,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[2], stream));
 
     // level 2: super-tile queues -> tile queues (count, scan of the tile counters + render order, emit)
-    const unsigned exp_grid = (unsigned)std::min<int64_t>(ctx->exp_grid, (int64_t)ns + (scene->n + SGS_SEG - 1) / SGS_SEG);
+    const unsigned exp_grid = (unsigned)std::min<int64_t>(std::max(64, ctx->exp_grid / nf), (int64_t)ns + (scene->n + SGS_SEG - 1) / SGS_SEG);
     if (bin) hipLaunchKernelGGL((sgs::k_expand<false>), dim3(std::max(1u, exp_grid), F), dim3(SGS_EXP_THREADS), 0, stream, G);
     // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
     const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
@@ -826,8 +833,8 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
             if ((rc = ensure_lane_stream(ctx, ctx->lanes[0])) != SGS_OK) return rc;
             SGS_HIP(ctx, hipEventRecord(ctx->lanes[0].fork, stream));
             for (int gl = 0; gl < GL; ++gl) {
-                if ((rc = ensure_lane_stream(ctx, ctx->lanes[gl * F])) != SGS_OK) return rc;
-                SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[gl * F].stream, ctx->lanes[0].fork, 0));
+                if ((rc = ensure_lane_stream(ctx, ctx->lanes[gl])) != SGS_OK) return rc;
+                SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[gl].stream, ctx->lanes[0].fork, 0));
             }
         }
         for (int i = 0, g = 0; i < cn; i += F, ++g) {
@@ -836,12 +843,12 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
             const int rb = rb0, re = re0;
             for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
-                                    (g % GL) * F)) != SGS_OK)
+                                    (g % GL) * F, g % GL)) != SGS_OK)
                 return rc;
             for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
         }
         // ... wait for the lanes and fetch every frame's status in one copy
-        if (lanes) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl * F].stream));
+        if (lanes) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl].stream));
         SGS_HIP(ctx, hipStreamSynchronize(stream));
         if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;           // (frames issued outside this call)
         SGS_HIP(ctx, hipMemcpy(ctx->h_status, ctx->d_status, sizeof(FrameStatus) * (size_t)cn, hipMemcpyDeviceToHost));

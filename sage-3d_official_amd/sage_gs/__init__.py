@@ -5,8 +5,17 @@ forward path (SH -> EWA projection -> AABB -> 16x16 tile binning -> per-tile rad
 front-to-back composite) is hand-written HIP for gfx950 in ``csrc/``, reached through the C ABI of
 ``include/sage_gs.h``; this package is the thin Python host side.
 """
-from . import _capi  # noqa: F401
-from ._capi import SgsError  # noqa: F401
+import os as _os
+
+# The library overlaps independent frames on three streams of its own ("lanes") next to the caller's.  The ROCm runtime maps
+# streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and two lanes that land on one queue serialise:
+# measured 3070 vs 4100 frames/s on the same box (profiles/r03y_*).  Eight queues keep the lanes, the caller's stream and an
+# exchange stream apart.  Read by the runtime when it initialises (the first HIP call of the process): set here, before the
+# renderer makes one; an application that initialises HIP earlier sets it itself (INTEGRATION.md).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import _capi  # noqa: F401,E402
+from ._capi import SgsError  # noqa: F401,E402
 
 __all__ = ["Camera", "RenderConfig", "Gaussians", "Renderer", "Scene", "render", "default_renderer",
            "SgsError", "scenes"]

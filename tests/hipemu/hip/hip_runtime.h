@@ -251,7 +251,7 @@ static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(true); }
 static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::shfl_from(v, src & 63); }
 // v_mov_b32 with a DPP modifier (the controls the kernels use): every lane of the wave takes part; a lane whose source
 // lane does not exist, or whose row is masked off, gets `old` (bound_ctrl = false: the destination is not written).
-//   0x101..0x10f row_shl:n   0x111..0x11f row_shr:n   0x142 row_bcast:15   0x143 row_bcast:31
+//   0x00..0xff quad_perm   0x101..0x10f row_shl:n   0x111..0x11f row_shr:n   0x142 row_bcast:15   0x143 row_bcast:31
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
     hipemu::BlockExec* e = hipemu::exec();
     const unsigned t = e->fibers[e->cur].tid.x;
@@ -259,7 +259,8 @@ static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int ro
     const int p = hipemu::collective(hipemu::bits(src));
     hipemu::WaveState& w = e->waves[t >> 6];
     int from = -1;
-    if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (in_row >= n) from = lane - n; }
+    if (ctrl >= 0 && ctrl <= 0xff) from = (lane & ~3) + ((ctrl >> (2 * (lane & 3))) & 3);     // quad_perm:[a,b,c,d]
+    else if (ctrl >= 0x111 && ctrl <= 0x11f) { const int n = ctrl - 0x110; if (in_row >= n) from = lane - n; }
     else if (ctrl >= 0x101 && ctrl <= 0x10f) { const int n = ctrl - 0x100; if (in_row + n <= 15) from = lane + n; }
     else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }                  // last lane of the previous row
     else if (ctrl == 0x143) { if (row >= 2) from = 31; }                            // last lane of row 1
@@ -322,5 +323,8 @@ inline void* dyn_shared() {
 }  // namespace hipemu
 #define SGS_DYNAMIC_LDS(T, name) T* const name = static_cast<T*>(hipemu::dyn_shared())
 #define SGS_PIN_VGPR(x) ((void)(x))      // (register-class hint of the GPU build)
+// v_fmac_f32 with a DPP quad_perm:[I,I,I,I] source (the GPU build writes it as asm)
+#define SGS_FMAC_QUAD(C, v, I, w)                                                                      \
+    C = __builtin_fmaf(__uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), (I) * 0x55, 0xf, 0xf, true)), w, C);
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     (hipemu::dyn_bytes() = (size_t)(shmem), hipemu::launch((grid), (block), [=]() { kernel(__VA_ARGS__); }))
