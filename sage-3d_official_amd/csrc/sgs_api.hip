@@ -93,6 +93,7 @@ struct sgs_ctx {
     int last_lane = 0;
     int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (SGS_EXP_GRID_ENV)
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
+    int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP (SGS_PRE_GRID): its waves loop over the live list
     int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
                                              // 64-KB window: binning alone 380 -> 305 us at 3840x2160, but such workgroups overlap worse
                                              // with the other frames in flight (sweep 1717 -> 1657 frames/s), so it is opt-in
@@ -393,7 +394,11 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     if (P.n_chunks > 0) {
         hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), F),
                            dim3(SGS_CULL_THREADS), 0, stream, G);
-        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)((P.n_chunks + 3) / 4), F), dim3(256), 0, stream, G);
+        // a single frame: a wave per chunk of the scene (most end at once; capping the grid cost 2-6 us of 76); a group's
+        // frames — bands, as a rule, that keep a few per cent of the chunks — share SGS_PRE_GRID workgroups (r03y: 0.0454 ->
+        // 0.0425 ms per frame of a 3-row band)
+        const int64_t pre_grid = nf > 1 ? std::min<int64_t>((P.n_chunks + 3) / 4, std::max(256, ctx->pre_grid / nf)) : (P.n_chunks + 3) / 4;
+        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)pre_grid, F), dim3(256), 0, stream, G);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
@@ -539,6 +544,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
     if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
     if (const char* env = getenv("SGS_EXP_GRID")) ctx->exp_grid = std::min(65535, std::max(8, atoi(env)));
+    if (const char* env = getenv("SGS_PRE_GRID")) ctx->pre_grid = std::max(256, atoi(env));
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_GROUP")) ctx->group = std::min(std::min(kMaxLanes, SGS_MAX_GROUP), std::max(1, atoi(env)));

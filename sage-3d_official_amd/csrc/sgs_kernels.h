@@ -489,13 +489,14 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     unsigned* __restrict__ big_list = S.big_list; uint4* __restrict__ binrec = S.binrec;
     FrameStatus* __restrict__ st = S.st;
     const int lane = threadIdx.x & 63;
-    // wave k of the launch takes entry k of the frame's live list (k_chunk_cull): the chunks that cannot reach this frame
-    // / this rank's band of tile rows are never touched
-    const unsigned k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (k >= st->n_live) return;                           // wave-uniform
-    const long long chunk = (long long)S.live_list[k];
+    // the waves of the launch take the entries of the frame's live list (k_chunk_cull) in turn: the chunks that cannot reach
+    // this frame / this rank's band of tile rows are never touched.  (A loop, so that the frames of a group — bands that keep
+    // a few per cent of 47 k chunks — can share a grid of a few thousand workgroups instead of starting 45 k waves each only to
+    // end them; a single frame is launched with a wave per chunk of the scene.)
+    const unsigned n_live = st->n_live, nw = gridDim.x * (blockDim.x >> 6);
     (void)cbound;
-    preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, chunk, lane);
+    for (unsigned k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n_live; k += nw)      // wave-uniform
+        preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
 }
 
 // ------------------------------------------------------------------------------------------------
