@@ -843,15 +843,25 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
                 SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[gl].stream, ctx->lanes[0].fork, 0));
             }
         }
-        for (int i = 0, g = 0; i < cn; i += F, ++g) {
-            const int nf = std::min(F, cn - i);
+        // The chunk's frames are dealt to the group streams in EQUAL shares, each share cut into groups of <= F: 20 frames on
+        // two streams are 4,4,2 + 4,4,2, not 4,4,4 + 4,4 (the stream with the extra group finished it alone, without a
+        // neighbour's kernels to overlap with).
+        const int n_streams = lanes ? std::min(GL, (cn + F - 1) / F) : 1;
+        int left[kMaxLanes];                            // frames each stream still has to issue
+        for (int sidx = 0; sidx < n_streams; ++sidx) left[sidx] = cn / n_streams + (sidx < cn % n_streams ? 1 : 0);
+        for (int i = 0, g = 0; i < cn; ++g) {
+            const int sidx = g % n_streams;
+            const int nf = std::min(F, left[sidx]);
+            if (nf <= 0) continue;
+            left[sidx] -= nf;
             float* outs[SGS_MAX_GROUP];
             const int rb = rb0, re = re0;
             for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
-                                    (g % GL) * F, g % GL)) != SGS_OK)
+                                    sidx * F, sidx)) != SGS_OK)
                 return rc;
             for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
+            i += nf;
         }
         // ... wait for the lanes and fetch every frame's status in one copy
         if (lanes) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl].stream));
