@@ -394,11 +394,13 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     if (P.n_chunks > 0) {
         hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), F),
                            dim3(SGS_CULL_THREADS), 0, stream, G);
-        // a single frame: a wave per chunk of the scene (most end at once; capping the grid cost 2-6 us of 76); a group's
-        // frames — bands, as a rule, that keep a few per cent of the chunks — share SGS_PRE_GRID workgroups (r03y: 0.0454 ->
-        // 0.0425 ms per frame of a 3-row band)
-        const int64_t pre_grid = nf > 1 ? std::min<int64_t>((P.n_chunks + 3) / 4, std::max(256, ctx->pre_grid / nf)) : (P.n_chunks + 3) / 4;
-        hipLaunchKernelGGL(sgs::k_preprocess, dim3((unsigned)pre_grid, F), dim3(256), 0, stream, G);
+        // a wave per chunk of the scene (most end at once) — except for a group of narrow bands, whose frames share
+        // SGS_PRE_GRID workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
+        const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
+        if (nf > 1 && 2 * (row_end - row_begin) < gy && cap < all)
+            hipLaunchKernelGGL((sgs::k_preprocess<true>), dim3((unsigned)cap, F), dim3(256), 0, stream, G);
+        else
+            hipLaunchKernelGGL((sgs::k_preprocess<false>), dim3((unsigned)all, F), dim3(256), 0, stream, G);
     }
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
 
@@ -414,7 +416,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     // level 2: super-tile queues -> tile queues (count, scan of the tile counters + render order, emit)
     const unsigned exp_grid = (unsigned)std::min<int64_t>(std::max(64, ctx->exp_grid / nf), (int64_t)ns + (scene->n + SGS_SEG - 1) / SGS_SEG);
     if (bin) hipLaunchKernelGGL((sgs::k_expand<false>), dim3(std::max(1u, exp_grid), F), dim3(SGS_EXP_THREADS), 0, stream, G);
-    // one workgroup per 1024 tiles of the band (8 at 1080p, 32 at 3840x2160), independent of each other
+    // one workgroup per SGS_SCAN_THREADS tiles of the band (16 at 1080p, 64 at 3840x2160), independent of each other
     const unsigned scan_groups = std::max(1u, ((unsigned)((row_end - row_begin) * gx) + SGS_SCAN_THREADS - 1) / SGS_SCAN_THREADS);
     hipLaunchKernelGGL(sgs::k_tile_scan, dim3(scan_groups, F), dim3(SGS_SCAN_THREADS), 0, stream, G);
     if (bin) hipLaunchKernelGGL((sgs::k_expand<true>), dim3(std::max(1u, exp_grid), F), dim3(SGS_EXP_THREADS), 0, stream, G);

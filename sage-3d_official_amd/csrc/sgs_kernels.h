@@ -480,37 +480,51 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
 // HBM-bound), which makes every integer decision (cull, radius, rect, tile counts) agree with the
 // fp64 oracle.  A pure map kernel: no LDS, no atomics; vismask[chunk] (the wave's ballot) tells the
 // consumers which of the chunk's 64 splat slots are live this frame.
+// LOOP = false: wave k of the launch takes entry k of the frame's live list (k_chunk_cull) — a wave per chunk of the SCENE is
+//               launched, the chunks that cannot reach this frame are never touched (their waves end at once);
+// LOOP = true : the waves of a smaller grid take the entries in turn.  For the frames of a group that are narrow bands of tile
+//               rows (a few per cent of 47 k chunks live: the launch otherwise starts 45 k waves per frame only to end them).
+//               Not for full frames: the loop makes the compiler keep the frame's constants (the view matrix as doubles, ...)
+//               in 43 more VGPRs — 135 instead of 92, three waves per SIMD instead of five, and a wave that no longer fits
+//               beside the composite's workgroups of the frames in flight (a sweep was 2 % slower, r03z).
+template <bool LOOP>
 __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];                  // this workgroup's frame of the group
     const FrameParams& P = S.P;
-    const float4* __restrict__ geom = G.geom; const float4* __restrict__ shq = G.shq; const float4* __restrict__ cbound = G.cbound;
+    const float4* __restrict__ geom = G.geom; const float4* __restrict__ shq = G.shq;
     Splat* __restrict__ splats = S.splats;
     unsigned long long* __restrict__ vismask = S.vismask; unsigned long long* __restrict__ bigmask = S.bigmask;
     unsigned* __restrict__ big_list = S.big_list; uint4* __restrict__ binrec = S.binrec;
     FrameStatus* __restrict__ st = S.st;
     const int lane = threadIdx.x & 63;
-    // the waves of the launch take the entries of the frame's live list (k_chunk_cull) in turn: the chunks that cannot reach
-    // this frame / this rank's band of tile rows are never touched.  (A loop, so that the frames of a group — bands that keep
-    // a few per cent of 47 k chunks — can share a grid of a few thousand workgroups instead of starting 45 k waves each only to
-    // end them; a single frame is launched with a wave per chunk of the scene.)
-    const unsigned n_live = st->n_live, nw = gridDim.x * (blockDim.x >> 6);
-    (void)cbound;
-    for (unsigned k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); k < n_live; k += nw)      // wave-uniform
-        preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
+    const unsigned n_live = st->n_live, k0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (!LOOP) {
+        if (k0 >= n_live) return;                          // wave-uniform
+        preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k0], lane);
+    } else {
+        const unsigned nw = gridDim.x * (blockDim.x >> 6);
+        for (unsigned k = k0; k < n_live; k += nw)         // wave-uniform
+            preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // S4: exclusive scan of the tile counts (ONE counter per tile: level 2 of the binning needs no per-XCD sub-queues, see
 // k_expand), D, the longest queue and the render order; the queue of tile t is [offset[t], offset[t+1]).
 //
-// One workgroup per 1024 tiles of the band, and NO communication between them: every workgroup reads ALL the band's
+// One workgroup per SGS_SCAN_THREADS (512) tiles of the band, and NO communication between them: every workgroup reads ALL the band's
 // counters (32 KB at 1080p, L2-resident, every load coalesced and in flight together) and derives what it needs about the
 // other workgroups' tiles itself — the records queued before its own tiles, and the tiles per length class before them
-// and overall — then writes the offsets and render-order entries of its own 1024 tiles (one per thread).  A single
+// and overall — then writes the offsets and render-order entries of its own tiles (one per thread).  A single
 // workgroup doing all of it was bound by ONE CU's memory and LDS pipelines (24 us at 1080p, 90 us at 3840x2160 as a
 // kernel of its own in r01; 30 us as the tail of k_expand<false> in r03w: profiles/r03w_fused_scans_experiment.txt).
 // The counters are cleared by k_expand<true> (the next launch), not here: other workgroups may still be reading them.
-#define SGS_SCAN_THREADS 1024
+// 512 threads per workgroup: 1024 (sixteen waves at 116 VGPRs: nearly a whole idle CU) waited ~95 us for a place beside the
+// composite's workgroups of the frames in flight; 512 costs 2.4 us more alone (16 workgroups each read every counter) and a sweep
+// is 2 % faster; 256: +8 us alone, +1.3 % (r03z)
+#ifndef SGS_SCAN_THREADS
+#define SGS_SCAN_THREADS 512
+#endif
 #define SGS_SCAN_SLABS 8
 // Per (wave, class) ONE LDS atomic instead of 64 serialised ones on the same address: neighbouring tiles have queues
 // of similar length, so a wave holds two or three classes.  Returns the lane's position (old cursor + rank in its class).
@@ -539,7 +553,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
     uint4* __restrict__ tile_order = S.tile_order; unsigned long long* __restrict__ row_acc = G.row_acc;
     FrameStatus* __restrict__ st = S.st;
     constexpr int NW = SGS_SCAN_THREADS / SGS_WAVE;
-    __shared__ unsigned s_row[SGS_SCAN_THREADS + 2];  // records per tile row among my 1024 tiles (-> row_acc, see the end)
+    __shared__ unsigned s_row[SGS_SCAN_THREADS + 2];  // records per tile row among my tiles (-> row_acc, see the end)
     __shared__ unsigned s_all[33], s_before[33];      // tiles per log2(queue length) class: whole band / before my tiles
     __shared__ unsigned s_cur[33];                    // my tiles' cursors: first render position of each class for them
     __shared__ unsigned s_wa[NW], s_wb[NW], s_wm[NW], s_wi[NW];
