@@ -1653,7 +1653,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
 #define SGS_PROF_MARK(acc) do { } while (0)
 #endif
     if (st->overflow) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tid_entry = tid;
     // blocks take the tiles longest queue first (k_tile_scan's order)
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
     if (blockIdx.x >= ntiles) return;    // workgroup-uniform
@@ -1669,9 +1669,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     // and it is stored at row tile_y of the (compact, when stride > 1) output image
     const unsigned frame_y = tile_y * (unsigned)P.row_stride + (unsigned)P.row_phase;
     const unsigned in_y = (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
-    const unsigned py = frame_y * 16u + in_y, out_py = tile_y * 16u + in_y;
-    const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
-    const float lx = (float)((unsigned)(wave & 1) * 8u + (unsigned)(lane & 7)), ly = (float)in_y;   // the pixel inside its tile
+    const unsigned py = frame_y * 16u + in_y;
+    const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;      // (again at the end, for the store)
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
     // per-frame constants of the trip (the header of the blend macros): all in VGPRs, an SGPR operand costs 1.6 issues
     float amax = P.alpha_max, big = SGS_BIG;
@@ -1714,6 +1713,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     // exclusive scan of the SGS_NB bucket counts in s_bcnt (-> cursors, positions from pbase) + ordered compaction of the
     // non-empty buckets; all threads, ends with a barrier
     auto scan_buckets = [&]() {
+        int tid_l = tid_entry; SGS_PIN_VGPR(tid_l);          // (a fresh copy of the thread index: see the group loop)
+        const int tid = tid_l, lane = tid & 63, wave = tid >> 6;
         const unsigned c = s_bcnt[tid];
         const unsigned incl = wave_incl_scan(c, lane);
         const unsigned long long nem = __ballot(c != 0u);
@@ -1732,6 +1733,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     };
     // long queues: the histogram of the records not yet consumed (key >= kdone) under the current (klo, ksh); all threads
     auto long_histogram = [&]() {
+        int tid_l = tid_entry; SGS_PIN_VGPR(tid_l);
+        const int tid = tid_l;
         s_bcnt[tid] = 0;
         __syncthreads();
         for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {                 // SGS_PASS_R loads in flight per lane
@@ -1823,6 +1826,13 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     unsigned win_lo = 0, win_hi = in_lds ? n : 0u;   // queue range resident in s_q (the whole queue when it fits)
     unsigned n_refine = 0u, no_refine_at = 0xffffffffu;
     while (lo < n && (!tile_done || full_sort)) {
+        // Everything a group derives from the thread index is derived HERE, per group, from a copy the compiler cannot see
+        // through: hoisted out of the loop, the dozen index expressions, LDS addresses and pixel coordinates below stayed live
+        // across the blend (the kernel's register peak) and were spilled in the prologue — 44 bytes per lane, 92 MB of scratch
+        // writes per 1080p frame, as much as the kernel's whole algorithmic traffic (r03c).
+        int tid_group = tid_entry; SGS_PIN_VGPR(tid_group);
+        const int tid = tid_group, lane = tid & 63, wave = tid >> 6;
+        const float lx = (float)((unsigned)(wave & 1) * 8u + (unsigned)(lane & 7)), ly = (float)((unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3));
         unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
         else {
@@ -2123,6 +2133,12 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
         o[20] = pt_rec; o[21] = 0; o[22] = 0; o[23] = 0;
     }
 #endif
+    {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)
+        int tid_out = tid_entry; SGS_PIN_VGPR(tid_out);
+        const unsigned lane_o = (unsigned)tid_out & 63u, wave_o = (unsigned)tid_out >> 6;
+        const unsigned px = tile_x * 16u + (wave_o & 1u) * 8u + (lane_o & 7u), in_y = (wave_o >> 1) * 8u + (lane_o >> 3);
+        const unsigned py = frame_y * 16u + in_y, out_py = tile_y * 16u + in_y;
+        const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
     if (inside) {
         float* o = out_rgb + ((size_t)out_py * P.width + px) * 3;
         if (TF) {
@@ -2134,6 +2150,7 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
                 a[0] = Dz; a[1] = 1.0f - Tf;
             }
         } else { o[0] = C0; o[1] = C1; o[2] = C2; }  // black background
+    }
     }
     if (STATS) {                         // SGS_FLAG_STATS: D_f = furthest queue position any pixel examined
         const unsigned wu = wave_max(inside ? used : 0u);
