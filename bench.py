@@ -341,7 +341,7 @@ def main():
     stage_bytes = {n: 0 for n in STAGE_NAMES}
     iso_ms = {n: [] for n in STAGE_NAMES}
     frame_ms, latency = [], []
-    counts = {"n_visible": 0, "d_total": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
+    counts = {"n_visible": 0, "d_total": 0, "d_super": 0, "d_fetched": 0, "max_tile_len": 0, "n_spill_tiles": 0}
     pixels = 0
     if rank == 0:
         own = sharded.g.render_target(0) if rows_primary else {"out": frame}      # (rows: rank 0's band of the even split)
@@ -357,7 +357,7 @@ def main():
             st = r.last_stats
             for n in STAGE_NAMES:
                 stage_bytes[n] += st["bytes"][n]
-            for k in ("n_visible", "d_total", "d_fetched"):
+            for k in ("n_visible", "d_total", "d_super", "d_fetched"):
                 counts[k] += st[k]
             counts["max_tile_len"] = max(counts["max_tile_len"], st["max_tile_len"])
             counts["n_spill_tiles"] += st["n_spill_tiles"]

@@ -122,6 +122,7 @@ typedef struct sgs_stats {
     float ms[SGS_NUM_STAGES];      /* per-stage GPU time (SGS_FLAG_TIMING), else 0       */
     float ms_total;                /* first launch -> last launch (SGS_FLAG_TIMING)      */
     int64_t bytes[SGS_NUM_STAGES]; /* algorithmic bytes per stage         */
+    int64_t d_super;       /* D_s: records in the super-tile queues (level 1 of the binning) */
 } sgs_stats;
 
 int sgs_version(void);

@@ -484,8 +484,12 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
     stats->bytes[SGS_STAGE_PREPROCESS] = 16 * n + (32 + 16 * (int64_t)sh_rows + 64 + 16) * nv;   // rows read; splat + binning record written
-    stats->bytes[SGS_STAGE_COUNT] = 16 * nv + 16 * ((int64_t)ctx->last_T + 1);   // rect re-read + counters
-    stats->bytes[SGS_STAGE_EMIT] = 16 * nv + 8 * D;
+    // two-level binning (D_s = records in the super-tile queues): level 1 reads every visible splat's 16-B binning record in
+    // both of its passes and writes D_s of them; level 2 reads those in both of its passes and writes the D 8-B tile records
+    const int64_t Ds = s.ds_total;
+    stats->d_super = Ds;
+    stats->bytes[SGS_STAGE_COUNT] = 2 * 16 * nv + 16 * Ds;
+    stats->bytes[SGS_STAGE_EMIT] = 2 * 16 * Ds + 8 * D + 8 * ((int64_t)ctx->last_T + 1);
     stats->bytes[SGS_STAGE_RENDER] = 8 * D + 36 * Df + 12 * pixels;               // every record seen once, D_f splats blended
     if (timed && ctx->ev) {
         hipEvent_t* ev = ctx->ev[slot];

@@ -38,7 +38,7 @@ def test_struct_layouts_match_the_header(lib):
     from sage_gs import _capi
     assert C.sizeof(_capi.SgsCamera) == 2 * 4 + 4 * 4 + 16 * 4
     assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4 + 2 * 4      # + tile_row_stride, tile_row_phase
-    assert C.sizeof(_capi.SgsStats) == 112      # 5 i64, 4 i32, float[4], float, (pad), i64[4]
+    assert C.sizeof(_capi.SgsStats) == 120      # 5 i64, 4 i32, float[4], float, (pad), i64[4], i64 (d_super)
 
 
 def test_no_cpu_backend_and_no_silent_fallback(lib):
