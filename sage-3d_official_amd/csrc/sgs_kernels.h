@@ -1572,6 +1572,9 @@ __device__ __forceinline__ float4 sgs_live_rect(unsigned long long m, float x0, 
 #ifndef SGS_PART_MIN
 #define SGS_PART_MIN 64               // queues up to this long are one group ranked all pairs; longer ones are partitioned into depth buckets
 #endif
+#ifndef SGS_TAIL_AFTER
+#define SGS_TAIL_AFTER 3u
+#endif
 #ifndef SGS_GROUP
 #define SGS_GROUP 192                 // soft cap of a group: buckets are added while the total stays below (192 vs 256: -1.3 % per frame, r02y)
 #endif
@@ -1840,7 +1843,10 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             // the resident window also ends inside it: buckets are placed once); at least one bucket.  s_ne_end is
             // increasing, so the buckets that fit are a prefix: every wave counts them with independent reads and
             // ballots — two LDS round-trips instead of one per bucket.
-            const unsigned limit = lo < win_hi ? min(lo + (unsigned)SGS_GROUP, win_hi) : lo + (unsigned)SGS_GROUP;
+            // (a tile past its third batch is going to read most of its queue — pixels that never saturate — and what it pays
+            //  per batch is mostly fixed: full batches from then on)
+            const unsigned gcap = it >= SGS_TAIL_AFTER ? (unsigned)SGS_BATCH : (unsigned)SGS_GROUP;
+            const unsigned limit = lo < win_hi ? min(lo + gcap, win_hi) : lo + gcap;
             unsigned fit = 0;
 #pragma unroll
             for (int r = 0; r < SGS_NB / 64; ++r) {
