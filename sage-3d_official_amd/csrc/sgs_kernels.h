@@ -375,19 +375,32 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                 // 16t .. 16t+15.  fp32 with outward padding; the reference rect stays in the splat record and is what
                 // SGS_FLAG_LOOSE_CULL (tests) bins.
                 brect01 = rect01; brect23 = rect23;
+                // The conic AS THE COMPOSITE SEES IT: rounded to fp32 (the format of the path, and what the oracle blends with).
+                // The extents below — of the ellipse alpha >= alpha_min — are derived from THAT form, not from the fp64
+                // covariance it was inverted from: for a needle (sigma_minor ~ 0.55 px from the dilation, sigma_major thousands
+                // of pixels) the rounding of three nearly dependent entries moves the determinant, i.e. the length of the long
+                // axis, by per cent — the composite blended pixels (alpha 1.01 alpha_min, 2 500 px from the centre) that the
+                // covariance's ellipse, and with it the bin rect, ended 5 px short of (gpu_fuzz seed 3002, r03).
+                //   q2 = A dx^2 + B dx dy + C dy^2 <= qmax:  |dx| <= sqrt(qmax C / det),  |dy| <= sqrt(qmax A / det),  det = A C - B^2 / 4
+                // (log2 units, as in the record; det <= 0: a degenerate form, every pixel may pass: no tightening).
+                const double idet = 1.0 / det;
+                ca = (float)(c * idet); cb = (float)(-b * idet); cc = (float)(a * idet);
+                const double A64e = (0.5 * 1.4426950408889634) * (double)ca, B64e = 1.4426950408889634 * (double)cb,
+                             C64e = (0.5 * 1.4426950408889634) * (double)cc;
+                const double det_e = A64e * C64e - 0.25 * B64e * B64e;
+                const float wx = det_e > 0.0 ? (float)(C64e / det_e) : 3.0e38f, wy = det_e > 0.0 ? (float)(A64e / det_e) : 3.0e38f;   // extent^2 per unit of q2
                 // what the composite needs to decide which 8x8 quadrants of a tile the splat can reach (k_tile_render):
-                // alpha >= alpha_min  <=>  q2 <= qmax = log2(o / alpha_min); the ellipse's axis-aligned half extents are
-                // sqrt(K a) x sqrt(K c), K = 2 ln(o / alpha_min) = 2 ln2 qmax, padded generously (the exact quadrant test follows)
+                // alpha >= alpha_min  <=>  q2 <= qmax = log2(o / alpha_min); half extents padded generously (the exact quadrant test follows)
                 qmax = __log2f(g0.w) - __log2f(P.alpha_min);
                 if (qmax > 0.0f) {
-                    const float Kq = 1.38629436112f * qmax;
-                    const float ex_ = sqrtf(Kq * (float)a) * 1.01f + 0.5f, ey_ = sqrtf(Kq * (float)c) * 1.01f + 0.5f;
+                    const float ex_ = sqrtf(qmax * wx) * 1.01f + 0.5f, ey_ = sqrtf(qmax * wy) * 1.01f + 0.5f;
                     ext_x = ex_ < 3.0e38f ? ex_ : 3.0e38f; ext_y = ey_ < 3.0e38f ? ey_ : 3.0e38f;      // (inf / NaN -> everywhere)
                 }
                 if (!(P.flags & 32u)) {
-                    const float Kc = 2.0f * __logf(g0.w / P.alpha_min) * 1.0001f + 1.0e-4f;
+                    const float Kc = qmax * 1.0001f + 1.0e-4f;
                     if (Kc > 0.0f) {
-                        const float hx = sqrtf(Kc * (float)a) * 1.0001f + 0.02f, hy = sqrtf(Kc * (float)c) * 1.0001f + 0.02f;
+                        const float hx_ = sqrtf(Kc * wx) * 1.0001f + 0.02f, hy_ = sqrtf(Kc * wy) * 1.0001f + 0.02f;
+                        const float hx = hx_ < 1.0e9f ? hx_ : 1.0e9f, hy = hy_ < 1.0e9f ? hy_ : 1.0e9f;          // (inf / NaN -> the whole rect)
                         const float fpx = (float)px, fpy = (float)py;
                         const float epx = 1.0e-6f * fabsf(fpx), epy = 1.0e-6f * fabsf(fpy);
                         const float lo_x = ceilf((fpx - hx - epx - 15.0f) * (1.0f / SGS_TILE_PX)), hi_x = floorf((fpx + hx + epx) * (1.0f / SGS_TILE_PX)) + 1.0f;
@@ -406,8 +419,6 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                     big = (sx1 - sx0) * (sy1 - sy0) > (unsigned)SGS_BIG_RECT;
                 }
                 sx = (float)px; sy = (float)py;
-                const double idet = 1.0 / det;
-                ca = (float)(c * idet); cb = (float)(-b * idet); cc = (float)(a * idet);
             }
         }
     }
