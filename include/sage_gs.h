@@ -26,7 +26,11 @@
 extern "C" {
 #endif
 
-#define SGS_VERSION 100            /* major*100 + minor */
+#define SGS_VERSION 110            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
+                                    * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points): a caller compiled against
+                                    * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
+                                    * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
+                                    * that takes a struct.  The library writes whole structs (sgs_stats arrays with ITS stride). */
 #define SGS_TILE 16                /* 16x16-pixel tiles (BASELINE.json north_star) */
 
 typedef enum sgs_status {
@@ -78,8 +82,10 @@ typedef struct sgs_scene sgs_scene;    /* opaque */
 
 /* Pinhole camera: +Z forward, +X right, +Y down; pixel i covers [i, i+1) so a point on the optical
  * axis lands at pixel coordinate cx - 0.5.  `view` maps MODEL space to camera space (row-major
- * 4x4, rigid): the asset's model->world transform (Data/template.usda:115-124, rotateXYZ -90,0,0)
- * is folded in by the caller.  Replaces Camera(prim_path, frequency, resolution) + focalLength
+ * 4x4, RIGID — rows of its 3x3 orthonormal to 1e-5, else SGS_ERR_INVALID at enqueue time: the culling bounds absorb ~1e-4 of
+ * non-rigidity and the contract sits an order of magnitude inside that.  A view composed or inverted in fp32 can miss it (a few 1e-6
+ * is typical, 1e-5 happens): re-orthonormalise it first, as sage_gs.renderer does for its callers): the asset's model->world transform
+ * (Data/template.usda:115-124, rotateXYZ -90,0,0) is folded in by the caller.  Replaces Camera(prim_path, frequency, resolution) + focalLength
  * (simple_env.py:840-844,905; generate_images.py:344-350) and cam.set_world_pose(position,
  * orientation) (simple_env.py:1284; generate_images.py:419-421). */
 typedef struct sgs_camera {
@@ -126,6 +132,9 @@ typedef struct sgs_stats {
 } sgs_stats;
 
 int sgs_version(void);
+/* sizeof(sgs_camera), sizeof(sgs_config), sizeof(sgs_stats) as THIS library was compiled (any pointer may be NULL): what a hand-written
+ * binding compares its own struct sizes with at load time (sage_gs/_capi.py does).  The reference has no counterpart (no FFI at all). */
+void sgs_struct_sizes(int32_t* camera_bytes, int32_t* config_bytes, int32_t* stats_bytes);
 void sgs_config_default(sgs_config* cfg);
 
 /* Replaces SimulationApp({...}) + World() construction (simple_env.py:160-230). */

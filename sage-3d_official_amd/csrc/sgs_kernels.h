@@ -20,6 +20,16 @@ namespace sgs {
 
 #define SGS_LOG2E 1.44269504088896341f
 
+// The binning kernels (and the per-chunk cull) are chains of short launches whose waves walk lists serially: a critical path, little
+// arithmetic.  They run BESIDE another frame's composite, whose five waves per SIMD are issue-bound; at equal priority a binning wave
+// gets a sixth of the issue slots and its walk takes 2-4x as long as alone (r04b/c timelines: k_bin_emit 18 -> 62 us, k_expand<true>
+// 25 -> 53 us, and the frame after next waits for them).  Raised wave priority lets them win the issue arbitration; what they take from
+// the composite is their instruction count (a seventh of its own).
+#ifndef SGS_BIN_PRIO
+#define SGS_BIN_PRIO 3
+#endif
+#define SGS_RAISE_PRIO() __builtin_amdgcn_s_setprio(SGS_BIN_PRIO)
+
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
@@ -178,6 +188,7 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
 // chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
 #define SGS_CULL_THREADS 256
 __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     __shared__ unsigned s_wcnt[SGS_CULL_THREADS / SGS_WAVE];
@@ -558,6 +569,7 @@ __device__ __forceinline__ unsigned class_take(unsigned* s_cls, unsigned cls, bo
 __device__ __forceinline__ unsigned queue_class(unsigned c) { return c ? 32u - (unsigned)__clz((int)c) : 0u; }
 
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const unsigned* __restrict__ tile_count = S.tile_count; unsigned* __restrict__ tile_offset = S.tile_offset;
@@ -866,6 +878,7 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const SuperGr
 // (~15 KB of LDS per workgroup at 1080p: what a binning workgroup takes from a CU is what the composite workgroups of
 // the frames in flight cannot use)
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
@@ -960,6 +973,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
 // work list: super-tile s with c records becomes ceil(c / SGS_SEG) jobs (super-tile, first record, records).
 #define SGS_SSCAN_THREADS 1024
 __global__ __launch_bounds__(SGS_SSCAN_THREADS) void k_stile_scan(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const unsigned* __restrict__ stile_count = S.stile_count; unsigned* __restrict__ stile_offset = S.stile_offset;
@@ -1006,6 +1020,7 @@ __global__ __launch_bounds__(SGS_SSCAN_THREADS) void k_stile_scan(const FrameGro
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
@@ -1062,6 +1077,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
 // No per-record atomics, and the 8-byte records reach HBM in runs instead of one by one.
 template <bool EMIT>
 __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) {
+    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ srec = reinterpret_cast<const uint4*>(S.alt); const uint4* __restrict__ jobs = S.jobs;
@@ -1619,9 +1635,8 @@ template <bool AUX, bool STATS, bool TF>
 #ifndef SGS_RENDER_WGS
 #define SGS_RENDER_WGS 5
 #endif
-__global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(const FrameGroup G) {
+__device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned bx) {
     static_assert(TF || !AUX, "the coverage output needs the final transmittance");
-    const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ tile_order = S.tile_order; const unsigned long long* __restrict__ rec = S.rec;
     unsigned long long* alt = S.alt; unsigned long long* part = S.part; unsigned* sorted_out = S.sorted_out;
@@ -1670,8 +1685,8 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tid_entry = tid;
     // blocks take the tiles longest queue first (k_tile_scan's order)
     const unsigned ntiles = (unsigned)((P.row_end - P.row_begin) * P.gx);
-    if (blockIdx.x >= ntiles) return;    // workgroup-uniform
-    const uint4 job = tile_order[blockIdx.x];        // (tile, first record, queue length) from k_tile_scan
+    if (bx >= ntiles) return;            // workgroup-uniform
+    const uint4 job = tile_order[bx];                // (tile, first record, queue length) from k_tile_scan
 #ifdef SGS_TILE_PROF
     __builtin_amdgcn_s_waitcnt(0); asm volatile("" ::: "memory");
     pt_job = clock64() - pt0;      // kernel entry -> job (and the status word) arrived
@@ -2180,6 +2195,51 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
             atomicAdd(&st->d_fetched, (unsigned long long)u);
         }
     }
+}
+
+template <bool AUX, bool STATS, bool TF>
+__global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(const FrameGroup G) {
+    render_tile<AUX, STATS, TF>(G.s[blockIdx.y], blockIdx.x);
+}
+
+// ---- frames in flight, by construction: k_fused = the composite of one frame + the projection of a later one ------------------
+// The composite is bound by vector issue slots (~0.8 busy) and leaves HBM idle; k_preprocess streams the scene at ~4 TB/s and leaves
+// the vector units idle (~0.35 busy).  Launched as two kernels on two streams they overlap badly: a composite workgroup holds 96
+// VGPRs per lane on every SIMD and five of them fill the register file, so the other kernel's workgroups only ever get the slots
+// the dispatcher happens to hand them between two composite workgroups (r03d: in-flight durations 1.6-2.5x the durations alone,
+// a sweep's frame time = preprocess + render + 20 us).  Here the two are ONE grid whose workgroups are dealt in a fixed ratio:
+// workgroup b of the launch is a projection workgroup (four chunks of the LATER frame's live list, one per wave) when
+// floor((b+1) nP / tot) > floor(b nP / tot), else the composite of tile-order position b - floor(b nP / tot) of the EARLIER frame
+// — nP = ceil(n_live / 4) read from the later frame's status word (k_chunk_cull has run), tot = tiles + nP — so every CU holds
+// the same mix of HBM-bound and issue-bound waves from the first workgroup to the last, whatever the dispatcher does.
+// The host launches tiles + ceil(n_chunks / 4) workgroups (n_live is not known there); the ones past tot end at once.
+template <bool TF>
+__global__ __launch_bounds__(256, SGS_RENDER_WGS) void k_fused(const FrameSlot SR, const FrameSlot SP, const float4* __restrict__ geom,
+                                                               const float4* __restrict__ shq) {
+    const unsigned b = blockIdx.x;
+    const unsigned n_live = SP.st->n_live;
+    const unsigned nP = (n_live + 3u) >> 2;
+    const unsigned nR = (unsigned)((SR.P.row_end - SR.P.row_begin) * SR.P.gx);
+    const unsigned tot = nR + nP;
+    if (b >= tot) return;                                      // (workgroup-uniform)
+    // floor(b nP / tot) for b and b + 1: a float estimate, corrected against the exact 64-bit products (uniform scalar work)
+    const float r_tot = 1.0f / (float)tot;
+    auto share = [&](unsigned x) {
+        const unsigned long long lhs = (unsigned long long)x * nP;
+        unsigned e = (unsigned)((float)x * (float)nP * r_tot);
+        while ((unsigned long long)e * tot > lhs) --e;
+        while ((unsigned long long)(e + 1u) * tot <= lhs) ++e;
+        return e;
+    };
+    const unsigned ip0 = share(b), ip1 = share(b + 1u);
+    if (ip1 > ip0) {
+        const unsigned k0 = ip0 * 4u + (threadIdx.x >> 6);
+        if (k0 < n_live)                                       // (wave-uniform)
+            preprocess_chunk(SP.P, geom, shq, SP.splats, SP.vismask, SP.bigmask, SP.big_list, SP.binrec, SP.st, (long long)SP.live_list[k0],
+                             (int)(threadIdx.x & 63));
+        return;
+    }
+    render_tile<false, false, TF>(SR, b - ip0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -12,7 +12,14 @@ import os as _os
 # measured 3070 vs 4100 frames/s on the same box (profiles/r03y_*).  Eight queues keep the lanes, the caller's stream and an
 # exchange stream apart.  Read by the runtime when it initialises (the first HIP call of the process): set here, before the
 # renderer makes one; an application that initialises HIP earlier sets it itself.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# A process-wide side effect (torch's HIP runtime reads the same variable), so: never overriding a value the application set,
+# switched off by SAGE_GS_KEEP_ENV=1, and recorded in HW_QUEUES_SET_BY_PACKAGE / logged on the "sage_gs" logger.
+HW_QUEUES_SET_BY_PACKAGE = False
+if "GPU_MAX_HW_QUEUES" not in _os.environ and _os.environ.get("SAGE_GS_KEEP_ENV") != "1":
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    HW_QUEUES_SET_BY_PACKAGE = True
+    import logging as _logging
+    _logging.getLogger("sage_gs").info("GPU_MAX_HW_QUEUES=8 set for this process (SAGE_GS_KEEP_ENV=1 leaves the environment alone)")
 
 from . import _capi  # noqa: F401,E402
 from ._capi import SgsError  # noqa: F401,E402

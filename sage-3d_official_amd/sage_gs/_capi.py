@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+ABI_VERSION = 110        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
@@ -23,7 +24,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
                            "libsage_gs.so")
 
 # every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
-EXPORTS = ("sgs_version", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
+EXPORTS = ("sgs_version", "sgs_struct_sizes", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
            "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_free", "sgs_render",
            "sgs_render_rgbd", "sgs_render_batch", "sgs_render_batch_strided", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
 
@@ -78,6 +79,18 @@ class Lib:
         lib = self._lib = C.CDLL(path)
         vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
         lib.sgs_version.restype = i32
+        # the structs below are restated by hand: a library built from another header (other sizes / strides) would write past
+        # them silently, so the binding refuses it here — before any call that takes a struct
+        if int(lib.sgs_version()) != ABI_VERSION:
+            raise ImportError(f"{path} reports ABI version {int(lib.sgs_version())}, this binding is written for {ABI_VERSION}: "
+                              "rebuild the library (make -C sage-3d_official_amd) or update sage_gs")
+        lib.sgs_struct_sizes.argtypes = [C.POINTER(C.c_int32)] * 3; lib.sgs_struct_sizes.restype = None
+        sz = (C.c_int32 * 3)()
+        lib.sgs_struct_sizes(C.cast(C.byref(sz, 0), C.POINTER(C.c_int32)), C.cast(C.byref(sz, 4), C.POINTER(C.c_int32)),
+                             C.cast(C.byref(sz, 8), C.POINTER(C.c_int32)))
+        mine = (C.sizeof(SgsCamera), C.sizeof(SgsConfig), C.sizeof(SgsStats))
+        if tuple(sz) != mine:
+            raise ImportError(f"{path}: struct sizes (camera, config, stats) = {tuple(sz)}, this binding's = {mine}")
         lib.sgs_config_default.argtypes = [C.POINTER(SgsConfig)]; lib.sgs_config_default.restype = None
         lib.sgs_create.argtypes = [i32, i32, C.POINTER(vp)]
         lib.sgs_destroy.argtypes = [vp]

@@ -407,12 +407,16 @@ class ShardedRenderer:
         # what the two batched gather buffers (+ the fp32 scratch of rgba8 output) will take on this rank
         esz = 1 if output == "rgba8" else 4
         ch = 4 if output == "rgba8" else 3
-        rows = height if self.g.rank == dst else min(height, self.g.max_band_rows * TILE)
-        need = 2 * self.batch * rows * width * ch * esz + (self.batch * min(height, self.g.max_band_rows * TILE) * width * 12 if output == "rgba8" else 0)
-        self.buffer_bytes = int(need)
+        band_rows = min(height, self.g.max_band_rows * TILE)
+        scratch = self.batch * band_rows * width * 12 if output == "rgba8" else 0
+        size = lambda rows: 2 * self.batch * rows * width * ch * esz + scratch
+        self.buffer_bytes = int(size(height if self.g.rank == dst else band_rows))
+        # The limit is checked against the LARGEST rank's need (rank dst holds whole frames) on EVERY rank: a check of the rank's own
+        # need would raise on dst alone and leave the others blocked in the collective below until the communicator times out.
+        need = size(height)
         if need > self.MAX_BUFFER_BYTES:
             raise ValueError(f"ShardedRenderer(batch={self.batch}) would hold {need / 2**30:.1f} GiB of gather buffers on rank "
-                             f"{self.g.rank} at {width}x{height}; use a smaller batch (MAX_BUFFER_BYTES = {self.MAX_BUFFER_BYTES >> 30} GiB)")
+                             f"{dst} at {width}x{height}; use a smaller batch (MAX_BUFFER_BYTES = {self.MAX_BUFFER_BYTES >> 30} GiB)")
         if self.world > 1:
             # create the communicator NOW, with every rank taking part: the framebuffer exchange is a group of point-to-point
             # operations in which a rank with an empty band takes no part, which is only safe on a communicator that exists

@@ -96,6 +96,23 @@ class Scene:
             pass
 
 
+def _rigid(views: np.ndarray) -> np.ndarray:
+    """[...,4,4] float64 views -> the same, with every 3x3 that is measurably off orthonormal AFTER the cast to fp32 (a view
+    composed or inverted in fp32: torch.linalg.inv of a c2w matrix, poses parsed from 6-digit text) replaced by the nearest
+    rotation (polar decomposition).  The C ABI wants the rows orthonormal to 1e-5 (include/sage_gs.h) and says so with an error at
+    enqueue time; a Python caller gets the projection instead.  Views already orthonormal to 2e-6 pass through bit for bit, and
+    one that is off by more than 1e-3 is not a pose with rounding noise: it is left alone and the library reports it."""
+    v = np.array(views, np.float64, copy=True)
+    flat = v.reshape(-1, 4, 4)
+    for m in flat:
+        r = m[:3, :3].astype(np.float32).astype(np.float64)
+        dev = np.abs(r @ r.T - np.eye(3)).max()
+        if 2.0e-6 < dev < 1.0e-3:
+            u, _, vt = np.linalg.svd(m[:3, :3])
+            m[:3, :3] = u @ vt
+    return v
+
+
 def _as_f32(t: torch.Tensor, device, shape_tail):
     if not isinstance(t, torch.Tensor):
         t = torch.as_tensor(np.asarray(t, np.float32))
@@ -163,6 +180,7 @@ class Renderer:
                           np.float64).reshape(4, 4)
         if scene.model_to_world is not None:
             view = view @ scene.model_to_world.reshape(4, 4)
+        view = _rigid(view)
         return _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                                  view.astype(np.float32).tolist())
 
@@ -179,6 +197,7 @@ class Renderer:
                                      np.float64).reshape(4, 4) for c in cameras])
         if scene.model_to_world is not None:
             views = views @ scene.model_to_world.reshape(4, 4)
+        views = _rigid(views)
         arr = np.zeros(b, cls._CAM_DTYPE)
         arr["width"] = [c.width for c in cameras]; arr["height"] = [c.height for c in cameras]
         arr["fx"] = [c.fx for c in cameras]; arr["fy"] = [c.fy for c in cameras]

@@ -308,6 +308,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)new int(0); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { delete (int*)s; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

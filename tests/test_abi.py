@@ -28,7 +28,10 @@ def test_header_and_binding_agree(lib):
 
 
 def test_version_and_default_config(lib):
-    assert lib.version() == 100
+    from sage_gs import _capi
+    assert lib.version() == _capi.ABI_VERSION == 110
+    hdr = open(os.path.join(ROOT, "include", "sage_gs.h")).read()
+    assert int(re.search(r"#define SGS_VERSION (\d+)", hdr).group(1)) == _capi.ABI_VERSION
     cfg = lib.default_config()
     assert abs(cfg.near_z - 0.2) < 1e-7 and abs(cfg.dilation - 0.3) < 1e-7 and abs(cfg.alpha_min - 1 / 255) < 1e-9
     assert abs(cfg.alpha_max - 0.99) < 1e-7 and abs(cfg.t_min - 1e-4) < 1e-10 and cfg.sh_degree == -1
@@ -39,6 +42,11 @@ def test_struct_layouts_match_the_header(lib):
     assert C.sizeof(_capi.SgsCamera) == 2 * 4 + 4 * 4 + 16 * 4
     assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4 + 2 * 4      # + tile_row_stride, tile_row_phase
     assert C.sizeof(_capi.SgsStats) == 120      # 5 i64, 4 i32, float[4], float, (pad), i64[4], i64 (d_super)
+    sz = (C.c_int32 * 3)()
+    p = lambda k: C.cast(C.byref(sz, 4 * k), C.POINTER(C.c_int32))
+    lib.sgs_struct_sizes(p(0), p(1), p(2))          # the sizes the LIBRARY was compiled with (Lib() has already refused a mismatch)
+    assert tuple(sz) == (C.sizeof(_capi.SgsCamera), C.sizeof(_capi.SgsConfig), C.sizeof(_capi.SgsStats))
+    lib.sgs_struct_sizes(None, None, None)
 
 
 def test_no_cpu_backend_and_no_silent_fallback(lib):
