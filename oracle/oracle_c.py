@@ -52,7 +52,8 @@ _libs = {}
 
 def _lib(real="f64"):
     if real not in _libs:
-        path = os.path.join(_HERE, f"liborc_{real}.so")
+        # ORC_LIB_SUFFIX=_asan: the sanitizer build of the checker (oracle/Makefile `asan`; scripts/oracle_asan.sh)
+        path = os.path.join(_HERE, f"liborc_{real}{os.environ.get('ORC_LIB_SUFFIX', '') if real == 'f64' else ''}.so")
         if not os.path.exists(path):
             build()
         lib = C.CDLL(path)

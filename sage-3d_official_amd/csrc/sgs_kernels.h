@@ -1612,6 +1612,12 @@ __device__ __forceinline__ float4 sgs_live_rect(unsigned long long m, float x0, 
 #define SGS_PASS_R 4                  // records per lane and trip of a pass over a long queue (loads in flight: the passes are latency-bound)
 #endif
 #define SGS_RANK_BUCKET_MAX 64        // bucket-local ranking walks at most this many records per lane
+#ifndef SGS_REFINE_SPAN
+#define SGS_REFINE_SPAN 1024          // records of a long queue's ordered copy that one refinement re-partitions (at least the bucket that asked)
+#endif
+#ifndef SGS_LAZY_WINDOWS
+#define SGS_LAZY_WINDOWS 2u           // windows a long queue fills by scanning itself before its bucket-ordered copy is made (k_tile_render)
+#endif
 
 // orders a wave's own LDS writes before its later LDS reads by OTHER lanes of the same wave
 __device__ __forceinline__ void wave_lds_sync() {
@@ -1638,7 +1644,8 @@ template <bool AUX, bool STATS, bool TF>
 __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned bx) {
     static_assert(TF || !AUX, "the coverage output needs the final transmittance");
     const FrameParams& P = S.P;
-    const uint4* __restrict__ tile_order = S.tile_order; const unsigned long long* __restrict__ rec = S.rec;
+    const uint4* __restrict__ tile_order = S.tile_order;
+    const unsigned long long* __restrict__ rec = S.rec; unsigned long long* rec_w = S.rec;    // (a long queue lends its own storage as scratch once it has been copied in bucket order)
     unsigned long long* alt = S.alt; unsigned long long* part = S.part; unsigned* sorted_out = S.sorted_out;
     const Splat* __restrict__ splats = S.splats;
     float* __restrict__ out_rgb = S.out_rgb; float* __restrict__ out_aux = S.out_aux;
@@ -1660,7 +1667,10 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     __shared__ unsigned s_bcnt[SGS_NB];               // bucket counts, then scatter cursors
     __shared__ unsigned s_ne_end[SGS_NB];             // non-empty buckets, in order: end offset in the queue
     __shared__ unsigned short s_ne_bkt[SGS_NB];       //                              bucket index
-    __shared__ unsigned s_wsum[4], s_wne[4], s_fill, s_kmn[4], s_kmx[4];
+    __shared__ unsigned s_wsum[4], s_wne[4], s_kmn[4], s_kmx[4];
+    __shared__ unsigned s_c_bcnt[SGS_NB], s_c_end[SGS_NB];    // the queue's own partition while a refinement is the current one
+    __shared__ unsigned short s_c_bkt[SGS_NB];
+    __shared__ unsigned s_cs[12];                              // ... and its scalars / the refinement's state (CS_*)
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
     __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
     __shared__ unsigned s_hyper[2];                   // the batch holds a splat with an indefinite conic: exact trips (by parity)
@@ -1726,13 +1736,22 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     // buckets cut from that sliver hold a handful of records each — the bucket-local rank below is then one or two trips
     // instead of ten, and a bucket too long for one batch (the slow paths) all but disappears.  Any monotone map is correct:
     // bucket(key) = 0 at or below klo, (key - klo) >> ksh above it, capped at SGS_NB - 1.
-    // A LONG queue (n > SGS_QCAP: it stays in HBM) whose FRONT bucket is still longer than one batch — a 640x480 frame's tile
-    // sees nine times the scene area of a 1080p tile: queues of 10-60 k records, hundreds per bucket — is partitioned again,
-    // over the key range of that bucket alone (refinement, below): keys under kdone are consumed and ignored from then on,
-    // everything behind the refined range collects in the last bucket until its turn comes.
-    unsigned klo = 0u, ksh = 0u, kdone = 0u, pbase = 0u;        // pbase: queue position of the current partition's first bucket
+    // A LONG queue (n > SGS_QCAP) is copied ONCE into `part` in bucket order (partition_range); a bucket of it that is still longer than one
+    // batch — a 640x480 frame's tile sees nine times the scene area of a 1080p tile: queues of 10-60 k records, hundreds per bucket — is
+    // partitioned again over ITS key range and ITS slice of the copy (refinement, below; the queue's own partition waits meanwhile).
+    unsigned klo = 0u, ksh = 0u, pbase = 0u;                    // pbase: queue position of the current partition's first bucket
+    // A long queue's bucket that is refined: the partition of ITS slice [.., fine_hi) is the current one, the queue's own partition waits in
+    // the s_c_* tables until the slice has been consumed.  This state (and the saved klo, ksh, pbase, n_ne, e_next) lives in LDS, s_cs[]: as
+    // registers its handful of values stayed live across the blend — the kernel's register peak — and cost 19 more spilled SGPRs and 3 VGPRs
+    // (r04n: +3 us on the 1080p composite, where one tile in six has a long queue and one in a thousand is ever refined).
+    // The ordered copy is made LAZILY (s_cs[7]): most long queues saturate their pixels inside the first window, which one scan of the queue
+    // fills.  A queue that asks for a second window, a refinement or the HBM sort is a tile that reads deep: it pays two more passes once
+    // (partition_range again: same buckets, same positions) and nothing per window after that.
+    enum { CS_KLO = 0, CS_KSH, CS_PBASE, CS_NNE, CS_ENEXT, CS_FINE_HI, CS_FINE, CS_ORDERED, CS_B1, CS_COUNT };
+#define SGS_CS(k) __builtin_amdgcn_readfirstlane(s_cs[k])
 #define SGS_BUCKET_OF(key) ((key) <= klo ? 0u : min((unsigned)(SGS_NB - 1), ((key) - klo) >> ksh))
     if (tid < 2) { s_any[tid] = 0; s_hyper[tid] = 0; }
+    if (tid < 12) s_cs[tid] = 0u;
     {
         const unsigned long long im = __ballot(inside);
         if (lane == 0) s_lrect[wave] = sgs_live_rect(im, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));
@@ -1760,27 +1779,51 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         }
         __syncthreads();
     };
-    // long queues: the histogram of the records not yet consumed (key >= kdone) under the current (klo, ksh); all threads
-    auto long_histogram = [&]() {
+    // Long queues: the partition of the records src[beg + a .. beg + b) under the current (klo, ksh) — histogram, scan (cursors from pbase = a),
+    // and the BUCKET-ORDERED COPY of those records into dst[beg + a ..): the cursors place every record, as the in-LDS scatter does for a
+    // short queue.  A window of the queue is then a contiguous slice of that copy — one coalesced read of <= 1024 records — and a bucket too
+    // long for one batch is refined by partitioning ITS slice again (below), not the queue.  Rounds 1-3 re-scanned the WHOLE queue per window
+    // and three times per refinement: a 640x480 tile sees nine times the scene area of a 1080p one, a 320x240 tile thirty-six times; their
+    // queues hold 10-100 k records, their pixels take 30-200 batches to saturate, and the re-scans were quadratic (r04h / r04l: 70 windows
+    // and 78 refinements = 12.7 M of the slowest 320x240 tile's 14.9 M cycles; 0.8 M of 2.0 M at 640x480).  (Scattered 8-byte stores
+    // amplify — 32 B each — but this is one pass per partition.)  All threads.
+    // scatter_only: the histogram and the cursors of this very partition are still in place (nothing, or only the buckets up to `skip`, has been
+    // placed with them: the queue's first window) — only the copy is made, of the buckets after `skip`.
+    auto partition_range = [&](const unsigned long long* src, unsigned a, unsigned b, unsigned long long* dst, bool scatter_only, int skip) {
         int tid_l = tid_entry; SGS_PIN_VGPR(tid_l);
         const int tid = tid_l;
+        if (!scatter_only) {
         s_bcnt[tid] = 0;
         __syncthreads();
-        for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {                 // SGS_PASS_R loads in flight per lane
+        for (unsigned i0 = a; i0 < b; i0 += 256u * SGS_PASS_R) {                 // SGS_PASS_R loads in flight per lane
             unsigned long long x[SGS_PASS_R];
 #pragma unroll
             for (int r = 0; r < SGS_PASS_R; ++r) {
                 const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
-                x[r] = i < n ? rec[beg + i] : ~0ull;
+                x[r] = i < b ? src[beg + i] : ~0ull;
             }
 #pragma unroll
-            for (int r = 0; r < SGS_PASS_R; ++r) {
-                const unsigned key = (unsigned)(x[r] >> 32);
-                if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone) atomicAdd(&s_bcnt[SGS_BUCKET_OF(key)], 1u);
-            }
+            for (int r = 0; r < SGS_PASS_R; ++r)
+                if (i0 + (unsigned)tid + 256u * (unsigned)r < b) atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(x[r] >> 32))], 1u);
         }
         __syncthreads();
         scan_buckets();
+        }
+        if (dst == nullptr) return;      // (histogram + scan only: the queue's FIRST window is filled by a scan of the queue, see below)
+        for (unsigned i0 = a; i0 < b; i0 += 256u * SGS_PASS_R) {
+            unsigned long long x[SGS_PASS_R];
+#pragma unroll
+            for (int r = 0; r < SGS_PASS_R; ++r) {
+                const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                x[r] = i < b ? src[beg + i] : ~0ull;
+            }
+#pragma unroll
+            for (int r = 0; r < SGS_PASS_R; ++r) {
+                const unsigned bk = SGS_BUCKET_OF((unsigned)(x[r] >> 32));
+                if (i0 + (unsigned)tid + 256u * (unsigned)r < b && (int)bk > skip) dst[beg + atomicAdd(&s_bcnt[bk], 1u)] = x[r];
+            }
+        }
+        __syncthreads();                 // (cursors are bucket ENDS now, as after the in-LDS scatter: the ranking reads them)
     };
     {
         unsigned long long rq[4];                      // the queue (n <= SGS_QCAP), or its first SGS_QCAP records: a sample of its depths
@@ -1828,7 +1871,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                         atomicAdd(&s_bcnt[SGS_BUCKET_OF((unsigned)(rq[r] >> 32))], 1u);
                 __syncthreads();
                 scan_buckets();
-            } else long_histogram();
+            } else partition_range(rec, 0u, n, nullptr, false, -1);
             if (in_lds) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1854,6 +1897,8 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     unsigned e_next = 0, lo = 0;         // next non-empty bucket (index into s_ne_*) / its queue position
     unsigned win_lo = 0, win_hi = in_lds ? n : 0u;   // queue range resident in s_q (the whole queue when it fits)
     unsigned n_refine = 0u, no_refine_at = 0xffffffffu;
+    unsigned n_fill = 0u;                // windows of a long queue filled so far (uniform; reported by the profiling build)
+    (void)n_refine; (void)n_fill;
     while (lo < n && (!tile_done || full_sort)) {
         // Everything a group derives from the thread index is derived HERE, per group, from a copy the compiler cannot see
         // through: hoisted out of the loop, the dozen index expressions, LDS addresses and pixel coordinates below stayed live
@@ -1861,6 +1906,14 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         // writes per 1080p frame, as much as the kernel's whole algorithmic traffic (r03c).
         int tid_group = tid_entry; SGS_PIN_VGPR(tid_group);
         const int tid = tid_group, lane = tid & 63, wave = tid >> 6;
+        if (!in_lds && SGS_CS(CS_FINE) != 0u && lo >= SGS_CS(CS_FINE_HI)) {     // the refined slice has been consumed: the queue's own
+            s_bcnt[tid] = s_c_bcnt[tid]; s_ne_end[tid] = s_c_end[tid]; s_ne_bkt[tid] = s_c_bkt[tid];   // partition again, at the bucket after it
+            klo = SGS_CS(CS_KLO); ksh = SGS_CS(CS_KSH); pbase = SGS_CS(CS_PBASE); n_ne = SGS_CS(CS_NNE); e_next = SGS_CS(CS_ENEXT);
+            win_lo = lo; win_hi = lo;
+            __syncthreads();             // (every thread has read the state)
+            if (tid == 0) s_cs[CS_FINE] = 0u;
+            __syncthreads();
+        }
         const float lx = (float)((unsigned)(wave & 1) * 8u + (unsigned)(lane & 7)), ly = (float)((unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3));
         unsigned hi, e0 = e_next, e1 = e_next;
         if (!parted) hi = n;
@@ -1883,49 +1936,85 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
             hi = s_ne_end[e1];
             e_next = e1 + 1;
         }
-        if (parted && !in_lds && e1 == e0 && hi - lo > (unsigned)SGS_BATCH && n_refine < 255u && lo != no_refine_at) {
-            // REFINEMENT: the front bucket of a long queue holds more than one batch.  One pass finds the key range of
-            // that bucket's records, a second one partitions the queue over it — 256 buckets across what was one —
-            // instead of sorting the whole bucket (the rank-sort / HBM-radix paths below, kept for the bucket whose keys
-            // are all equal).
-            const unsigned g = s_ne_bkt[e0];
-            unsigned kmn = 0xffffffffu, kmx = 0u;
-            for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {
-                unsigned long long x[SGS_PASS_R];
+        if (parted && !in_lds) {
+            // Two things a long queue may need before this group can be taken, both ONE partition_range (one instance of its code: the
+            // kernel's instruction footprint is what a 1080p frame pays for it):
+            //   (1) the ordered copy itself — when the group is not resident and the first window has been used, when its bucket wants
+            //       refining, or when it is longer than the LDS holds (HBM sort): partition the queue into `part`, then select the group again;
+            //   (2) REFINEMENT — the group is ONE bucket that holds more than a batch: its records are the slice [lo, hi) of the copy; one
+            //       pass over the SLICE finds their key range, partition_range cuts 256 buckets from it and orders the slice into `alt`
+            //       (instead of sorting the whole bucket: the rank-sort / HBM-radix paths below, kept for the bucket whose keys are all equal).
+            const bool want_refine = e1 == e0 && hi - lo > (unsigned)SGS_BATCH && lo != no_refine_at && SGS_CS(CS_FINE) == 0u;
+            const bool have_copy = SGS_CS(CS_ORDERED) != 0u;
+            const unsigned long long* p_src = rec; unsigned long long* p_dst = part;
+            unsigned p_a = 0u, p_b = n;
+            bool go = !have_copy && (want_refine || hi - lo > (unsigned)SGS_QCAP || (hi > win_hi && n_fill >= SGS_LAZY_WINDOWS));
+            if (!go && want_refine) {
+                // the slice that is refined: this bucket and as many of the buckets behind it as keep it within SGS_REFINE_SPAN records — a
+                // depth range dense enough to overfill one bucket usually overfills its neighbours too (a wall, a shelf), and one
+                // refinement per bucket would pay the fixed cost of a partition (its barriers, the scan, the tables) each time; the span
+                // bounds what a refinement costs on a queue of 100 k records
+                unsigned rfit = 0;
 #pragma unroll
-                for (int r = 0; r < SGS_PASS_R; ++r) {
-                    const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
-                    x[r] = i < n ? rec[beg + i] : ~0ull;
+                for (int r = 0; r < SGS_NB / 64; ++r) {
+                    const unsigned e = e0 + 1u + (unsigned)(r * 64 + lane);
+                    rfit += (unsigned)__popcll(__ballot(e < n_ne && s_ne_end[e] - lo <= (unsigned)SGS_REFINE_SPAN));
                 }
+                const unsigned ek = e0 + rfit;
+                const unsigned hi_r = s_ne_end[ek];
+                unsigned kmn = 0xffffffffu, kmx = 0u;
+                for (unsigned i0 = lo; i0 < hi_r; i0 += 256u * SGS_PASS_R) {
+                    unsigned long long x[SGS_PASS_R];
 #pragma unroll
-                for (int r = 0; r < SGS_PASS_R; ++r) {
-                    const unsigned key = (unsigned)(x[r] >> 32);
-                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && SGS_BUCKET_OF(key) == g) {
-                        kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
+                    for (int r = 0; r < SGS_PASS_R; ++r) {
+                        const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                        x[r] = i < hi_r ? part[beg + i] : ~0ull;
+                    }
+#pragma unroll
+                    for (int r = 0; r < SGS_PASS_R; ++r) {
+                        const unsigned key = (unsigned)(x[r] >> 32);
+                        if (i0 + (unsigned)tid + 256u * (unsigned)r < hi_r) { kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx; }
                     }
                 }
+                kmn = wave_min(kmn); kmx = wave_max(kmx);
+                __syncthreads();                          // (s_kmn / s_kmx: everyone is past their last use)
+                if (lane == 0) { s_kmn[wave] = kmn; s_kmx[wave] = kmx; }
+                __syncthreads();
+                kmn = min(min(s_kmn[0], s_kmn[1]), min(s_kmn[2], s_kmn[3])); kmx = max(max(s_kmx[0], s_kmx[1]), max(s_kmx[2], s_kmx[3]));
+                if (kmx > kmn) {
+                    s_c_bcnt[tid] = s_bcnt[tid]; s_c_end[tid] = s_ne_end[tid]; s_c_bkt[tid] = s_ne_bkt[tid];      // the queue's own partition waits
+                    if (tid == 0) {
+                        s_cs[CS_KLO] = klo; s_cs[CS_KSH] = ksh; s_cs[CS_PBASE] = pbase; s_cs[CS_NNE] = n_ne; s_cs[CS_ENEXT] = ek + 1u;
+                        s_cs[CS_FINE_HI] = hi_r; s_cs[CS_FINE] = 1u;
+                    }
+                    const unsigned span = kmx - kmn;
+                    klo = kmn; ksh = span < (unsigned)SGS_NB ? 0u : 24u - (unsigned)__clz((int)span);
+                    pbase = lo;
+                    p_src = part; p_dst = alt; p_a = lo; p_b = hi_r;
+                    go = true;
+                    ++n_refine;
+                } else no_refine_at = lo;                 // all keys equal: the sorting paths order them by index
             }
-            kmn = wave_min(kmn); kmx = wave_max(kmx);
-            __syncthreads();                          // (s_kmn / s_kmx: everyone is past their last use)
-            if (lane == 0) { s_kmn[wave] = kmn; s_kmx[wave] = kmx; }
-            __syncthreads();
-            kmn = min(min(s_kmn[0], s_kmn[1]), min(s_kmn[2], s_kmn[3])); kmx = max(max(s_kmx[0], s_kmx[1]), max(s_kmx[2], s_kmx[3]));
-            if (kmx > kmn) {
-                const unsigned span = kmx - kmn;
-                kdone = kmn; klo = kmn; ksh = span < (unsigned)SGS_NB ? 0u : 24u - (unsigned)__clz((int)span);
-                pbase = lo;
-                long_histogram();
-                e_next = 0; win_lo = lo; win_hi = lo;     // nothing of the new partition is resident
-                ++n_refine;
+            if (go) {
+                // (1) re-uses the queue's histogram and cursors where they still stand: before any window (nothing placed), or for a group
+                // behind the first window (the buckets up to its last one, s_cs[CS_B1], have been placed and consumed)
+                const bool copy_only = p_dst == part && (n_fill == 0u || lo >= win_hi);
+                partition_range(p_src, p_a, p_b, p_dst, copy_only, copy_only && n_fill != 0u ? (int)SGS_CS(CS_B1) : -1);
+                if (p_dst == part) {                      // (1): the same group again, now from the copy
+                    if (tid == 0) s_cs[CS_ORDERED] = 1u;
+                    e_next = e0;
+                    __syncthreads();                      // (the flag is read by every thread right after the group has been selected)
+                }
+                else e_next = 0;                                                             // (2): the slice's first bucket
+                win_lo = lo; win_hi = lo;                 // nothing of the current partition is resident
                 continue;
             }
-            no_refine_at = lo;                        // all keys equal: the sorting paths order them by index
         }
         const unsigned cnt = hi - lo;
         const unsigned* gv = nullptr;    // the group's slots in (depth, index) order
         if (cnt <= SGS_QCAP && hi > win_hi) {
             // long queue, group not resident: slide the window to start at this group and take as many whole
-            // buckets as fit.  Each bucket is placed exactly once, so the partition cursors stay valid.
+            // buckets as fit
             unsigned wfit = 0;                                        // same prefix count, for the window's capacity
 #pragma unroll
             for (int r = 0; r < SGS_NB / 64; ++r) {
@@ -1933,20 +2022,38 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                 wfit += (unsigned)__popcll(__ballot(e < n_ne && s_ne_end[e] - lo <= (unsigned)SGS_QCAP));
             }
             const unsigned ew = e1 + wfit;
-            const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[ew];
             win_lo = lo; win_hi = s_ne_end[ew];
-            for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {
-                unsigned long long x[SGS_PASS_R];
+            ++n_fill;
+            if (SGS_CS(CS_ORDERED) == 0u) {               // (n_fill <= SGS_LAZY_WINDOWS: the copy is made before a later window)
+                // one of the queue's first windows: one coalesced scan of the queue places the records of its buckets with the bucket cursors
+                const unsigned b0 = s_ne_bkt[e0], b1 = s_ne_bkt[ew];
+                if (tid == 0) s_cs[CS_B1] = b1;
+                for (unsigned i0 = 0; i0 < n; i0 += 256u * SGS_PASS_R) {
+                    unsigned long long x[SGS_PASS_R];
 #pragma unroll
-                for (int r = 0; r < SGS_PASS_R; ++r) {
-                    const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
-                    x[r] = i < n ? rec[beg + i] : ~0ull;
+                    for (int r = 0; r < SGS_PASS_R; ++r) {
+                        const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
+                        x[r] = i < n ? rec[beg + i] : ~0ull;
+                    }
+#pragma unroll
+                    for (int r = 0; r < SGS_PASS_R; ++r) {
+                        const unsigned bk = SGS_BUCKET_OF((unsigned)(x[r] >> 32));
+                        if (i0 + (unsigned)tid + 256u * (unsigned)r < n && bk >= b0 && bk <= b1)
+                            s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
+                    }
+                }
+            } else {   // the window = a slice of the bucket-ordered copy (partition_range)
+                const unsigned long long* src_w = SGS_CS(CS_FINE) != 0u ? alt : part;
+                unsigned long long x[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned i = (unsigned)tid + 256u * (unsigned)r;
+                    x[r] = i < win_hi - win_lo ? src_w[beg + win_lo + i] : ~0ull;
                 }
 #pragma unroll
-                for (int r = 0; r < SGS_PASS_R; ++r) {
-                    const unsigned key = (unsigned)(x[r] >> 32), bk = SGS_BUCKET_OF(key);
-                    if (i0 + (unsigned)tid + 256u * (unsigned)r < n && key >= kdone && bk >= b0 && bk <= b1)
-                        s_q[atomicAdd(&s_bcnt[bk], 1u) - win_lo] = x[r];
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned i = (unsigned)tid + 256u * (unsigned)r;
+                    if (i < win_hi - win_lo) s_q[i] = x[r];
                 }
             }
             if (tid < 8) s_q[win_hi - win_lo + tid] = ~0ull;
@@ -2060,35 +2167,22 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                 __syncthreads();         // s_sorted is rewritten by the next group when the blend is skipped
             }
         } else {
-            // One oversized bucket of a long queue: radix sort through HBM.  The bucket's records are filtered
-            // out of the queue and split into a key half and a slot half inside two scratch spans.
+            // One oversized bucket of a long queue (keys all equal, or more than the LDS holds): radix sort through HBM.
             const unsigned g0 = s_ne_bkt[e0], g1 = s_ne_bkt[e1];
             // buckets g0..g1 hold the keys [klo + (g0 << ksh), klo + ((g1 + 1) << ksh)); the first and the last bucket are open-ended
             unsigned sub = klo + (g0 << ksh);
             unsigned nbits = ksh + (32u - (unsigned)__clz((int)(g1 - g0 + 1u)));
             if (g0 == 0u || g1 == SGS_NB - 1 || nbits >= 32u) { sub = 0u; nbits = 32u; }
-            // alt[beg+lo, +cnt) and part[beg+lo, +cnt) are private to this bucket (cnt 8-byte slots = keys[cnt] | slots[cnt]).
-            unsigned* b_k = reinterpret_cast<unsigned*>(alt + beg + lo); unsigned* b_v = b_k + cnt;     // keys[cnt] | slots[cnt]
-            unsigned* a_k = reinterpret_cast<unsigned*>(part + beg + lo); unsigned* a_v = a_k + cnt;    // ping-pong space
-            if (tid == 0) s_fill = 0;
-            __syncthreads();
-            for (unsigned i0 = 0; i0 < n; i0 += 256) {
-                const unsigned i = i0 + (unsigned)tid;
-                unsigned long long x = 0ull;
-                bool take = false;
-                if (i < n) {
-                    x = rec[beg + i];
-                    const unsigned key = (unsigned)(x >> 32), bk = SGS_BUCKET_OF(key);
-                    take = key >= kdone && bk >= g0 && bk <= g1;
-                }
-                const unsigned long long m = __ballot(take);
-                unsigned base = 0;
-                if (lane == 0 && m != 0ull) base = atomicAdd(&s_fill, (unsigned)__popcll(m));
-                base = __shfl(base, 0);
-                if (take) {
-                    const unsigned pos = base + (unsigned)__popcll(m & lanemask_lt(lane));
-                    b_k[pos] = (unsigned)(x >> 32); b_v[pos] = (unsigned)x;
-                }
+            // The group's records are the slice [lo, hi) of the current ordered copy (`part`, or `alt` inside a refined bucket).  They are
+            // split into a key half and a slot half in the OTHER of the two buffers (that slice of it holds a stale order of the same
+            // records), and the queue itself — every record of it lives in the ordered copy by now — lends the ping-pong space.
+            const bool fine = SGS_CS(CS_FINE) != 0u;
+            const unsigned long long* src_g = fine ? alt : part;
+            unsigned* b_k = reinterpret_cast<unsigned*>((fine ? part : alt) + beg + lo); unsigned* b_v = b_k + cnt;     // keys[cnt] | slots[cnt]
+            unsigned* a_k = reinterpret_cast<unsigned*>(rec_w + beg + lo); unsigned* a_v = a_k + cnt;                   // ping-pong space
+            for (unsigned i = (unsigned)tid; i < cnt; i += 256u) {
+                const unsigned long long x = src_g[beg + lo + i];
+                b_k[i] = (unsigned)(x >> 32); b_v[i] = (unsigned)x;
             }
             __syncthreads();
             sort_segment(b_k, b_v, a_k, a_v, cnt, sub, nbits, sh, splats, P.n, st);
@@ -2162,7 +2256,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
         o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = pt_job;
-        o[20] = pt_rec; o[21] = 0; o[22] = 0; o[23] = 0;
+        o[20] = pt_rec; o[21] = n_refine; o[22] = n_fill; o[23] = 0;
     }
 #endif
     {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)

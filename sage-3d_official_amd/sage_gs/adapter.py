@@ -58,8 +58,11 @@ class GsCamera:
         return self._r.render(self._camera(), self._scene, config=self._config)
 
     def get_rgba(self) -> np.ndarray:
-        """uint8 [H,W,4], alpha 255 — what `cam.get_rgba()` returns (simple_env.py:1380; generate_images.py:428)."""
-        return self._r.pack_rgba8(self.get_rgb_tensor()).cpu().numpy()
+        """uint8 [H,W,4], alpha 255 — what `cam.get_rgba()` returns (simple_env.py:1380; generate_images.py:428).  Render, pack and
+        the copy into a PINNED host buffer are one stream-ordered sequence with a single wait (Renderer.render_rgba8_host); the
+        array is renderer-owned, as Isaac Sim's is: callers copy what they keep (generate_images.py:431 `.copy()`,
+        simple_env.py:1386 `.astype`), and it stays valid until the next-but-one frame."""
+        return self._r.render_rgba8_host(self._camera(), self._scene, config=self._config)
 
     def _rgb_depth(self):
         """(rgb [H,W,3] float32 on the GPU, depth [H,W] float32 on the GPU): depth = the scene's expected view depth along

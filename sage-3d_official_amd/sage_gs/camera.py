@@ -68,6 +68,31 @@ def view_from_isaac_pose(position: Sequence[float], orientation_wxyz: Sequence[f
     return V
 
 
+def isaac_pose_from_view(view) -> tuple:
+    """Inverse of view_from_isaac_pose: (position [3], orientation (w,x,y,z)) of the `cam.set_world_pose` call that gives this
+    world->camera matrix (rows right, down, forward).  Lets pose lists kept as view matrices (scenes.room_cameras) drive a GsCamera."""
+    V = np.asarray(view, np.float64).reshape(4, 4)
+    rot = V[:3, :3]
+    pos = -rot.T @ V[:3, 3]
+    fwd, up = rot[2], -rot[1]
+    left = np.cross(up, fwd)
+    R = np.stack([fwd, left, up], 1)                        # columns: the camera's +X (forward), +Y (left), +Z (up) in the world
+    tr = R[0, 0] + R[1, 1] + R[2, 2]
+    if tr > 0:
+        s = math.sqrt(tr + 1.0) * 2
+        q = [0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s]
+    elif R[0, 0] >= R[1, 1] and R[0, 0] >= R[2, 2]:
+        s = math.sqrt(1.0 + R[0, 0] - R[1, 1] - R[2, 2]) * 2
+        q = [(R[2, 1] - R[1, 2]) / s, 0.25 * s, (R[0, 1] + R[1, 0]) / s, (R[0, 2] + R[2, 0]) / s]
+    elif R[1, 1] >= R[2, 2]:
+        s = math.sqrt(1.0 + R[1, 1] - R[0, 0] - R[2, 2]) * 2
+        q = [(R[0, 2] - R[2, 0]) / s, (R[0, 1] + R[1, 0]) / s, 0.25 * s, (R[1, 2] + R[2, 1]) / s]
+    else:
+        s = math.sqrt(1.0 + R[2, 2] - R[0, 0] - R[1, 1]) * 2
+        q = [(R[1, 0] - R[0, 1]) / s, (R[0, 2] + R[2, 0]) / s, (R[1, 2] + R[2, 1]) / s, 0.25 * s]
+    return pos, np.asarray(q, np.float64)
+
+
 def datagen_pose(point: dict):
     """(position, orientation) exactly as generate_images.py:417-421 passes them to the camera."""
     pos = [float(v) for v in point["position"]]

@@ -391,6 +391,37 @@ class Renderer:
                                                  self._stream()), self._ctx)
         return out
 
+    # -- host frames (the boundary the reference really has: uint8 arrays on the host) -----------------------------------------
+    def host_frames(self, shape, depth: int = 2) -> "HostFrames":
+        """A ring of `depth` PINNED uint8 host buffers of `shape` (+ their device-side uint8 twins, a copy stream and events):
+        what get_rgba()-shaped callers read frames from.  Cached per (shape, depth)."""
+        key = (tuple(int(v) for v in shape), int(depth))
+        ring = self._host_rings.get(key) if hasattr(self, "_host_rings") else None
+        if ring is None:
+            if not hasattr(self, "_host_rings"):
+                self._host_rings = {}
+            ring = self._host_rings[key] = HostFrames(self, key[0], key[1])
+        return ring
+
+    def render_rgba8_host(self, camera: Camera, gaussians, *, config: Optional[RenderConfig] = None, tonemap: Optional[str] = None) -> np.ndarray:
+        """One frame as the reference's callers receive it: uint8 [H,W,4] (alpha 255) in HOST memory (simple_env.py:1380-1386;
+        generate_images.py:428-431).  Render, pack and copy are enqueued back to back on the current stream — the copy lands in a
+        pinned buffer (no pageable staging copy, no second synchronisation) — and the call waits once.  The array is renderer-owned
+        and stays valid until the next-but-one call at this resolution (the reference's callers copy what they keep)."""
+        scene = self._scene_of(gaussians)
+        ring = self.host_frames((camera.height, camera.width, 4))
+        rgb = self.render(camera, scene, config=config, out=ring.rgb_scratch(), sync=False)
+        h = ring.submit(rgb, tonemap=tonemap)
+        try:
+            self.sync()                  # the frame's status — and, stream-ordered behind it, pack + copy
+        except _capi.SgsError as e:
+            if e.code != -4:             # SGS_ERR_OVERFLOW: an asynchronous frame cannot grow the queues; a synchronous one does
+                raise
+            h.wait()
+            rgb = self.render(camera, scene, config=config, out=ring.rgb_scratch(), sync=True)
+            h = ring.submit(rgb, tonemap=tonemap)
+        return h.wait()
+
     # -- test hooks -------------------------------------------------------------------------------
     def debug_buffer(self, what, dtype):
         have = self._lib.sgs_debug_read(self._ctx, what, None, 0)
@@ -423,6 +454,56 @@ class Renderer:
             self.close()
         except Exception:
             pass
+
+
+class HostFrames:
+    """`depth` pinned uint8 host buffers + device twins of one shape, a D2H copy stream and one event per buffer.
+    submit(rgb) packs fp32 -> uint8 RGBA on the CURRENT stream and starts the copy into the next pinned buffer on the copy
+    stream (behind an event), so that the copy of frame i overlaps whatever the current stream does next (the rendering of
+    frame i+1); wait() on the returned handle blocks until THAT copy has landed and returns the numpy view."""
+
+    class Handle:
+        def __init__(self, ring, k, n):
+            self._ring, self._k, self._n = ring, k, n
+
+        def wait(self) -> np.ndarray:
+            self._ring._done[self._k].synchronize()
+            a = self._ring._host_np[self._k]
+            return a if self._n is None else a[:self._n]
+
+    def __init__(self, renderer: "Renderer", shape, depth: int):
+        self._r, self.shape, self.depth = renderer, tuple(shape), int(depth)
+        dev = renderer.device
+        self._dev = [torch.empty(self.shape, dtype=torch.uint8, device=dev) for _ in range(self.depth)]
+        self._host = [torch.empty(self.shape, dtype=torch.uint8, pin_memory=True) for _ in range(self.depth)]
+        self._host_np = [t.numpy() for t in self._host]
+        self._packed = [torch.cuda.Event() for _ in range(self.depth)]
+        self._done = [torch.cuda.Event() for _ in range(self.depth)]
+        self._copy_stream = torch.cuda.Stream(device=dev)
+        self._turn = 0
+        self._rgb = None
+
+    def rgb_scratch(self) -> torch.Tensor:
+        """An fp32 [..., 3] device buffer of the ring's image shape to render into (one: the pack consumes it in stream order)."""
+        if self._rgb is None:
+            self._rgb = torch.zeros(self.shape[:-1] + (3,), dtype=torch.float32, device=self._r.device)
+        return self._rgb
+
+    def submit(self, rgb: torch.Tensor, tonemap: Optional[str] = None, n: Optional[int] = None) -> "HostFrames.Handle":
+        """rgb: fp32 [..., 3] of the ring's image shape (a batch [B,H,W,3] counts as one tall image).  n: leading entries that are
+        valid (a partial last batch)."""
+        k = self._turn
+        self._turn = (k + 1) % self.depth
+        self._done[k].synchronize()                  # the buffer's previous copy (depth frames ago) has long landed
+        flat = rgb.reshape(-1, rgb.shape[-2], 3)
+        self._r.pack_rgba8(flat, tonemap=tonemap, out=self._dev[k].reshape(-1, rgb.shape[-2], 4))
+        cur = torch.cuda.current_stream(self._r.device)
+        self._packed[k].record(cur)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(self._packed[k])
+            self._host[k].copy_(self._dev[k], non_blocking=True)
+            self._done[k].record(self._copy_stream)
+        return HostFrames.Handle(self, k, n)
 
 
 _default = {}

@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
-os.environ.setdefault("SAGE_GS_LIB", os.path.join(ROOT, "sage-3d_official_amd", "lib", "libsage_gs_prof.so"))
+os.environ.setdefault("SAGE_GS_LIB", os.path.join(ROOT, "build", "lib", "libsage_gs_prof.so"))
 import numpy as np, torch
 from sage_gs import Renderer, scenes
 sc = scenes.cached_room(3_000_000, seed=2)

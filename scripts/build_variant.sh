@@ -1,12 +1,12 @@
 #!/bin/bash
 # scripts/build_variant.sh <git-rev|WORK> <name> [extra hipcc flags...]
 #   compiles the library from the sources of a git revision (or of the working tree) into
-#   sage-3d_official_amd/lib/variants/<name>.so, for A/B runs in ONE GPU-box visit (box-to-box variance is +-1.5 %):
-#   SAGE_GS_LIB=sage-3d_official_amd/lib/variants/<name>.so python scripts/r02_probe.py quick
+#   build/variants/<name>.so, for A/B runs in ONE GPU-box visit (box-to-box variance is +-1.5 %):
+#   SAGE_GS_LIB=build/variants/<name>.so python scripts/r02_probe.py quick
 set -e
 REV=$1; NAME=$2; shift 2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/sage-3d_official_amd/lib/variants; mkdir -p $OUT
+OUT=$ROOT/build/variants; mkdir -p $OUT
 TMP=$(mktemp -d)
 mkdir -p $TMP/pkg/csrc $TMP/include
 if [ "$REV" = WORK ]; then

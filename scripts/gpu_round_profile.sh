@@ -44,7 +44,7 @@ passes() { # set skip flags...
   python $ROOT/scripts/pmc_summary.py $OUT/pmc_$set $skip > $OUT/pmc_summary_$set.json
 }
 echo "== lane use of the composite (profiling build, the driver's first poses)"
-(cd $ROOT && make -s -C sage-3d_official_amd lib/libsage_gs_prof.so >/dev/null 2>&1; POSES=$(python -c "print(','.join(str((i*77)%256) for i in range(5,25)))") timeout 300 python scripts/tile_prof.py > $OUT/tile_prof_k20.txt 2>/dev/null; grep TOTAL $OUT/tile_prof_k20.txt | cut -c1-300)
+(cd $ROOT && make -s -C sage-3d_official_amd prof >/dev/null 2>&1; POSES=$(python -c "print(','.join(str((i*77)%256) for i in range(5,25)))") timeout 300 python scripts/tile_prof.py > $OUT/tile_prof_k20.txt 2>/dev/null; grep TOTAL $OUT/tile_prof_k20.txt | cut -c1-300)
 echo "== trained-like scene, bench line"; timeout 600 python $ROOT/bench.py --scene-kind trained --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trained_k20.json 2> $OUT/bench_trained.err; tail -c 200 $OUT/bench_trained_k20.json
 echo "== PMC passes (default pose set)"; passes default 10
 echo "== PMC passes (driver's pose set)"; passes k20 5 --steps 20 --warmup 5
@@ -81,6 +81,14 @@ out["_note"] = ("per pose set (bench.py config.pose_set): HBM bytes per launch =
                 "--kernel-trace only), FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM and this repo's own calibration (profiles/r01_hbm_calib_*.csv: "
                 "2 GiB streamed reads report 1 GiB at 16 and at 4 B/lane; streamed writes are exact); averaged over the launches of the bench "
                 "command's frames (warm-up launches skipped), one frame at a time")
+import subprocess, sys
+sys.path.insert(0, "$ROOT")
+import bench
+out["_kernel_sha"] = bench.kernel_sha()           # bench.py quotes these figures only while csrc/ hashes to this
+try:
+    out["_commit"] = subprocess.check_output(["git", "-C", "$ROOT", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    out["_commit"] = os.environ.get("SGS_COMMIT")  # (the GPU box has no .git: the caller passes the commit)
 json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
 print(json.dumps({k: (v if k.startswith("_") else {s: v[s] for s in ("preprocess", "count", "emit", "render")}) for k, v in out.items() if k != "_note"}, indent=1))
 PY

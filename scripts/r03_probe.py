@@ -18,7 +18,7 @@ STAGES = ("preprocess", "count", "emit", "render")
 tag = os.path.basename(os.environ.get("SAGE_GS_LIB", "default"))
 for (W, H) in res:
     cams = scenes.room_cameras(sc, W, H, n_positions=4, n_yaw=64, seed=2)
-    poses = [(i * 77) % 256 for i in range(5, 29)]
+    poses = [(i * 77) % 256 for i in range(5, 5 + int(os.environ.get("NPOSES", 24)))]
     out = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     for p in poses[:4]:
         r.render(cams[p], gs, out=out)
@@ -32,4 +32,4 @@ for (W, H) in res:
     for p in poses:
         t0 = time.perf_counter(); r.render(cams[p], gs, out=out); lat.append(1e3 * (time.perf_counter() - t0))
     n = len(poses)
-    print(f"{tag} {kind} {W}x{H}: alone us { {s: round(1e3 * acc[s] / n, 1) for s in STAGES} } N_v={dv // n} D={d // n} | latency ms p50 {np.percentile(lat, 50):.3f} p90 {np.percentile(lat, 90):.3f}", flush=True)
+    print(f"{tag} {kind} {W}x{H} ({n} poses): alone us { {s: round(1e3 * acc[s] / n, 1) for s in STAGES} } N_v={dv // n} D={d // n} | latency ms p50 {np.percentile(lat, 50):.3f} p90 {np.percentile(lat, 90):.3f}", flush=True)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Per-tile phase breakdown of k_tile_render (profiling build lib/libsage_gs_prof.so).  Run on the GPU box."""
+"""Per-tile phase breakdown of k_tile_render (profiling build build/lib/libsage_gs_prof.so).  Run on the GPU box."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
-os.environ["SAGE_GS_LIB"] = os.path.join(ROOT, "sage-3d_official_amd", "lib", "libsage_gs_prof.so")
+os.environ["SAGE_GS_LIB"] = os.path.join(ROOT, "build", "lib", "libsage_gs_prof.so")
 import numpy as np, torch
 from sage_gs import Renderer, scenes
 sc = scenes.cached_room(int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, seed=2)

@@ -152,3 +152,18 @@ def test_env_pose_gives_a_rigid_level_view(env_poses):
             a = 2.0 * math.atan2(z, w)                        # a rotation about +Z: the camera stays level
             assert np.allclose(R[2], [math.cos(a), math.sin(a), 0.0], atol=1e-9)      # camera +Z = heading
             assert np.allclose(R[1], [0.0, 0.0, -1.0], atol=1e-9)                     # camera +Y = world down
+
+
+def test_isaac_pose_from_view_inverts_view_from_isaac_pose():
+    from sage_gs import scenes
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pos = rng.uniform(-5, 5, 3)
+        V = camera.view_from_isaac_pose(pos, q)
+        p2, q2 = camera.isaac_pose_from_view(V)
+        assert np.allclose(p2, pos, atol=1e-12) and np.allclose(camera.view_from_isaac_pose(p2, q2), V, atol=1e-12)
+    for yaw in (0.0, 1.0, math.pi, -2.5):                    # the pose lists of the benchmarks (level cameras)
+        V = scenes.view_from_yaw((1.0, 2.0, 1.2), yaw)
+        p2, q2 = camera.isaac_pose_from_view(V)
+        assert np.allclose(camera.view_from_isaac_pose(p2, q2), V, atol=1e-12)

@@ -86,7 +86,8 @@ def test_library_is_the_hip_build(drv):
     import os
     assert os.path.basename(drv.r._lib.path) == "libsage_gs.so"
     assert "sage-3d_official_amd/lib" in drv.r._lib.path.replace("\\", "/")
-    assert drv.r._lib.version() == 100
+    from sage_gs import _capi
+    assert drv.r._lib.version() == _capi.ABI_VERSION
 
 
 def test_config1(drv):

@@ -192,3 +192,119 @@ def test_sweep_input_and_cameras(tmp_path):
     assert (cams[0].width, cams[0].height) == (1024, 768) and abs(cams[0].fx - 1024 * 8 / 20.955) < 1e-9
     eye = -cams[0].view[:3, :3].T @ cams[0].view[:3, 3]
     assert np.allclose(eye, [1.0, 2.0, 1.2])                      # eye height forced to 1.2 m
+
+
+class _FakeScene:
+    def __init__(self, g):
+        self.g, self.freed = g, False
+
+    def free(self):
+        self.freed = True
+
+
+class _FakeRenderer:
+    """Stands where sage_gs.Renderer stands behind isaac_shim / GsCamera in this CPU test: records what it is asked to draw and
+    hands back a frame that encodes the camera (so the test can tell which pose each saved image came from)."""
+    device = "cpu"
+
+    def __init__(self):
+        self.uploads, self.frames = [], []
+
+    def upload(self, g):
+        self.uploads.append(g)
+        return _FakeScene(g)
+
+    def render_rgba8_host(self, cam, scene, *, config=None, tonemap=None):
+        self.frames.append((cam, scene))
+        img = np.zeros((cam.height, cam.width, 4), np.uint8)
+        img[..., 0] = len(self.frames) % 256; img[..., 3] = 255
+        return img
+
+
+def test_isaac_shim_runs_the_reference_frame_loop_unchanged(tmp_path, monkeypatch):
+    """The call sequence of generate_images.py:318-350 (scene set-up) and :408-436 (frame loop), written exactly as the reference
+    writes it — its own import lines, resolved by isaac_shim.install() — against a fake renderer: the stage's .usda is parsed, the
+    Gaussians beside the referenced USDZ are loaded with the prim's model->world transform and uploaded ONCE, every frame is drawn
+    from the pose the loop set (z forced to 1.2, the stored rotation as the Isaac orientation), with the lens the loop set."""
+    import sys
+    from sage_gs import isaac_shim, scenes
+    # a scene stage as sage3d_usda_builder writes it (tests/golden/usda_golden.json holds the shape), its USDZ, the .ply beside it
+    scene_dir = tmp_path / "InteriorGS_usdz"; scene_dir.mkdir()
+    (scene_dir / "0042.usdz").write_bytes(b"")
+    rng = np.random.default_rng(3)
+    n = 50
+    arrays = (rng.normal(size=(n, 3)).astype(np.float32), np.full((n, 3), 0.05, np.float32),
+              np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1)), np.full(n, 0.5, np.float32), rng.normal(size=(n, 1, 3)).astype(np.float32), 0)
+    ply.save_ply(str(scene_dir / "0042.ply"), *arrays)
+    usda = tmp_path / "usda" / "0042.usda"; usda.parent.mkdir()
+    usda.write_text('#usda 1.0\n(\n    metersPerUnit = 1\n    upAxis = "Z"\n)\ndef Xform "World"\n{\n    over "gauss" (\n'
+                    '        prepend references = @../InteriorGS_usdz/0042.usdz[gauss.usda]@\n    )\n    {\n'
+                    '        double3 xformOp:rotateXYZ = (-90, 0, 0)\n        double3 xformOp:scale = (1, 1, 1)\n'
+                    '        double3 xformOp:translate = (0, 0, 0)\n'
+                    '        uniform token[] xformOpOrder = ["xformOp:translate", "xformOp:rotateXYZ", "xformOp:scale"]\n    }\n}\n')
+    fake = _FakeRenderer()
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("omni", "pxr", "isaacsim")}
+    isaac_shim.configure(renderer=fake)
+    isaac_shim._state["loader"] = None
+    try:
+        assert isaac_shim.install(force=True)
+        # ---- generate_images.py:24-33, verbatim -------------------------------------------------------------------------------
+        from omni.isaac.kit import SimulationApp
+        simulation_app = SimulationApp({"headless": True})
+        import omni.usd
+        from omni.isaac.core import World
+        from omni.isaac.core.utils.stage import open_stage
+        from omni.isaac.sensor import Camera
+        from pxr import Gf, UsdGeom, UsdLux
+        CAMERA_RESOLUTION, CAMERA_FOCAL_LENGTH, CAMERA_HEIGHT, WORLD_STEP_COUNT, RENDER_STEP_COUNT = (1024, 768), 8.0, 1.2, 5, 3
+        file_info = {"usd_file": str(usda)}
+        # ---- :320-350 ---------------------------------------------------------------------------------------------------------
+        omni.usd.get_context().close_stage()
+        assert not open_stage(usd_path=str(tmp_path / "missing.usda"))          # the reference's failure mode: False
+        assert open_stage(usd_path=file_info["usd_file"])
+        stage = omni.usd.get_context().get_stage()
+        if not stage.GetPrimAtPath("/World/EnvLight"):
+            dome = UsdLux.DomeLight.Define(stage, "/World/EnvLight")
+            dome.CreateIntensityAttr(30000.0)
+            dome.CreateColorAttr(Gf.Vec3f(1.0, 1.0, 1.0))
+        world = World()
+        world.reset()
+        for _ in range(WORLD_STEP_COUNT):
+            world.step(render=True)
+        sensor_cam_path = "/World/NaVILACamera"
+        cam = Camera(prim_path=sensor_cam_path, frequency=30, resolution=CAMERA_RESOLUTION)
+        cam.initialize()
+        cam_prim = stage.GetPrimAtPath(sensor_cam_path)
+        usd_cam = UsdGeom.Camera(cam_prim)
+        usd_cam.GetFocalLengthAttr().Set(CAMERA_FOCAL_LENGTH)
+        # ---- :408-436 ---------------------------------------------------------------------------------------------------------
+        points = [{"position": [1.0 + 0.1 * i, 2.0, 0.3], "rotation": [float(np.cos(0.2 * i)), 0.0, 0.0, float(np.sin(0.2 * i))]} for i in range(4)]
+        images = []
+        for frame_idx, point in enumerate(points):
+            position = np.array(point["position"], dtype=np.float32)
+            position[2] = CAMERA_HEIGHT
+            cam.set_world_pose(position=position, orientation=np.array(point["rotation"], dtype=np.float32))
+            for _ in range(RENDER_STEP_COUNT):
+                world.step(render=True)
+            img = cam.get_rgba()
+            assert img is not None and img.size > 0
+            images.append(img[:, :, :3].copy())
+        world.clear()
+        simulation_app.close()
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("omni", "pxr", "isaacsim")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+        isaac_shim._state.update(renderer=None, stage=None, app=None)
+    # one upload of the stage's Gaussians, with the prim's transform; freed when the stage closed
+    assert len(fake.uploads) == 1
+    g = fake.uploads[0]
+    assert len(g) == n and np.allclose(g.means.numpy(), arrays[0]) and g.sh_degree == 0
+    assert np.allclose(g.model_to_world, scenes.MODEL_TO_WORLD)
+    # every frame: the loop's pose, the loop's lens, the stage's scene
+    assert len(fake.frames) == len(points) and world.steps == WORLD_STEP_COUNT + RENDER_STEP_COUNT * len(points)
+    for i, ((c, sc), point) in enumerate(zip(fake.frames, points)):
+        assert (c.width, c.height) == CAMERA_RESOLUTION and abs(c.fx - 1024 * 8.0 / 20.955) < 1e-3 and c.fx == c.fy
+        pos = np.array(point["position"], np.float32); pos[2] = CAMERA_HEIGHT
+        assert np.allclose(c.view, camera.view_from_isaac_pose(pos, np.array(point["rotation"], np.float32)))
+        assert sc.g is g and images[i].shape == (768, 1024, 3) and images[i][0, 0, 0] == (i + 1) % 256
