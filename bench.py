@@ -88,6 +88,7 @@ def parse():
                     help="untimed rendering of the same sweep for about this long BEFORE the W warm-up steps, so that a short timed region "
                          "(the driver's --steps 20 is ~5 ms) is measured at the clocks a sweep of any length runs at, not while the GPU "
                          "is still leaving its idle power state (0 = off; reported as preheat_steps)")
+    ap.add_argument("--no-upload-probe", action="store_true", help="N=1: skip timing the scene load from host arrays / from the compressed payload")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="issue the frames of the sweep strictly one after another (default: SGS_FLAG_PIPELINED, a few "
                          "independent frames in flight on the library's internal streams)")
@@ -128,6 +129,49 @@ def kernel_sha():
         if name.endswith((".h", ".hip")):
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+def quantise_on_gpu(g):
+    """The PlayCanvas compressed.ply payload of a Gaussians object, made with torch ops on its device (the arithmetic of
+    sage_gs.ply.encode_compressed): (chunks float32 [nch,18], packed int32 [n,4], sh uint8 [n, 3 k_rest] or None)."""
+    import torch
+    n = g.means.shape[0]
+    nch = (n + 255) // 256
+    pad = nch * 256 - n
+
+    def chunked(a):
+        ap = torch.cat([a, a[-1:].expand(pad, -1)]) if pad else a
+        ap = ap.reshape(nch, 256, 3)
+        lo, hi = ap.min(1).values, ap.max(1).values
+        span = torch.where(hi > lo, hi - lo, torch.ones_like(hi))
+        u = (a - lo.repeat_interleave(256, 0)[:n]) / span.repeat_interleave(256, 0)[:n]
+        return lo, hi, u.clamp(0, 1)
+
+    def pack111011(u):
+        q = torch.round(u * torch.tensor([2047.0, 1023.0, 2047.0], device=u.device)).to(torch.int64)
+        return (q[:, 0] << 21) | (q[:, 1] << 11) | q[:, 2]
+    lo_p, hi_p, up = chunked(g.means.float())
+    lo_s, hi_s, us = chunked(torch.log(g.scales.float()))
+    q = g.quats.float() / g.quats.float().norm(dim=1, keepdim=True)
+    which = q.abs().argmax(1)
+    q = q * torch.sign(q.gather(1, which[:, None]))
+    keep = torch.ones_like(q, dtype=torch.bool); keep.scatter_(1, which[:, None], False)
+    rest = q[keep].reshape(n, 3)
+    u = torch.round((rest / 2 ** 0.5 + 0.5).clamp(0, 1) * 1023).to(torch.int64)
+    rot = (which.to(torch.int64) << 30) | (u[:, 0] << 20) | (u[:, 1] << 10) | u[:, 2]
+    sh = g.sh.float().reshape(n, -1, 3)
+    rgb = (0.5 + 0.28209479177387814 * sh[:, 0, :]).clamp(0, 1)
+    c8 = torch.round(torch.cat([rgb, g.opacities.float().reshape(n, 1).clamp(0, 1)], 1) * 255).to(torch.int64)
+    col = (c8[:, 0] << 24) | (c8[:, 1] << 16) | (c8[:, 2] << 8) | c8[:, 3]
+    packed = torch.stack([pack111011(up), rot, pack111011(us), col], 1)
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)        # the uint32 words as int32 bit patterns
+    chunks = torch.cat([lo_p, hi_p, lo_s, hi_s, torch.zeros_like(lo_p), torch.ones_like(lo_p)], 1).contiguous()
+    k_rest = sh.shape[1] - 1
+    shb = None
+    if k_rest > 0:
+        r_ = sh[:, 1:, :].permute(0, 2, 1).reshape(n, 3 * k_rest)
+        shb = torch.trunc((r_ / 8.0 + 0.5) * 256.0).clamp(0, 255).to(torch.uint8).contiguous()
+    return chunks, packed.contiguous(), shb
 
 
 def pct(xs):
@@ -204,7 +248,36 @@ def main():
         pose_desc = "256-pose sweep (4 positions x 64 headings)"
     n_poses = len(cams)
     r = Renderer(device, record_capacity=(192 << 20) if config == 5 else (96 << 20))
-    gs = r.upload(scenes.to_gaussians(scene, device))
+    g_dev = scenes.to_gaussians(scene, device)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    gs = r.upload(g_dev)                     # once per scene, as the reference loads a stage once — never in `value`
+    torch.cuda.synchronize(device)
+    upload_ms = {"arrays_on_device": 1e3 * (time.perf_counter() - t0),
+                 "what": "scene load, once per scene and outside every timed region: Z-order (device radix sort of 63-bit Morton keys), layout into "
+                         "wave-chunked rows, per-chunk bounds.  arrays_on_device = the fp32 tensors already in HBM (236 B per Gaussian at degree 3); "
+                         "compressed_* = the PlayCanvas compressed.ply payload (16 B + 45 SH bytes per Gaussian), dequantised by the layout kernel"}
+    if rank == 0 and world == 1 and not args.no_upload_probe and not args.scene:
+        from sage_gs import ply as ply_mod
+        t0 = time.perf_counter()
+        g_host = scenes.to_gaussians(scene, "cpu")
+        s2 = r.upload(g_host); torch.cuda.synchronize(device)
+        upload_ms["arrays_from_host"] = 1e3 * (time.perf_counter() - t0)
+        s2.free()
+        dv = quantise_on_gpu(g_dev)              # (the quantiser of sage_gs.ply.encode_compressed as torch ops: 3 M Gaussians take NumPy half a minute)
+        hv = [t.cpu() for t in dv]
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        s3 = r.upload_compressed(hv[0], hv[1], hv[2], scene.sh_degree, model_to_world=scene.model_to_world); torch.cuda.synchronize(device)
+        upload_ms["compressed_from_host"] = 1e3 * (time.perf_counter() - t0)
+        s3.free()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        s4 = r.upload_compressed(dv[0], dv[1], dv[2], scene.sh_degree, model_to_world=scene.model_to_world); torch.cuda.synchronize(device)
+        upload_ms["compressed_on_device"] = 1e3 * (time.perf_counter() - t0)
+        s4.free()
+        del dv, hv, g_host
+    del g_dev
     K, W = args.steps, args.warmup
     timing = not args.no_events
     pipelined = not args.no_pipeline
@@ -438,6 +511,7 @@ def main():
             #   1 (rounds 1-2)  N > 1: fp32 bands gathered;  2 (round 3)  N >= 4: bands gathered as uint8 RGBA (fp32 under also_measured.rows_f32);
             #   3 (round 4)     + an untimed pre-heat of the same sweep before the W warm-up steps (preheat_steps; --preheat-ms 0 = off)
             "metric_version": 3,
+            "upload_ms": upload_ms,
             "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                             "gather_us_per_frame": gather_us, "what": "ranks = the size the communicator reports; gather_us_per_frame = the "
                             "framebuffer gatherv alone (bands already rendered), 8 frames per exchange, host-timed between fences"}

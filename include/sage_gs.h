@@ -154,6 +154,25 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
 int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means, const float* scales,
                      const float* quats, const float* opacities, const float* sh, int on_device,
                      sgs_scene** out);
+/* The same, from the PlayCanvas "compressed.ply" payload InteriorGS ships (`3dgs_compressed.ply`, README.md:197-231 of the reference — which
+ * converts it back to a standard .ply with @playcanvas/splat-transform and then to USDZ before Isaac Sim can load it): the payload is
+ * dequantised ON THE DEVICE while the scene is laid out; the fp32 arrays never exist.  16 bytes per Gaussian instead of 236.
+ *   chunks[n_chunks][18]   per 256 Gaussians: min xyz, max xyz, min / max of log(scale) xyz, min rgb, max rgb (0 and 1 when the file has no
+ *                          colour range: the chunk element's first 12 or 18 float properties, in file order)
+ *   packed[n][4]           the vertex element's uint32 properties packed_position (11-10-11), packed_rotation (2 + 10-10-10), packed_scale
+ *                          (11-10-11), packed_color (8-8-8-8), in THIS order
+ *   sh[n][3 * ((d+1)^2-1)] the `sh` element's uint8 properties f_rest_*, in file order (channel-major); NULL at degree 0
+ * sage_gs/ply.py (read_compressed_payload) produces exactly these from a file.  n_chunks must be ceil(n / 256). */
+typedef struct sgs_compressed_scene {
+    int64_t n;
+    int64_t n_chunks;
+    int32_t sh_degree;
+    int32_t reserved_;
+    const float* chunks;
+    const uint32_t* packed;
+    const uint8_t* sh;
+} sgs_compressed_scene;
+int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int on_device, sgs_scene** out);
 int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene);
 
 /* One frame — replaces world.step(render=True) x2..5 + cam.get_rgba() (simple_env.py:1368-1380;
@@ -215,7 +234,9 @@ enum {
     SGS_BUF_SORTED_SLOTS = 1,      /* uint32[D]    per-tile queues in (depth, index) order — complete only with SGS_FLAG_FULL_SORT */
     SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    slot i holds Gaussian i: i if live this frame, 0xFFFFFFFF if culled; S = ceil(N/64)*64 */
     SGS_BUF_CHUNK_SKIPPED = 4,     /* uint8[ceil(N/64)]  1 = the 64-Gaussian chunk (in layout order) was skipped by its bounds */
-    SGS_BUF_SPLATS       = 3       /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
+    SGS_BUF_SPLATS       = 3,      /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
+    SGS_BUF_SCENE_GEOM   = 5       /* float[N][11] of the LAST RENDERED scene as the device holds it, by original index: mean xyz, opacity, scale xyz,
+                                    * quaternion wxyz (as uploaded / as dequantised from a compressed payload) */
 };
 int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);
 

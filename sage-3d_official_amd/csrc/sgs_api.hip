@@ -810,6 +810,115 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records) {
     return ensure_records(ctx, ctx->lanes[0]);
 }
 
+namespace {
+
+// The device side of a scene load (sgs_kernels.h "Upload"): Z-order permutation of the means by a radix sort on the device, layout
+// (dequantising when the source is the compressed payload), per-chunk bounds.  src = the five fp32 arrays on the device, or Z.
+int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs::PackedScene& Z, bool packed) {
+    const int64_t n = sc->n;
+    const int nf = 3 * (sc->sh_degree + 1) * (sc->sh_degree + 1);
+    const size_t npad = (size_t)std::max<int64_t>(sc->n_chunks, 1) * 64;
+    hipError_t e;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned* idx[2] = {nullptr, nullptr};
+    unsigned *hist = nullptr, *bounds = nullptr;
+    const unsigned* d_perm = nullptr;
+    int rc = SGS_OK;
+    auto fail = [&](const char* what, hipError_t err) {
+        ctx->err = std::string("scene layout: ") + what + ": " + hipGetErrorString(err);
+        rc = err == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
+    };
+    const float* means = packed ? nullptr : src[0];
+    if (ctx->morton && n > SGS_WAVE) {
+        // Z-order (Morton) permutation of the means, once per scene: 64 consecutive Gaussians then occupy a compact cell, so a chunk is
+        // visible or culled as a whole (no half-used SH cache lines in k_preprocess) and its splats overlap on screen (binning)
+        const unsigned nblocks = (unsigned)((n + SGS_RSORT_TILE - 1) / SGS_RSORT_TILE);
+        for (int k = 0; k < 2 && rc == SGS_OK; ++k) {
+            if ((e = hipMalloc(reinterpret_cast<void**>(&keys[k]), (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
+            else if ((e = hipMalloc(reinterpret_cast<void**>(&idx[k]), (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
+        }
+        if (rc == SGS_OK && (e = hipMalloc(reinterpret_cast<void**>(&hist), (size_t)256 * nblocks * 4)) != hipSuccess) fail("hipMalloc", e);
+        if (rc == SGS_OK && (e = hipMalloc(reinterpret_cast<void**>(&bounds), 6 * 4)) != hipSuccess) fail("hipMalloc", e);
+        if (rc == SGS_OK) {
+            const unsigned init[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
+            if ((e = hipMemcpy(bounds, init, sizeof init, hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", e);
+        }
+        if (rc == SGS_OK) {
+            const unsigned g1 = (unsigned)std::min<int64_t>(1024, (n + 255) / 256), gn = (unsigned)((n + 255) / 256);
+            if (packed) {
+                hipLaunchKernelGGL((sgs::k_mean_bounds<true>), dim3(g1), dim3(256), 0, 0, (long long)n, means, Z, bounds);
+                hipLaunchKernelGGL((sgs::k_morton_keys<true>), dim3(gn), dim3(256), 0, 0, (long long)n, means, Z, bounds, keys[0], idx[0]);
+            } else {
+                hipLaunchKernelGGL((sgs::k_mean_bounds<false>), dim3(g1), dim3(256), 0, 0, (long long)n, means, Z, bounds);
+                hipLaunchKernelGGL((sgs::k_morton_keys<false>), dim3(gn), dim3(256), 0, 0, (long long)n, means, Z, bounds, keys[0], idx[0]);
+            }
+            int cur = 0;
+            for (int shift = 0; shift < 64; shift += 8, cur ^= 1) {      // 63 key bits: eight stable passes
+                hipLaunchKernelGGL(sgs::k_radix_count, dim3(nblocks), dim3(256), 0, 0, (long long)n, keys[cur], shift, nblocks, hist);
+                hipLaunchKernelGGL(sgs::k_radix_scan, dim3(1), dim3(1024), 0, 0, 256u * nblocks, hist);
+                hipLaunchKernelGGL(sgs::k_radix_scatter, dim3(nblocks), dim3(256), 0, 0, (long long)n, keys[cur], idx[cur], keys[cur ^ 1], idx[cur ^ 1],
+                                   shift, nblocks, hist);
+            }
+            d_perm = idx[cur];               // (an even number of passes: back in buffer 0)
+            sc->perm_host = (unsigned*)malloc((size_t)n * 4);
+            if (!sc->perm_host) { ctx->err = "scene layout: out of host memory"; rc = SGS_ERR_OOM; }
+            else if ((e = hipMemcpy(sc->perm_host, d_perm, (size_t)n * 4, hipMemcpyDeviceToHost)) != hipSuccess) fail("reading the permutation", e);
+        }
+    }
+    if (rc == SGS_OK) {
+        const unsigned grid = (unsigned)((npad + 255) / 256);
+        if (packed)
+            hipLaunchKernelGGL((sgs::k_scene_layout<true>), dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows, d_perm,
+                               nullptr, nullptr, nullptr, nullptr, nullptr, Z, sc->geom, sc->shq);
+        else
+            hipLaunchKernelGGL((sgs::k_scene_layout<false>), dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows, d_perm,
+                               src[0], src[1], src[2], src[3], src[4], Z, sc->geom, sc->shq);
+        hipLaunchKernelGGL(sgs::k_chunk_bounds, dim3((unsigned)((sc->n_chunks + 3) / 4)), dim3(256), 0, 0, (long long)n,
+                           (long long)sc->n_chunks, sc->geom, sc->cbound);
+        if ((e = hipDeviceSynchronize()) != hipSuccess) fail("k_scene_layout / k_chunk_bounds", e);
+    }
+    for (int k = 0; k < 2; ++k) { if (keys[k]) (void)hipFree(keys[k]); if (idx[k]) (void)hipFree(idx[k]); }
+    if (hist) (void)hipFree(hist);
+    if (bounds) (void)hipFree(bounds);
+    return rc;
+}
+
+// a new scene object with its device buffers
+int new_scene(sgs_ctx* ctx, int64_t n, int sh_degree, sgs_scene** out) {
+    sgs_scene* sc = new (std::nothrow) sgs_scene;
+    if (!sc) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
+    const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
+    sc->n = n; sc->n_chunks = (n + 63) / 64; sc->sh_degree = sh_degree; sc->sh_rows = (nf + 3) / 4;
+    const size_t npad = (size_t)std::max<int64_t>(sc->n_chunks, 1) * 64;
+    hipError_t e;
+    if ((e = hipMalloc(reinterpret_cast<void**>(&sc->geom), npad * SGS_GEOM_ROWS * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&sc->shq), npad * sc->sh_rows * sizeof(float4))) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&sc->cbound), (npad / 64) * 2 * sizeof(float4))) != hipSuccess) {
+        ctx->err = std::string("scene upload: hipMalloc: ") + hipGetErrorString(e);
+        sgs_scene_free(ctx, sc);
+        return e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
+    }
+    *out = sc;
+    return SGS_OK;
+}
+
+// host arrays -> device copies (on_device: the caller's pointers as they are).  staged[] holds what must be freed.
+int stage(sgs_ctx* ctx, int on_device, const void* const* src, const size_t* bytes, int count, const void** dev, void** staged) {
+    for (int i = 0; i < count; ++i) {
+        staged[i] = nullptr;
+        if (on_device || !src[i] || bytes[i] == 0) { dev[i] = src[i]; continue; }
+        hipError_t e;
+        if ((e = hipMalloc(&staged[i], bytes[i])) != hipSuccess || (e = hipMemcpy(staged[i], src[i], bytes[i], hipMemcpyHostToDevice)) != hipSuccess) {
+            ctx->err = std::string("scene upload: staging: ") + hipGetErrorString(e);
+            return e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
+        }
+        dev[i] = staged[i];
+    }
+    return SGS_OK;
+}
+
+}  // namespace
+
 int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means, const float* scales,
                      const float* quats, const float* opacities, const float* sh, int on_device,
                      sgs_scene** out) {
@@ -820,97 +929,52 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
     if (sh_degree < 0 || sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d not in 0..3", sh_degree);
     if (n > 0 && (!means || !scales || !quats || !opacities || !sh)) SGS_FAIL(ctx, SGS_ERR_INVALID, "null input array");
     SGS_HIP(ctx, hipSetDevice(ctx->device));
-    sgs_scene* sc = new (std::nothrow) sgs_scene;
-    if (!sc) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
-    const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
-    sc->n = n; sc->n_chunks = (n + 63) / 64; sc->sh_degree = sh_degree; sc->sh_rows = (nf + 3) / 4;
-    const size_t npad = (size_t)std::max<int64_t>(sc->n_chunks, 1) * 64;
-    auto bail = [&](int code) { sgs_scene_free(ctx, sc); return code; };
-    hipError_t e;
-    if ((e = hipMalloc(reinterpret_cast<void**>(&sc->geom), npad * SGS_GEOM_ROWS * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&sc->shq), npad * sc->sh_rows * sizeof(float4))) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&sc->cbound), (npad / 64) * 2 * sizeof(float4))) != hipSuccess) {
-        ctx->err = std::string("sgs_scene_upload: hipMalloc: ") + hipGetErrorString(e);
-        return bail(e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP);
-    }
+    sgs_scene* sc = nullptr;
+    int rc;
+    if ((rc = new_scene(ctx, n, sh_degree, &sc)) != SGS_OK) return rc;
     if (n > 0) {
-        const float* src[5] = {means, scales, quats, opacities, sh};
-        const size_t cnt[5] = {(size_t)n * 3, (size_t)n * 3, (size_t)n * 4, (size_t)n, (size_t)n * nf};
-        float* staged[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-        const float* dev[5];
-        int rc = SGS_OK;
-        for (int i = 0; i < 5 && rc == SGS_OK; ++i) {
-            if (on_device) { dev[i] = src[i]; continue; }
-            if ((e = hipMalloc(reinterpret_cast<void**>(&staged[i]), cnt[i] * sizeof(float))) != hipSuccess ||
-                (e = hipMemcpy(staged[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) {
-                ctx->err = std::string("sgs_scene_upload: staging: ") + hipGetErrorString(e);
-                rc = e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
-            }
-            dev[i] = staged[i];
-        }
-        unsigned* d_perm = nullptr;
-        if (rc == SGS_OK && ctx->morton && n > SGS_WAVE) {
-            // Z-order (Morton) permutation of the means, computed on the host once per scene: 64 consecutive
-            // Gaussians then occupy a compact cell, so a chunk is visible or culled as a whole (no half-used SH
-            // cache lines in k_preprocess) and its splats overlap on screen (binning).
-            std::vector<float> hm((size_t)n * 3);
-            e = hipMemcpy(hm.data(), dev[0], (size_t)n * 12, on_device ? hipMemcpyDeviceToHost : hipMemcpyDeviceToHost);
-            if (e == hipSuccess) {
-                float lo[3] = {3.0e38f, 3.0e38f, 3.0e38f}, hi[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-                for (int64_t i = 0; i < n; ++i)
-                    for (int c = 0; c < 3; ++c) {
-                        const float v = hm[(size_t)i * 3 + c];
-                        if (std::isfinite(v)) { lo[c] = std::min(lo[c], v); hi[c] = std::max(hi[c], v); }   // (a NaN / inf mean is never visible)
-                    }
-                float inv[3];
-                for (int c = 0; c < 3; ++c) inv[c] = hi[c] > lo[c] ? 2097151.0f / (hi[c] - lo[c]) : 0.f;
-                auto spread = [](uint64_t v) {          // 21 bits -> every third bit
-                    v &= 0x1fffffull;
-                    v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
-                    v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-                    v = (v | v << 2) & 0x1249249249249249ull;
-                    return v;
-                };
-                std::vector<std::pair<uint64_t, unsigned>> keys((size_t)n);
-                for (int64_t i = 0; i < n; ++i) {
-                    uint64_t q[3];
-                    for (int c = 0; c < 3; ++c) {
-                        const float v = hm[(size_t)i * 3 + c];
-                        const float u = std::isfinite(v) ? (v - lo[c]) * inv[c] : 0.f;
-                        q[c] = (uint64_t)std::min(2097151.0f, std::max(0.0f, u));
-                    }
-                    keys[(size_t)i] = {spread(q[0]) | spread(q[1]) << 1 | spread(q[2]) << 2, (unsigned)i};
-                }
-                std::sort(keys.begin(), keys.end());
-                sc->perm_host = (unsigned*)malloc((size_t)n * 4);
-                if (!sc->perm_host) { ctx->err = "sgs_scene_upload: out of host memory"; rc = SGS_ERR_OOM; }
-                else {
-                    for (int64_t i = 0; i < n; ++i) sc->perm_host[i] = keys[(size_t)i].second;
-                    if ((e = hipMalloc(reinterpret_cast<void**>(&d_perm), (size_t)n * 4)) != hipSuccess ||
-                        (e = hipMemcpy(d_perm, sc->perm_host, (size_t)n * 4, hipMemcpyHostToDevice)) != hipSuccess) {
-                        ctx->err = std::string("sgs_scene_upload: permutation: ") + hipGetErrorString(e);
-                        rc = e == hipErrorOutOfMemory ? SGS_ERR_OOM : SGS_ERR_HIP;
-                    }
-                }
-            } else {
-                ctx->err = std::string("sgs_scene_upload: reading means: ") + hipGetErrorString(e);
-                rc = SGS_ERR_HIP;
-            }
-        }
+        const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
+        const void* src[5] = {means, scales, quats, opacities, sh};
+        const size_t bytes[5] = {(size_t)n * 12, (size_t)n * 12, (size_t)n * 16, (size_t)n * 4, (size_t)n * nf * 4};
+        const void* dev[5]; void* staged[5] = {};
+        rc = stage(ctx, on_device, src, bytes, 5, dev, staged);
         if (rc == SGS_OK) {
-            const unsigned grid = (unsigned)((npad + 255) / 256);
-            hipLaunchKernelGGL(sgs::k_scene_layout, dim3(grid), dim3(256), 0, 0, (long long)n, nf, sc->sh_rows, d_perm,
-                               dev[0], dev[1], dev[2], dev[3], dev[4], sc->geom, sc->shq);
-            hipLaunchKernelGGL(sgs::k_chunk_bounds, dim3((unsigned)((sc->n_chunks + 3) / 4)), dim3(256), 0, 0, (long long)n,
-                               (long long)sc->n_chunks, sc->geom, sc->cbound);
-            if ((e = hipDeviceSynchronize()) != hipSuccess) {
-                ctx->err = std::string("sgs_scene_upload: k_scene_layout / k_chunk_bounds: ") + hipGetErrorString(e);
-                rc = SGS_ERR_HIP;
-            }
+            const float* f[5] = {(const float*)dev[0], (const float*)dev[1], (const float*)dev[2], (const float*)dev[3], (const float*)dev[4]};
+            sgs::PackedScene Z = {nullptr, nullptr, nullptr, 0};
+            rc = layout_scene(ctx, sc, f, Z, false);
         }
-        for (float* p : staged) if (p) (void)hipFree(p);
-        if (d_perm) (void)hipFree(d_perm);
-        if (rc != SGS_OK) return bail(rc);
+        for (void* q : staged) if (q) (void)hipFree(q);
+        if (rc != SGS_OK) { sgs_scene_free(ctx, sc); return rc; }
+    }
+    *out = sc;
+    return SGS_OK;
+}
+
+int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int on_device, sgs_scene** out) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (!out || !z) SGS_FAIL(ctx, SGS_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int64_t n = z->n;
+    if (n < 0 || n > 0x7fffffffll) SGS_FAIL(ctx, SGS_ERR_INVALID, "n = %lld out of range", (long long)n);
+    if (z->sh_degree < 0 || z->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d not in 0..3", z->sh_degree);
+    const int k_rest = (z->sh_degree + 1) * (z->sh_degree + 1) - 1;
+    if (n > 0 && (!z->chunks || !z->packed || (k_rest > 0 && !z->sh))) SGS_FAIL(ctx, SGS_ERR_INVALID, "null input array");
+    if (z->n_chunks != (n + 255) / 256) SGS_FAIL(ctx, SGS_ERR_INVALID, "n_chunks %lld is not ceil(n / 256)", (long long)z->n_chunks);
+    SGS_HIP(ctx, hipSetDevice(ctx->device));
+    sgs_scene* sc = nullptr;
+    int rc;
+    if ((rc = new_scene(ctx, n, z->sh_degree, &sc)) != SGS_OK) return rc;
+    if (n > 0) {
+        const void* src[3] = {z->chunks, z->packed, z->sh};
+        const size_t bytes[3] = {(size_t)z->n_chunks * 18 * 4, (size_t)n * 16, (size_t)n * 3 * k_rest};
+        const void* dev[3]; void* staged[3] = {};
+        rc = stage(ctx, on_device, src, bytes, 3, dev, staged);
+        if (rc == SGS_OK) {
+            sgs::PackedScene Z = {(const float*)dev[0], (const uint4*)dev[1], (const unsigned char*)dev[2], k_rest};
+            rc = layout_scene(ctx, sc, nullptr, Z, true);
+        }
+        for (void* q : staged) if (q) (void)hipFree(q);
+        if (rc != SGS_OK) { sgs_scene_free(ctx, sc); return rc; }
     }
     *out = sc;
     return SGS_OK;
@@ -1191,6 +1255,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_SLOT_IDS: elem = 4; have = n_slots * elem; break;
         case SGS_BUF_SPLATS: elem = 48; have = n_slots * elem; break;          // the 12-word view documented in sage_gs.h
         case SGS_BUF_CHUNK_SKIPPED: have = n_chunks; break;
+        case SGS_BUF_SCENE_GEOM: have = ctx->last_scene ? ctx->last_n * 11 * 4 : 0; break;
         case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
@@ -1209,6 +1274,21 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         for (int64_t i = 0; (i + 1) * 4 <= n; ++i)
             ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i];
         free(tmp);
+    }
+    if (what == SGS_BUF_SCENE_GEOM) {
+        std::vector<float4> rows((size_t)n_slots * SGS_GEOM_ROWS);
+        hipError_t e = hipMemcpy(rows.data(), ctx->last_scene->geom, rows.size() * sizeof(float4), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+        float* dst = (float*)host_dst;
+        for (int64_t p = 0; p < ctx->last_n; ++p) {
+            const int64_t chunk = p >> 6, lane = p & 63;
+            const float4 g0 = rows[(size_t)((chunk * SGS_GEOM_ROWS + 0) * 64 + lane)], g1 = rows[(size_t)((chunk * SGS_GEOM_ROWS + 1) * 64 + lane)],
+                         g2 = rows[(size_t)((chunk * SGS_GEOM_ROWS + 2) * 64 + lane)];
+            unsigned i; memcpy(&i, &g2.w, 4);
+            if ((int64_t)(i + 1) * 11 * 4 > n) continue;
+            float* o = dst + (size_t)i * 11;
+            o[0] = g0.x; o[1] = g0.y; o[2] = g0.z; o[3] = g0.w; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[7] = g1.w; o[8] = g2.x; o[9] = g2.y; o[10] = g2.z;
+        }
     }
     if (what == SGS_BUF_CHUNK_SKIPPED) {
         std::vector<unsigned long long> vm((size_t)std::max<int64_t>(1, n_chunks)), bm(vm.size());

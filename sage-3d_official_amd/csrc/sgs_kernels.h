@@ -75,9 +75,184 @@ __device__ __forceinline__ unsigned wave_sum(unsigned x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Upload: AoS fp32 inputs -> wave-chunked float4 rows, so every per-frame load is a 1-KiB coalesced
-// row (64 lanes x 16 B).  geom rows: (mx,my,mz,opacity) (sx,sy,sz,qw) (qx,qy,qz,original index).
-// sh rows: the (deg+1)^2*3 floats of a Gaussian, 4 per row, zero padded.
+// Upload.  A scene arrives as the caller's AoS fp32 tensors (sgs_scene_upload) or as the PlayCanvas "compressed.ply" payload
+// InteriorGS ships (sgs_scene_upload_compressed: 16 bytes per Gaussian + a table per 256-Gaussian chunk + 8-bit SH; README.md:197-243
+// of the reference names the format, its bit layout is restated in sage_gs/ply.py) and is laid out on the device:
+//   k_mean_bounds -> k_morton_keys -> 8 x (k_radix_count, k_radix_scan, k_radix_scatter) -> k_scene_layout -> k_chunk_bounds
+// i.e. the Z-order (Morton) permutation of the means is made HERE, by an LSD radix sort of (63-bit key, index) pairs, and the layout
+// kernel gathers through it — dequantising on the way when the source is compressed.  (Rounds 1-3 copied the means to the host,
+// sorted 3 M pairs with one thread of std::sort and copied the permutation back: ~0.5 s of a scene load.)
+
+// A compressed scene as the kernels see it.  chunk[c] = 18 floats: min xyz, max xyz, min scale xyz, max scale xyz (log scales), min rgb,
+// max rgb (0 / 1 when the file carries no colour range); packed[i] = (position 11-10-11, rotation 2+10-10-10, scale 11-10-11, colour 8-8-8-8);
+// sh[i * 3 k_rest ..] = the file's f_rest bytes, channel-major.
+struct PackedScene {
+    const float* chunk; const uint4* packed; const unsigned char* sh;
+    int k_rest;                       // SH coefficients per channel beyond the DC term: 0, 3, 8 or 15
+};
+struct UnpackedG { float m[3], s[3], q[4], o, dc[3]; };
+__device__ __forceinline__ float sgs_unorm(unsigned v, int bits) { return (float)(v & ((1u << bits) - 1u)) / (float)((1u << bits) - 1u); }
+__device__ __forceinline__ float sgs_lerp(float u, float lo, float hi) { return lo + u * (hi - lo); }
+// the position of Gaussian i alone (Morton keys)
+__device__ __forceinline__ void unpack_position(const PackedScene& Z, long long i, float* m) {
+    const float* c = Z.chunk + (i >> 8) * 18;
+    const unsigned p = Z.packed[i].x;
+    m[0] = sgs_lerp(sgs_unorm(p >> 21, 11), c[0], c[3]); m[1] = sgs_lerp(sgs_unorm(p >> 11, 10), c[1], c[4]); m[2] = sgs_lerp(sgs_unorm(p, 11), c[2], c[5]);
+}
+// everything but the SH rest: the arithmetic of sage_gs/ply.py load_compressed_ply, in fp32
+__device__ __forceinline__ void unpack_gaussian(const PackedScene& Z, long long i, UnpackedG& g) {
+    const float* c = Z.chunk + (i >> 8) * 18;
+    const uint4 p = Z.packed[i];
+    g.m[0] = sgs_lerp(sgs_unorm(p.x >> 21, 11), c[0], c[3]); g.m[1] = sgs_lerp(sgs_unorm(p.x >> 11, 10), c[1], c[4]); g.m[2] = sgs_lerp(sgs_unorm(p.x, 11), c[2], c[5]);
+    g.s[0] = expf(sgs_lerp(sgs_unorm(p.z >> 21, 11), c[6], c[9])); g.s[1] = expf(sgs_lerp(sgs_unorm(p.z >> 11, 10), c[7], c[10]));
+    g.s[2] = expf(sgs_lerp(sgs_unorm(p.z, 11), c[8], c[11]));
+    // rotation: the three smallest components at 10 bits each in [-1/sqrt2, 1/sqrt2], the index of the dropped (largest, positive) one on top
+    const float r2 = 1.41421356237309505f;
+    const float a = (sgs_unorm(p.y >> 20, 10) - 0.5f) * r2, b = (sgs_unorm(p.y >> 10, 10) - 0.5f) * r2, cc = (sgs_unorm(p.y, 10) - 0.5f) * r2;
+    const float mx = sqrtf(fmaxf(0.0f, 1.0f - (a * a + b * b + cc * cc)));
+    const unsigned which = p.y >> 30;
+    g.q[0] = which == 0u ? mx : a;                              // (w, x, y, z)
+    g.q[1] = which == 0u ? a : which == 1u ? mx : b;
+    g.q[2] = which <= 1u ? b : which == 2u ? mx : cc;
+    g.q[3] = which == 3u ? mx : cc;
+    const float cr = sgs_unorm(p.w >> 24, 8), cg = sgs_unorm(p.w >> 16, 8), cb = sgs_unorm(p.w >> 8, 8);
+    g.o = sgs_unorm(p.w, 8);
+    const float k0 = 1.0f / 0.28209479177387814f;               // colour = 0.5 + C0 dc
+    g.dc[0] = (sgs_lerp(cr, c[12], c[15]) - 0.5f) * k0; g.dc[1] = (sgs_lerp(cg, c[13], c[16]) - 0.5f) * k0; g.dc[2] = (sgs_lerp(cb, c[14], c[17]) - 0.5f) * k0;
+}
+// SH coefficient k (0 .. 3 (k_rest + 1) - 1, Gaussian-major [coefficient][channel] as the renderer takes them) of Gaussian i
+__device__ __forceinline__ float unpack_sh(const PackedScene& Z, long long i, const UnpackedG& g, int k) {
+    const int coef = k / 3, ch = k - 3 * coef;
+    if (coef == 0) return g.dc[ch];
+    const unsigned char v = Z.sh[i * (3 * Z.k_rest) + ch * Z.k_rest + (coef - 1)];
+    return ((float)v * (1.0f / 256.0f) - 0.5f) * 8.0f + 4.0f / 256.0f;
+}
+
+// floats <-> unsigned keys that order the same way (atomicMin / atomicMax on the bits)
+__device__ __forceinline__ unsigned sgs_ordered(float f) { const unsigned b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : b | 0x80000000u; }
+__device__ __forceinline__ float sgs_unordered(unsigned k) { return __uint_as_float((k & 0x80000000u) ? k & 0x7fffffffu : ~k); }
+// bounds of the finite means: out[0..2] = min (ordered keys), out[3..5] = max; initialised to ~0 / 0 by the host
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_mean_bounds(long long n, const float* __restrict__ means, const PackedScene Z, unsigned* __restrict__ out) {
+    unsigned lo[3] = {~0u, ~0u, ~0u}, hi[3] = {0u, 0u, 0u};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float m[3];
+        if (PACKED) unpack_position(Z, i, m); else { m[0] = means[3 * i]; m[1] = means[3 * i + 1]; m[2] = means[3 * i + 2]; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (fabsf(m[c]) < 3.0e38f) { const unsigned k = sgs_ordered(m[c]); lo[c] = k < lo[c] ? k : lo[c]; hi[c] = k > hi[c] ? k : hi[c]; }   // (NaN / inf: never visible)
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned l = wave_min(lo[c]), h = wave_max(hi[c]);
+        if ((threadIdx.x & 63) == 0) { atomicMin(&out[c], l); atomicMax(&out[3 + c], h); }
+    }
+}
+__device__ __forceinline__ unsigned long long sgs_spread21(unsigned long long v) {          // 21 bits -> every third bit
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull; v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full; v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+// (63-bit Morton code of the mean, index) per Gaussian: 21 bits per axis over the scene's bounds
+template <bool PACKED>
+__global__ __launch_bounds__(256) void k_morton_keys(long long n, const float* __restrict__ means, const PackedScene Z, const unsigned* __restrict__ bounds,
+                                                      unsigned long long* __restrict__ keys, unsigned* __restrict__ idx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float m[3];
+    if (PACKED) unpack_position(Z, i, m); else { m[0] = means[3 * i]; m[1] = means[3 * i + 1]; m[2] = means[3 * i + 2]; }
+    unsigned long long q[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lo = sgs_unordered(bounds[c]), hi = sgs_unordered(bounds[3 + c]);
+        const float inv = hi > lo ? 2097151.0f / (hi - lo) : 0.0f;
+        const float u = fabsf(m[c]) < 3.0e38f ? (m[c] - lo) * inv : 0.0f;
+        q[c] = (unsigned long long)fminf(2097151.0f, fmaxf(0.0f, u));
+    }
+    keys[i] = sgs_spread21(q[0]) | sgs_spread21(q[1]) << 1 | sgs_spread21(q[2]) << 2;
+    idx[i] = (unsigned)i;
+}
+
+// LSD radix sort of (key, index) pairs, 8 bits per pass, stable.  Workgroup b owns the keys [b T, (b + 1) T), T = SGS_RSORT_TILE:
+//   k_radix_count    per-workgroup digit histogram  -> hist[digit * B + b]
+//   k_radix_scan     exclusive scan of hist (digit major, workgroup minor): where workgroup b's keys of each digit go
+//   k_radix_scatter  every wave walks its contiguous quarter of the tile a row (64 keys) at a time; the lanes of a row that share a
+//                    digit find each other with 8 ballots, the first of them takes the run's base from the wave's cursor
+#define SGS_RSORT_TILE 2048
+__global__ __launch_bounds__(256) void k_radix_count(long long n, const unsigned long long* __restrict__ keys, int shift, unsigned nblocks,
+                                                      unsigned* __restrict__ hist) {
+    __shared__ unsigned s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long base = (long long)blockIdx.x * SGS_RSORT_TILE;
+    for (int r = 0; r < SGS_RSORT_TILE / 256; ++r) {
+        const long long i = base + r * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&s_h[(unsigned)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_radix_scan(unsigned total, unsigned* __restrict__ hist) {
+    __shared__ unsigned s_w[16];
+    const unsigned tid = threadIdx.x, per = (total + 1023u) / 1024u, a = min(total, tid * per), b = min(total, a + per);
+    unsigned sum = 0;
+    for (unsigned i = a; i < b; ++i) sum += hist[i];
+    const unsigned incl = wave_incl_scan(sum, (int)(tid & 63));
+    if ((tid & 63) == 63) s_w[tid >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - sum;
+    for (unsigned w = 0; w < (tid >> 6); ++w) run += s_w[w];
+    for (unsigned i = a; i < b; ++i) { const unsigned c = hist[i]; hist[i] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void k_radix_scatter(long long n, const unsigned long long* __restrict__ keys_in, const unsigned* __restrict__ idx_in,
+                                                        unsigned long long* __restrict__ keys_out, unsigned* __restrict__ idx_out, int shift,
+                                                        unsigned nblocks, const unsigned* __restrict__ hist) {
+    __shared__ unsigned s_cur[4][256];               // per wave and digit: where the wave's next key of that digit goes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * SGS_RSORT_TILE + (long long)wave * (SGS_RSORT_TILE / 4);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) s_cur[w][tid] = 0;
+    __syncthreads();
+    for (int r = 0; r < SGS_RSORT_TILE / 256; ++r) {                // the wave's own digit counts
+        const long long i = base + r * 64 + lane;
+        if (i < n) atomicAdd(&s_cur[wave][(unsigned)(keys_in[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {   // digit tid: the workgroup's base (scan) + the counts of the waves in front
+        unsigned run = hist[(size_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { const unsigned c = s_cur[w][tid]; s_cur[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+    for (int r = 0; r < SGS_RSORT_TILE / 256; ++r) {
+        const long long i = base + r * 64 + lane;
+        const bool valid = i < n;
+        const unsigned long long k = valid ? keys_in[i] : 0ull;
+        const unsigned v = valid ? idx_in[i] : 0u;
+        const unsigned d = (unsigned)(k >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(valid && bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const unsigned rank = (unsigned)__popcll(peers & lanemask_lt(lane));
+        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        unsigned dst = 0;
+        if (valid && rank == 0) dst = atomicAdd(&s_cur[wave][d], (unsigned)__popcll(peers));
+        dst = __shfl(dst, leader);
+        if (valid) { keys_out[dst + rank] = k; idx_out[dst + rank] = v; }
+    }
+}
+
+// Layout: position p of the laid-out scene holds Gaussian perm[p] (identity when perm == nullptr); geom rows (mx,my,mz,opacity)
+// (sx,sy,sz,qw) (qx,qy,qz,original index) and the SH floats, 4 per row, zero padded — every per-frame load is then a 1-KiB coalesced row
+// (64 lanes x 16 B).  PACKED: the source is the compressed payload, dequantised here (unpack_gaussian) — the scene is never
+// materialised as fp32 arrays.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floats, int sh_rows,
                                                       const unsigned* __restrict__ perm,
                                                       const float* __restrict__ means,
@@ -85,6 +260,7 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
                                                       const float* __restrict__ quats,
                                                       const float* __restrict__ opac,
                                                       const float* __restrict__ sh,
+                                                      const PackedScene Z,
                                                       float4* __restrict__ geom,
                                                       float4* __restrict__ shq) {
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // position in the laid-out scene
@@ -92,15 +268,22 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
     if (p >= n_pad) return;
     const long long chunk = p >> 6;
     const int lane = (int)(p & 63);
-    // position p holds Gaussian i = perm[p] (Z-order of the means; identity when perm == nullptr); the
-    // original index travels in the last word of the geometry rows: splats, records and depth ties use it.
+    // the original index travels in the last word of the geometry rows: splats, records and depth ties use it
     const long long i = p < n ? (perm ? (long long)perm[p] : p) : -1;
     float4 g0 = make_float4(0.f, 0.f, -1.0e30f, 0.f), g1 = make_float4(1.f, 1.f, 1.f, 1.f),
            g2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    UnpackedG u;
     if (i >= 0) {
-        g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
-        g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
-        g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)i));
+        if (PACKED) {
+            unpack_gaussian(Z, i, u);
+            g0 = make_float4(u.m[0], u.m[1], u.m[2], u.o);
+            g1 = make_float4(u.s[0], u.s[1], u.s[2], u.q[0]);
+            g2 = make_float4(u.q[1], u.q[2], u.q[3], __uint_as_float((unsigned)i));
+        } else {
+            g0 = make_float4(means[3 * i], means[3 * i + 1], means[3 * i + 2], opac[i]);
+            g1 = make_float4(scales[3 * i], scales[3 * i + 1], scales[3 * i + 2], quats[4 * i]);
+            g2 = make_float4(quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], __uint_as_float((unsigned)i));
+        }
     }
     geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
     geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
@@ -110,7 +293,7 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = 4 * r + c;
-            v[c] = (i >= 0 && k < n_sh_floats) ? sh[i * n_sh_floats + k] : 0.f;
+            v[c] = (i >= 0 && k < n_sh_floats) ? (PACKED ? unpack_sh(Z, i, u, k) : sh[i * n_sh_floats + k]) : 0.f;
         }
         shq[(chunk * sh_rows + r) * SGS_WAVE + lane] = make_float4(v[0], v[1], v[2], v[3]);
     }

@@ -15,7 +15,7 @@ STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
 FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL, FLAG_NO_CHUNK_CULL = 1, 2, 4, 8, 16, 32, 64
 BACKEND_CPU, BACKEND_HIP = 0, 1
-BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED = 0, 1, 2, 3, 4
+BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM = 0, 1, 2, 3, 4, 5
 
 ERR_NAMES = {-1: "SGS_ERR_INVALID", -2: "SGS_ERR_HIP", -3: "SGS_ERR_OOM", -4: "SGS_ERR_OVERFLOW",
              -5: "SGS_ERR_BACKEND"}
@@ -25,7 +25,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 
 # every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
 EXPORTS = ("sgs_version", "sgs_struct_sizes", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
-           "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_free", "sgs_render",
+           "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_upload_compressed", "sgs_scene_free", "sgs_render",
            "sgs_render_rgbd", "sgs_render_batch", "sgs_render_batch_strided", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
 
 
@@ -45,6 +45,11 @@ class SgsConfig(C.Structure):
                 ("clamp", C.c_float), ("alpha_min", C.c_float), ("alpha_max", C.c_float),
                 ("t_min", C.c_float), ("bg", C.c_float * 3), ("sh_degree", C.c_int32),
                 ("flags", C.c_uint32), ("tile_row_stride", C.c_int32), ("tile_row_phase", C.c_int32)]
+
+
+class SgsCompressedScene(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_chunks", C.c_int64), ("sh_degree", C.c_int32), ("reserved_", C.c_int32),
+                ("chunks", C.c_void_p), ("packed", C.c_void_p), ("sh", C.c_void_p)]
 
 
 class SgsStats(C.Structure):
@@ -97,6 +102,7 @@ class Lib:
         lib.sgs_last_error.argtypes = [vp]; lib.sgs_last_error.restype = C.c_char_p
         lib.sgs_set_record_capacity.argtypes = [vp, i64]
         lib.sgs_scene_upload.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]
+        lib.sgs_scene_upload_compressed.argtypes = [vp, C.POINTER(SgsCompressedScene), i32, C.POINTER(vp)]
         lib.sgs_scene_free.argtypes = [vp, vp]
         lib.sgs_render.argtypes = [vp, vp, C.POINTER(SgsCamera), C.POINTER(SgsConfig), i32, i32, vp,
                                    C.POINTER(SgsStats), vp]

@@ -193,20 +193,54 @@ def load_compressed_ply(path):
     return means.astype(np.float32), scales.astype(np.float32), quats, opac.astype(np.float32), sh, deg
 
 
-def save_compressed_ply(path, means, scales, quats, opacities, sh, sh_degree):
-    """Encoder matching load_compressed_ply (degree 0 colour only; used for round-trip tests)."""
+CHUNK_PROPS = ["min_x", "min_y", "min_z", "max_x", "max_y", "max_z",
+               "min_scale_x", "min_scale_y", "min_scale_z", "max_scale_x", "max_scale_y", "max_scale_z"]
+CHUNK_COLOR_PROPS = ["min_r", "min_g", "min_b", "max_r", "max_g", "max_b"]
+PACKED_PROPS = ["packed_position", "packed_rotation", "packed_scale", "packed_color"]
+
+
+def read_compressed_payload(path):
+    """A compressed.ply as the C ABI takes it (include/sage_gs.h sgs_compressed_scene): (chunks float32 [nch,18], packed uint32 [n,4],
+    sh uint8 [n, 3 k_rest] or None, sh_degree) — no dequantisation here: `Renderer.upload_compressed` hands these to the device, whose
+    layout kernel decodes them (csrc/sgs_kernels.h unpack_gaussian).  `load_compressed_ply` below is the same arithmetic in NumPy."""
+    el = read_elements(path)
+    ch, v = el["chunk"], el["vertex"]
+    nch = ch.shape[0]
+    chunks = np.empty((nch, 18), np.float32)
+    for k, name in enumerate(CHUNK_PROPS):
+        chunks[:, k] = ch[name]
+    if "min_r" in ch.dtype.names:
+        for k, name in enumerate(CHUNK_COLOR_PROPS):
+            chunks[:, 12 + k] = ch[name]
+    else:
+        chunks[:, 12:15] = 0.0; chunks[:, 15:18] = 1.0
+    packed = np.stack([v[name].astype(np.uint32) for name in PACKED_PROPS], 1)
+    if "sh" in el:
+        s = el["sh"]
+        rest = sorted(s.dtype.names, key=lambda k: int(k.split("_")[-1]))
+        sh = np.ascontiguousarray(np.stack([s[k] for k in rest], 1).astype(np.uint8))
+        deg = {3: 1, 8: 2, 15: 3}[len(rest) // 3]
+    else:
+        sh, deg = None, 0
+    return np.ascontiguousarray(chunks), np.ascontiguousarray(packed), sh, deg
+
+
+def encode_compressed(means, scales, quats, opacities, sh, sh_degree):
+    """(chunk table [nch,12] as a structured array, vertex table, sh bytes [n, 3 k_rest] or None): the quantisation of the PlayCanvas
+    layout — per 256-Gaussian chunk the bounds of position and log-scale, 11/10/11-bit position and scale, 2+10+10+10-bit "smallest three"
+    rotation, 8-bit colour (0.5 + C0 dc) and opacity, and — degree > 0 — 8-bit SH (value / 8 + 0.5, 256 levels, truncated)."""
     means, scales, quats = (np.asarray(a, np.float64) for a in (means, scales, quats))
+    sh = np.asarray(sh, np.float64)
     n = means.shape[0]
     nch = (n + 255) // 256
     ci = np.arange(n) // 256
     ls = np.log(scales)
-    rgb = np.clip(0.5 + SH_C0 * np.asarray(sh, np.float64)[:, 0, :], 0, 1)
-    chunk = np.zeros(nch, dtype=[(k, "<f4") for k in
-                                 ["min_x", "min_y", "min_z", "max_x", "max_y", "max_z",
-                                  "min_scale_x", "min_scale_y", "min_scale_z", "max_scale_x", "max_scale_y", "max_scale_z"]])
+    rgb = np.clip(0.5 + SH_C0 * sh[:, 0, :], 0, 1)
+    chunk = np.zeros(nch, dtype=[(k, "<f4") for k in CHUNK_PROPS])
+
     def bounds(a, pre):
-        lo = np.full((nch, 3), np.inf); hi = np.full((nch, 3), -np.inf)
-        np.minimum.at(lo, ci, a); np.maximum.at(hi, ci, a)
+        ap = np.concatenate([a, np.repeat(a[-1:], nch * 256 - n, 0)]).reshape(nch, 256, 3) if n else np.zeros((0, 256, 3))
+        lo, hi = ap.min(1), ap.max(1)
         for k, ax in enumerate("xyz"):
             chunk[f"min_{pre}{ax}"] = lo[:, k]; chunk[f"max_{pre}{ax}"] = hi[:, k]
         span = np.where(hi > lo, hi - lo, 1.0)
@@ -215,23 +249,41 @@ def save_compressed_ply(path, means, scales, quats, opacities, sh, sh_degree):
     q = quats / np.linalg.norm(quats, axis=1, keepdims=True)
     which = np.argmax(np.abs(q), axis=1)
     q = q * np.sign(q[np.arange(n), which])[:, None]
-    rest = np.stack([np.delete(q[i], which[i]) for i in range(n)]) if n else np.zeros((0, 3))
+    keep = np.ones((n, 4), bool); keep[np.arange(n), which] = False
+    rest = q[keep].reshape(n, 3)                                               # the three that are kept, in (w,x,y,z) order
     u = np.round(np.clip(rest / _SQRT2 + 0.5, 0, 1) * 1023).astype(np.uint32)
-    vert = np.zeros(n, dtype=[("packed_position", "<u4"), ("packed_rotation", "<u4"), ("packed_scale", "<u4"), ("packed_color", "<u4")])
+    vert = np.zeros(n, dtype=[(k, "<u4") for k in PACKED_PROPS])
     vert["packed_position"] = _pack_111011(up)
     vert["packed_scale"] = _pack_111011(us)
     vert["packed_rotation"] = (which.astype(np.uint32) << 30) | (u[:, 0] << 20) | (u[:, 1] << 10) | u[:, 2]
     c8 = np.round(np.concatenate([rgb, np.clip(np.asarray(opacities, np.float64), 0, 1)[:, None]], 1) * 255).astype(np.uint32)
     vert["packed_color"] = (c8[:, 0] << 24) | (c8[:, 1] << 16) | (c8[:, 2] << 8) | c8[:, 3]
+    shb = None
+    k_rest = (sh_degree + 1) ** 2 - 1
+    if k_rest > 0:
+        r = np.transpose(sh[:, 1:, :], (0, 2, 1)).reshape(n, 3 * k_rest)          # channel-major, as f_rest_* are
+        shb = np.clip(np.trunc((r / 8.0 + 0.5) * 256.0), 0, 255).astype(np.uint8)
+    return chunk, vert, shb
+
+
+def save_compressed_ply(path, means, scales, quats, opacities, sh, sh_degree):
+    """Encoder matching load_compressed_ply / read_compressed_payload (fixtures, round-trip tests, bench.py's compressed upload)."""
+    chunk, vert, shb = encode_compressed(means, scales, quats, opacities, sh, sh_degree)
     with open(path, "wb") as f:
-        f.write(("ply\nformat binary_little_endian 1.0\nelement chunk %d\n" % nch).encode())
+        f.write(("ply\nformat binary_little_endian 1.0\nelement chunk %d\n" % chunk.shape[0]).encode())
         for k in chunk.dtype.names:
             f.write(f"property float {k}\n".encode())
-        f.write(("element vertex %d\n" % n).encode())
+        f.write(("element vertex %d\n" % vert.shape[0]).encode())
         for k in vert.dtype.names:
             f.write(f"property uint {k}\n".encode())
+        if shb is not None:
+            f.write(("element sh %d\n" % shb.shape[0]).encode())
+            for k in range(shb.shape[1]):
+                f.write(f"property uchar f_rest_{k}\n".encode())
         f.write(b"end_header\n")
         f.write(chunk.tobytes()); f.write(vert.tobytes())
+        if shb is not None:
+            f.write(shb.tobytes())
 
 
 def to_gaussians(arrays: Tuple, device, model_to_world=None):

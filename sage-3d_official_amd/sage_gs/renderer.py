@@ -159,6 +159,33 @@ class Renderer:
                                                        sh.data_ptr(), 1, C.byref(h)), self._ctx)
         return Scene(self, h, n, int(g.sh_degree), g.model_to_world)
 
+    def upload_compressed(self, chunks, packed, sh, sh_degree: int, model_to_world=None) -> Scene:
+        """A scene from the PlayCanvas compressed.ply payload (ply.read_compressed_payload: chunks float32 [nch,18], packed uint32 [n,4],
+        sh uint8 [n, 3 k_rest] or None): copied to the device as it is — 16 B + SH bytes per Gaussian — and dequantised there by the
+        layout kernel (sgs_scene_upload_compressed).  NumPy arrays or tensors; tensors already on this device are used in place."""
+        def dev(a, dt):
+            if a is None:
+                return None
+            t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+            if t.dtype != dt:
+                t = t.view(dt) if t.element_size() == torch.empty((), dtype=dt).element_size() else t.to(dt)
+            return t.to(self.device).contiguous()
+        with torch.cuda.device(self.device):
+            c = dev(chunks, torch.float32)
+            p = dev(packed if isinstance(packed, torch.Tensor) else np.ascontiguousarray(packed).view(np.int32), torch.int32)
+            b = dev(sh, torch.uint8)
+            n, nch = int(p.shape[0]), int(c.shape[0])
+            if tuple(c.shape) != (nch, 18) or tuple(p.shape) != (n, 4) or nch != (n + 255) // 256:
+                raise ValueError("chunks must be [ceil(n/256), 18] and packed [n, 4]")
+            k_rest = (int(sh_degree) + 1) ** 2 - 1
+            if (k_rest > 0) != (b is not None) or (b is not None and tuple(b.shape) != (n, 3 * k_rest)):
+                raise ValueError(f"sh must be uint8 [n, {3 * k_rest}] at degree {sh_degree} (None at degree 0)")
+            z = _capi.SgsCompressedScene(n, nch, int(sh_degree), 0, c.data_ptr(), p.data_ptr(), b.data_ptr() if b is not None else None)
+            torch.cuda.synchronize(self.device)
+            h = C.c_void_p()
+            self._lib.check(self._lib.sgs_scene_upload_compressed(self._ctx, C.byref(z), 1, C.byref(h)), self._ctx)
+        return Scene(self, h, n, int(sh_degree), model_to_world)
+
     def _scene_of(self, g):
         if isinstance(g, Scene):
             if g._r is not self:

@@ -67,6 +67,21 @@ class EmuRenderer:
         self.scene = sc
         self.n = arrs[0].shape[0]
 
+    def upload_compressed(self, chunks, packed, sh, sh_degree):
+        """sgs_scene_upload_compressed with host buffers (ply.read_compressed_payload's arrays)."""
+        c = np.ascontiguousarray(chunks, np.float32); p = np.ascontiguousarray(packed, np.uint32)
+        b = None if sh is None else np.ascontiguousarray(sh, np.uint8)
+        if self.scene is not None:
+            self.lib.sgs_scene_free(self.ctx, self.scene)
+        z = _capi.SgsCompressedScene(p.shape[0], c.shape[0], int(sh_degree), 0, c.ctypes.data, p.ctypes.data, b.ctypes.data if b is not None else None)
+        sc = C.c_void_p()
+        self.lib.check(self.lib.sgs_scene_upload_compressed(self.ctx, C.byref(z), 0, C.byref(sc)), self.ctx)
+        self.scene, self.n = sc, p.shape[0]
+
+    def scene_geom(self):
+        """float [N,11] of the scene as the device holds it (after one frame): mean, opacity, scale, quaternion wxyz."""
+        return self.debug(_capi.BUF_SCENE_GEOM, np.float32).reshape(-1, 11)
+
     def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
                chunk_cull=True, stats=True):
         flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL

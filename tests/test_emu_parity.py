@@ -328,3 +328,47 @@ def test_argument_errors_are_reported_not_swallowed(drv):
     # the context still renders after all of that
     img, st = drv.render(onp.Camera(32, 32, 30.0, 30.0, 16.0, 16.0, np.eye(4, dtype=np.float32)))
     assert np.isfinite(img).all() and st["n_gaussians"] == 200
+
+
+def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
+    """sgs_scene_upload_compressed under the emulator: (1) the known-answer words of tests/golden/compressed_ply_kat.json come out of the
+    layout kernel's dequantiser as the expected floats (SGS_BUF_SCENE_GEOM: the scene as the device holds it, by original index);
+    (2) a quantised scene renders like the same scene decoded by NumPy and uploaded as fp32 arrays — per-splat records and frame to
+    rounding — with the scene in Z-order made by the device radix sort (every Gaussian present exactly once)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_next_rows import _kat_payload, _check_kat
+    from sage_gs import ply
+    d = emu_harness.EmuRenderer(record_capacity=1 << 20)
+    try:
+        cases, chunks, packed, shb = _kat_payload()
+        d.upload_compressed(chunks, packed, shb, 3)
+        cam = onp.Camera(64, 48, 50.0, 50.0, 32.0, 24.0, np.eye(4, dtype=np.float32))
+        d.render(cam)
+        g = d.scene_geom()
+        assert g.shape == (len(cases), 11)
+        _check_kat(cases, g[:, 0:3], g[:, 4:7], g[:, 7:11], g[:, 3], None, None)
+        # a scene of a few chunks (so that the radix sort has several tiles... of one workgroup each), degree 3 and degree 0
+        rng = np.random.default_rng(12)
+        n = 5000
+        means = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 7, n)], 1).astype(np.float32)
+        scales = np.exp(rng.normal(-2.6, 0.5, (n, 3))).astype(np.float32)
+        quats = rng.normal(size=(n, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+        opac = rng.uniform(0.05, 1.0, n).astype(np.float32)
+        sh = (rng.normal(size=(n, 16, 3)) * 0.3).astype(np.float32)
+        cam = onp.Camera(160, 112, 120.0, 120.0, 80.0, 56.0, np.eye(4, dtype=np.float32))
+        for deg in (3, 0):
+            path = str(tmp_path / f"c{deg}.ply")
+            ply.save_compressed_ply(path, means, scales, quats, opac, sh[:, :(deg + 1) ** 2], deg)
+            arrays = ply.load_compressed_ply(path)
+            d.upload(*arrays)
+            ref, st_ref = d.render(cam)
+            d.upload_compressed(*ply.read_compressed_payload(path))
+            img, st = d.render(cam)
+            g = d.scene_geom()
+            assert np.allclose(g[:, 0:3], arrays[0], atol=1e-6) and np.allclose(g[:, 4:7], arrays[1], rtol=3e-6) and np.allclose(g[:, 3], arrays[3], atol=1e-7)
+            assert np.allclose(g[:, 7:11], arrays[2], atol=2e-6)
+            assert st["n_visible"] == st_ref["n_visible"] and abs(st["d_total"] - st_ref["d_total"]) <= 2      # (a rect edge may move with a 1e-6 scale change)
+            assert np.abs(img - ref).max() < 2e-4 and ref.max() > 0.2
+    finally:
+        d.close()

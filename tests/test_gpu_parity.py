@@ -575,6 +575,49 @@ def test_ply_scene_against_the_oracle(drv, tmp_path):
         assert img.max() > 0.2
 
 
+@pytest.mark.parametrize("deg", [3, 0])
+def test_compressed_ply_scene_against_the_oracle(drv, tmp_path, deg):
+    """f-1, the format InteriorGS actually ships (PlayCanvas compressed.ply, README.md:210-231 of the reference): a scene is quantised
+    into a file (chunk tables, 16-byte vertices, and at degree 3 the 8-bit `sh` element), the file's payload goes to the device AS IT IS
+    (Renderer.upload_compressed: dequantised by the layout kernel, Z-order made by the device radix sort) and the HIP frame is held
+    against the ORACLE's frame of the NumPy-decoded arrays — parity tolerance, threshold-sensitive pixels two-sidedly — and against the
+    oracle's frame of the ORIGINAL arrays within what the quantisation can move.  The device's own decode is compared array by array."""
+    from sage_gs import ply, scenes
+    from sage_gs import _capi
+    sc = scenes.make_room(30_000, seed=9)
+    m, s_, q, o, sh, _ = sc.as_tuple()
+    # (Z-order the scene before quantising, as a converter would: a chunk of 256 then spans decimetres, not the flat)
+    key = np.lexsort((m[:, 0] // 0.5, m[:, 1] // 0.5, m[:, 2] // 0.5))
+    m, s_, q, o, sh = m[key], s_[key], q[key], o[key], sh[key][:, :(deg + 1) ** 2]
+    path = str(tmp_path / f"room_c{deg}.ply")
+    ply.save_compressed_ply(path, m, s_, q, o, sh, deg)
+    arrays = ply.load_compressed_ply(path)
+    assert arrays[5] == deg
+    payload = ply.read_compressed_payload(path)
+    assert payload[1].shape == (30_000, 4) and (payload[2] is None) == (deg == 0)
+    scene = drv.r.upload_compressed(*payload, model_to_world=sc.model_to_world)
+    cams = scenes.room_cameras(sc, 640, 480, n_positions=1, n_yaw=4, seed=9)[1:3]
+    for cam in cams:
+        img = drv.r.render(cam, scene).cpu().numpy()
+        view = _oracle_view(sc, cam)
+        ref, aux = oracle_c.render(*arrays, view, want="image")
+        err = np.abs(img.astype(np.float64) - ref).max(axis=-1)
+        flagged = aux["margin"] < 20 * 1.0e-4            # (the device's exp / sqrt of the decode are a few ulp off NumPy's: see test_ply_scene_against_the_oracle)
+        assert err[~flagged].max() < 1e-3 and flagged.mean() < 0.02
+        ys, xs = np.nonzero(flagged & (err >= 1e-3))
+        if len(ys):
+            aux["recheck"].rel_margin = 20 * 1.0e-4
+            best, _, _ = aux["recheck"](ys, xs, img[ys, xs])
+            assert best.max() < 1e-3
+        orig, _ = oracle_c.render(m, s_, q, o, sh, deg, view, want="image")
+        d0 = np.abs(img.astype(np.float64) - orig)
+        assert d0.mean() < 0.03 and img.max() > 0.2       # quantisation: centimetres of position, 1/255 of colour and opacity
+    g = drv.r.debug_buffer(_capi.BUF_SCENE_GEOM, np.float32).reshape(-1, 11)
+    assert np.allclose(g[:, 0:3], arrays[0], atol=2e-6) and np.allclose(g[:, 4:7], arrays[1], rtol=5e-6) and np.allclose(g[:, 3], arrays[3], atol=1e-7)
+    assert np.allclose(g[:, 7:11], arrays[2], atol=3e-6)
+    scene.free()
+
+
 def test_ply_scene_at_full_size(drv, tmp_path):
     """f-1 at the size of configs[2]: a 3 M-Gaussian scene (trained-3DGS statistics, SH degree 3: a 744-MB file) written to
     a standard 3DGS PLY and read back; the loaded arrays go through `scenes.scene_from_arrays` + `ply.to_gaussians` (the

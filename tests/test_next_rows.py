@@ -308,3 +308,85 @@ def test_isaac_shim_runs_the_reference_frame_loop_unchanged(tmp_path, monkeypatc
         pos = np.array(point["position"], np.float32); pos[2] = CAMERA_HEIGHT
         assert np.allclose(c.view, camera.view_from_isaac_pose(pos, np.array(point["rotation"], np.float32)))
         assert sc.g is g and images[i].shape == (768, 1024, 3) and images[i][0, 0, 0] == (i + 1) % 256
+
+
+def _kat_payload():
+    """The known-answer vectors of tests/golden/compressed_ply_kat.json as ONE compressed scene: vertex i carries case i's word in its
+    field (zeros elsewhere).  Returns (cases, chunk table [1,18], packed [n,4], sh bytes [n,45])."""
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "compressed_ply_kat.json")))
+    ck = kat["chunk"]
+    chunks = np.array([ck["min"] + ck["max"] + ck["min_scale"] + ck["max_scale"] + ck["min_rgb"] + ck["max_rgb"]], np.float32)
+    cases = kat["cases"]
+    n = len(cases)
+    packed = np.zeros((n, 4), np.uint32)
+    shb = np.zeros((n, 45), np.uint8)
+    col = {"packed_position": 0, "packed_rotation": 1, "packed_scale": 2, "packed_color": 3}
+    for i, c in enumerate(cases):
+        if c["field"] == "sh_byte":
+            shb[i, :] = c["byte"]
+        else:
+            packed[i, col[c["field"]]] = int(c["word"], 16)
+    return cases, chunks, packed, shb
+
+
+def _check_kat(cases, means, scales, quats, opac, sh_dc, sh_rest, rtol=3e-6):
+    close = lambda a, b: np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=2e-6)
+    for i, c in enumerate(cases):
+        f = c["field"]
+        if f == "packed_position":
+            assert close(means[i], c["expect"]), (i, c, means[i])
+        elif f == "packed_scale":
+            assert close(scales[i], c["expect"]), (i, c, scales[i])
+        elif f == "packed_rotation":
+            assert close(quats[i], c["expect"]), (i, c, quats[i])
+        elif f == "packed_color":
+            assert close(opac[i], c["expect_opacity"]) and (sh_dc is None or close(sh_dc[i], c["expect_dc"])), (i, c, opac[i])
+        elif f == "sh_byte" and sh_rest is not None:
+            assert close(sh_rest[i], np.full_like(sh_rest[i], c["expect"])), (i, c, sh_rest[i][:3])
+
+
+def test_compressed_ply_known_answer_vectors(tmp_path):
+    """Byte-level known answers for the PlayCanvas compressed layout (words written by hand, expected values in exact arithmetic:
+    tests/golden/make_compressed_kat.py) through the NumPy decoder — from a FILE assembled here, so header parsing, element order and the
+    `sh` element are in the loop — and through the payload reader the device path uses."""
+    cases, chunks, packed, shb = _kat_payload()
+    n = len(cases)
+    path = tmp_path / "kat_compressed.ply"
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\nelement chunk 1\n")
+        for k in ply.CHUNK_PROPS + ply.CHUNK_COLOR_PROPS:
+            f.write(f"property float {k}\n".encode())
+        f.write(f"element vertex {n}\n".encode())
+        for k in ply.PACKED_PROPS:
+            f.write(f"property uint {k}\n".encode())
+        f.write(f"element sh {n}\n".encode())
+        for k in range(45):
+            f.write(f"property uchar f_rest_{k}\n".encode())
+        f.write(b"end_header\n")
+        f.write(chunks.astype("<f4").tobytes()); f.write(packed.astype("<u4").tobytes()); f.write(shb.tobytes())
+    m, s, q, o, sh, deg = ply.load_compressed_ply(str(path))
+    assert deg == 3 and sh.shape == (n, 16, 3)
+    _check_kat(cases, m, s, q, o, sh[:, 0, :], sh[:, 1:, :].reshape(n, -1))
+    c2, p2, b2, d2 = ply.read_compressed_payload(str(path))
+    assert d2 == 3 and (c2 == chunks).all() and (p2 == packed).all() and (b2 == shb).all()
+
+
+def test_compressed_encoder_round_trip_with_sh(tmp_path):
+    """save_compressed_ply (degree 3: the `sh` element too) -> load_compressed_ply: every attribute within its quantisation step."""
+    rng = np.random.default_rng(4)
+    n = 1000
+    means = rng.normal(size=(n, 3)).astype(np.float32) * 3
+    scales = np.exp(rng.normal(-3.0, 0.7, (n, 3))).astype(np.float32)
+    quats = rng.normal(size=(n, 4)); quats /= np.linalg.norm(quats, axis=1, keepdims=True)
+    opac = rng.uniform(0.02, 1.0, n).astype(np.float32)
+    sh = (rng.normal(size=(n, 16, 3)) * 0.4).astype(np.float32)
+    path = str(tmp_path / "c3.ply")
+    ply.save_compressed_ply(path, means, scales, quats, opac, sh, 3)
+    m, s, q, o, sh2, deg = ply.load_compressed_ply(path)
+    assert deg == 3
+    span = np.ptp(means, axis=0).max()
+    assert np.abs(m - means).max() <= span / 1023 and np.abs(np.log(s / scales)).max() <= np.ptp(np.log(scales)) / 1023
+    assert np.abs(o - opac).max() <= 0.5 / 255 + 1e-6 and np.abs(sh2[:, 1:] - np.clip(sh[:, 1:], -4, 4 - 8 / 256)).max() <= 4 / 256 + 1e-6
+    assert np.abs(sh2[:, 0] - sh[:, 0]).max() <= 0.5 / 255 / ply.SH_C0 + 1e-5
+    dot = np.abs(np.sum(q * quats, axis=1))
+    assert dot.min() > 1 - 3e-6 * 1023                      # rotations agree to the 10-bit step
