@@ -105,7 +105,7 @@ struct sgs_ctx {
     bool fuse = false;                       // SGS_FUSE=1: pipelined full frames go through the software pipelines below (default: they rotate over the lanes, one kernel per stage)
     int fuse_lds_pad = 0;                    // SGS_FUSE_LDS_PAD: bytes of dynamic LDS added to k_fused's workgroups (fewer of them per CU)
     struct PipeFrame { FrameGroup G; bool need_tf = false; int slot = 0; bool in_batch = false; };
-    static constexpr int kPipeMax = 3, kPipes = 2;
+    static constexpr int kPipeMax = 3, kPipes = 3;
     int pipe_depth = 2;                      // SGS_FUSE_DEPTH (2 or 3): the composite of frame t - depth rides with the projection of frame t; the
                                              // binning of a frame has depth - 1 steps to finish (depth 3: two binning streams alternate)
     int n_pipes = 2;                         // SGS_FUSE_PIPES (1 or 2): independent software pipelines, frames dealt to them in turn — while one
@@ -546,7 +546,8 @@ int pipe_push(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const
     int rc;
     sgs_ctx::Pipe& Q = ctx->pipes[ctx->pipe_pushed % ctx->n_pipes];
     if ((rc = pipe_streams(ctx, Q)) != SGS_OK) return rc;
-    hipStream_t sA = Q.sA, sB = ctx->pipe_serial ? sA : Q.sB[Q.t % (ctx->pipe_depth - 1)], sC = ctx->pipe_serial ? sA : Q.sC;
+    // depth 1: the pipe is ONE stream — k_fused{P(t), R(t-1)}, then B(t) — and the overlap comes from several such pipes side by side
+    hipStream_t sA = Q.sA, sB = (ctx->pipe_serial || ctx->pipe_depth == 1) ? sA : Q.sB[Q.t % (ctx->pipe_depth - 1)], sC = ctx->pipe_serial ? sA : Q.sC;
     const int lane = (int)(Q.t % (ctx->pipe_depth + 1));
     sgs_ctx::PipeFrame N;
     float* outs[1] = {out_rgb};
@@ -750,8 +751,9 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if (const char* env = getenv("SGS_PRE_GRID")) ctx->pre_grid = std::max(256, atoi(env));
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_FUSE")) ctx->fuse = atoi(env) != 0;
-    if (const char* env = getenv("SGS_FUSE_DEPTH")) ctx->pipe_depth = atoi(env) >= 3 ? 3 : 2;
-    if (const char* env = getenv("SGS_FUSE_PIPES")) ctx->n_pipes = atoi(env) >= 2 ? 2 : 1;
+    if (const char* env = getenv("SGS_FUSE_DEPTH")) ctx->pipe_depth = std::min(3, std::max(1, atoi(env)));
+    if (const char* env = getenv("SGS_FUSE_PIPES")) ctx->n_pipes = std::min((int)sgs_ctx::kPipes, std::max(1, atoi(env)));
+    if (ctx->n_pipes * (ctx->pipe_depth + 1) > kMaxLanes) ctx->n_pipes = kMaxLanes / (ctx->pipe_depth + 1);
     if (const char* env = getenv("SGS_FUSE_B_PRIO")) ctx->pipe_b_prio = atoi(env) != 0;
     if (const char* env = getenv("SGS_FUSE_SERIAL")) ctx->pipe_serial = atoi(env) != 0;
     if (const char* env = getenv("SGS_FUSE_LDS_PAD")) ctx->fuse_lds_pad = std::min(64 << 10, std::max(0, atoi(env)));

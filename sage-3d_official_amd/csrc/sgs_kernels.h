@@ -20,16 +20,6 @@ namespace sgs {
 
 #define SGS_LOG2E 1.44269504088896341f
 
-// The binning kernels (and the per-chunk cull) are chains of short launches whose waves walk lists serially: a critical path, little
-// arithmetic.  They run BESIDE another frame's composite, whose five waves per SIMD are issue-bound; at equal priority a binning wave
-// gets a sixth of the issue slots and its walk takes 2-4x as long as alone (r04b/c timelines: k_bin_emit 18 -> 62 us, k_expand<true>
-// 25 -> 53 us, and the frame after next waits for them).  Raised wave priority lets them win the issue arbitration; what they take from
-// the composite is their instruction count (a seventh of its own).
-#ifndef SGS_BIN_PRIO
-#define SGS_BIN_PRIO 3
-#endif
-#define SGS_RAISE_PRIO() __builtin_amdgcn_s_setprio(SGS_BIN_PRIO)
-
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
@@ -371,7 +361,6 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
 // chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
 #define SGS_CULL_THREADS 256
 __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     __shared__ unsigned s_wcnt[SGS_CULL_THREADS / SGS_WAVE];
@@ -752,7 +741,6 @@ __device__ __forceinline__ unsigned class_take(unsigned* s_cls, unsigned cls, bo
 __device__ __forceinline__ unsigned queue_class(unsigned c) { return c ? 32u - (unsigned)__clz((int)c) : 0u; }
 
 __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const unsigned* __restrict__ tile_count = S.tile_count; unsigned* __restrict__ tile_offset = S.tile_offset;
@@ -1061,7 +1049,6 @@ __device__ __forceinline__ void bin_walk_big(const FrameParams& P, const SuperGr
 // (~15 KB of LDS per workgroup at 1080p: what a binning workgroup takes from a CU is what the composite workgroups of
 // the frames in flight cannot use)
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
@@ -1156,7 +1143,6 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
 // work list: super-tile s with c records becomes ceil(c / SGS_SEG) jobs (super-tile, first record, records).
 #define SGS_SSCAN_THREADS 1024
 __global__ __launch_bounds__(SGS_SSCAN_THREADS) void k_stile_scan(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const unsigned* __restrict__ stile_count = S.stile_count; unsigned* __restrict__ stile_offset = S.stile_offset;
@@ -1203,7 +1189,6 @@ __global__ __launch_bounds__(SGS_SSCAN_THREADS) void k_stile_scan(const FrameGro
 }
 
 __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ binrec = S.binrec;
@@ -1260,7 +1245,6 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_emit(const FrameGroup G
 // No per-record atomics, and the 8-byte records reach HBM in runs instead of one by one.
 template <bool EMIT>
 __global__ __launch_bounds__(SGS_EXP_THREADS) void k_expand(const FrameGroup G) {
-    SGS_RAISE_PRIO();
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
     const uint4* __restrict__ srec = reinterpret_cast<const uint4*>(S.alt); const uint4* __restrict__ jobs = S.jobs;
