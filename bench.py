@@ -379,9 +379,12 @@ def main():
         Before the first measurement of the process: the pre-heat (--preheat-ms), the same sweep untimed."""
         warming[0] = True
         if args.preheat_ms > 0 and preheat["steps"] == 0:
+            runner(0, max(n_warm, 8), False)         # (the first call allocates the lanes' buffers — tens of ms that heat nothing)
+            preheat["steps"] += max(n_warm, 8)
+            torch.cuda.synchronize(device)
             t_end = time.perf_counter() + 1e-3 * args.preheat_ms
             # (N > 1: a fixed number of rounds — the tile-row mode exchanges in each, so every rank must run the same number)
-            while (preheat["steps"] < 8 * max(n_warm, 8)) if world > 1 else (time.perf_counter() < t_end and preheat["steps"] < 4096):
+            while (preheat["steps"] < 9 * max(n_warm, 8)) if world > 1 else (time.perf_counter() < t_end and preheat["steps"] < 4096):
                 runner(0, max(n_warm, 8), False)
                 preheat["steps"] += max(n_warm, 8)
         runner(0, n_warm, False)

@@ -4,7 +4,7 @@
 #   (frames in flight, and one frame at a time), PMC passes (counters in their own runs, --kernel-trace only) over the SAME
 #   pose sets, traffic.json keyed by pose set (bench.py quotes PMC figures only for the pose set they were taken on),
 #   the 4K sweep of BASELINE config 5.
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
@@ -12,10 +12,10 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json
 timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err; tail -c 300 $OUT/bench_k20.json
-echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
+echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres --no-upload-probe > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
 trace() { # name args...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-lowres "$@" > $OUT/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-upload-probe --preheat-ms 0 "$@" > $OUT/$name.log 2>&1
   local db=$(find $OUT/raw_$name -name "*.db" | head -1)
   python $ROOT/scripts/rocpd_stats.py $db > $OUT/kernel_stats_$name.csv
   python $ROOT/scripts/rocpd_timeline.py $db ${WIN:-0.04 0.34} > $OUT/timeline_$name.txt 2>/dev/null
@@ -29,7 +29,7 @@ pmc() { # set name flags... -- counters...
   local set=$1 name=$2; shift 2
   local flags=()
   while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-pipeline "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-pipeline --no-upload-probe --preheat-ms 0 "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
   mkdir -p $OUT/pmc_$set
   find $OUT/pmc_${set}_$name -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$set/$name.csv \;
   rm -rf $OUT/pmc_${set}_$name
@@ -43,9 +43,21 @@ passes() { # set skip flags...
   pmc $set grbm "$@" -- GRBM_GUI_ACTIVE
   python $ROOT/scripts/pmc_summary.py $OUT/pmc_$set $skip > $OUT/pmc_summary_$set.json
 }
+echo "== what a kernel waits for when it wants to start workgroups (VERDICT r3 item 1: SPI resource-allocation stalls, SQ wait cycles) — the default command, frames in flight"
+stall() { # name counters...
+  local name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/stall_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-upload-probe --preheat-ms 0 > $OUT/stall_$name.log 2>&1
+  mkdir -p $OUT/stalls
+  find $OUT/stall_$name -name "*counter_collection.csv" -exec cp {} $OUT/stalls/$name.csv \;
+  rm -rf $OUT/stall_$name
+}
+stall sq SQ_BUSY_CU_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE
+stall spi1 SPI_RA_REQ_NO_ALLOC_CSN SPI_RA_RES_STALL_CSN SPI_RA_VGPR_SIMD_FULL_CSN SPI_RA_LDS_CU_FULL_CSN
+stall spi2 SPI_RA_WAVE_SIMD_FULL_CSN SPI_RA_TMP_STALL_CSN SPI_RA_BAR_CU_FULL_CSN SPI_RA_TGLIM_CU_FULL_CSN
+python $ROOT/scripts/pmc_summary.py $OUT/stalls 10 > $OUT/pipeline_stalls.json 2>/dev/null; head -c 1500 $OUT/pipeline_stalls.json
 echo "== lane use of the composite (profiling build, the driver's first poses)"
 (cd $ROOT && make -s -C sage-3d_official_amd prof >/dev/null 2>&1; POSES=$(python -c "print(','.join(str((i*77)%256) for i in range(5,25)))") timeout 300 python scripts/tile_prof.py > $OUT/tile_prof_k20.txt 2>/dev/null; grep TOTAL $OUT/tile_prof_k20.txt | cut -c1-300)
-echo "== trained-like scene, bench line"; timeout 600 python $ROOT/bench.py --scene-kind trained --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_trained_k20.json 2> $OUT/bench_trained.err; tail -c 200 $OUT/bench_trained_k20.json
+echo "== trained-like scene, bench line"; timeout 600 python $ROOT/bench.py --scene-kind trained --steps 20 --warmup 5 --no-cpu-baseline --no-upload-probe > $OUT/bench_trained_k20.json 2> $OUT/bench_trained.err; tail -c 200 $OUT/bench_trained_k20.json
 echo "== PMC passes (default pose set)"; passes default 10
 echo "== PMC passes (driver's pose set)"; passes k20 5 --steps 20 --warmup 5
 python - <<PY
