@@ -199,6 +199,7 @@ static inline unsigned long long __ballot(bool pred) {
         if (((w.part[p] >> l) & 1ull) && w.vals[p][l]) m |= 1ull << l;
     return m;
 }
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool pred) { return __ballot(pred); }
 template <class T> static inline T __shfl(T v, int src) { return hipemu::shfl_from(v, src & 63); }
 template <class T> static inline T __shfl_up(T v, int d) { return hipemu::shfl_from(v, (int)(hipemu::me().tid.x & 63) - d); }
 template <class T> static inline T __shfl_xor(T v, int d) { return hipemu::shfl_from(v, (int)((hipemu::me().tid.x & 63) ^ (unsigned)d)); }
@@ -247,6 +248,15 @@ static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 // Wave-scope fence / barrier: a rendezvous of the wave's fibers orders their LDS accesses.
 #define __builtin_amdgcn_fence(order_, scope_) ((void)0)
 static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(true); }
+// v_mbcnt_lo/hi_u32_b32: base + the set bits of the mask half below this lane.
+static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned base) {
+    const unsigned lane = hipemu::me().tid.x & 63u;
+    return base + (unsigned)__builtin_popcount(lane >= 32u ? mask : mask & ((1u << lane) - 1u));
+}
+static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned base) {
+    const unsigned lane = hipemu::me().tid.x & 63u;
+    return base + (lane > 32u ? (unsigned)__builtin_popcount(mask & ((1u << (lane - 32u)) - 1u)) : 0u);
+}
 // v_readlane_b32: the value of lane `src` (callers read an active lane).
 static inline int __builtin_amdgcn_readlane(int v, int src) { return hipemu::shfl_from(v, src & 63); }
 // v_mov_b32 with a DPP modifier (the controls the kernels use): every lane of the wave takes part; a lane whose source
