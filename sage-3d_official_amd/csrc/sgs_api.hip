@@ -325,12 +325,13 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
     P.n_ranges = (int32_t)((scene->n + SGS_RANGE - 1) / SGS_RANGE);
-    P.win_tiles = SGS_WT; P.win_rows = std::max(1, P.gy); P.n_windows = 1;       // (one window of super-tiles: sgs_kernels.h, level 1)
+    P.n_windows = 1;                                                              // (one window of super-tiles: sgs_kernels.h, level 1)
+    P.limx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx); P.limy = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
     P.rec_capacity = L.rec_cap;
     P.job_capacity = (int32_t)std::min<int64_t>(L.job_cap, 0x7fffffff);
     P.flags = cfg.flags;
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
-        const double lx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx), ly = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
+        const double lx = P.limx, ly = P.limy;
         P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
         const double c0 = 1.001 * (3.0 * std::sqrt(2.0 * (double)P.dilation + 0.3163) + 1.0) + 0.5 + 1.0;      // + one pixel of slack
         P.cull_off[0] = (double)P.cx - 0.5 + c0;                                     // px + rb >= 0

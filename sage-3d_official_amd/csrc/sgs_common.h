@@ -64,22 +64,21 @@ struct FrameParams {
     int64_t n;                      // Gaussians
     int64_t n_chunks;               // ceil(n / 64)
     int32_t n_ranges;               // ceil(n / SGS_RANGE)
-    int32_t win_rows;               // tile rows per binning window = max(1, SGS_WT / gx)
-    int32_t n_windows;              // ceil((row_end - row_begin) / win_rows)
-    int32_t win_tiles;              // SGS_WT or SGS_WT_BIG: counters a binning workgroup keeps in (dynamic) LDS
+    int32_t n_windows;              // binning windows (one: the super-tiles of a band fit one window)
     int64_t rec_capacity;           // records the tile queues can hold (the super-tile queues: half as many 16-byte records)
     int32_t job_capacity;           // level-2 jobs the job table can hold
-    int32_t pad2_;
     uint32_t flags;
     int32_t row_stride, row_phase;  // interleaved tile rows: local row k of this call is frame row k * row_stride + row_phase
     int32_t cull_y0, cull_y1;       // pixel rows outside [cull_y0, cull_y1) cannot matter to this call (conservative)
-    uint32_t pad_;
+    // S2's clamp of t.xy / t.z, constants of the frame (a division each: once on the host, not once per Gaussian):
+    double limx, limy;              // clamp * (0.5 * width / fx), clamp * (0.5 * height / fy) — fp64 from the fp32 parameters, as the oracle forms them
     // k_chunk_cull's four planes (left, right, top, bottom), constants of the frame (filled on the host, fill_params):
     // a chunk is outside when  f u + off tz + nrm R + A s_max < 0  for one of them (chunk_outside, sgs_kernels.h)
     double cull_A;                  // 1.001 * 3 sqrt(2 (2 + lx^2 + ly^2)) max(fx, fy): radius bound = A s_max / tz + c0
     double cull_off[4];             // the plane's tz coefficient (image edge, principal point, c0)
     double cull_nrm[4];             // sqrt(f^2 + off^2)
 };
+static_assert(sizeof(FrameParams) == 304, "FrameGroup (8 slots, by value) must stay inside the 4-KiB kernarg segment");
 
 // Device-resident per-frame status; zeroed by a memset node at frame start, copied to pinned host
 // memory at frame end.

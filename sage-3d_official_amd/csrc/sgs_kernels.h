@@ -427,6 +427,19 @@ __device__ __forceinline__ void eval_sh(const float4* __restrict__ row0, float x
     out_r = res[0]; out_g = res[1]; out_b = res[2];
 }
 
+// 1 / sqrt(x) in fp64 from v_rsq_f64 and two Newton steps (~1 ulp; 9 instructions where sqrt followed by a division expands to ~45).
+// Used where the argument is a squared length of well-scaled values (a quaternion's norm, a view vector): 0, inf and NaN give
+// NaN products downstream exactly as 1.0 / sqrt(x) did (0 * inf there, 0 * NaN here).
+__device__ __forceinline__ double rsqrt64(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double e = fma(-(x * y), y, 1.0);      // 1 - x y^2
+        y = fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 // floor(v) clamped to [lo, hi]; NaN -> lo.  Mirrors clampi() of oracle/sgs_oracle.c.
 __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
     const double f = floor(v);
@@ -478,8 +491,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     bool maybe = front;
     if (front) {
         const float smax = fmaxf(g1.x, fmaxf(g1.y, g1.z));
-        const float inv = 1.0f / (float)tz;
-        const float lx = P.clamp * (0.5f * (float)P.width / P.fx), ly = P.clamp * (0.5f * (float)P.height / P.fy);
+        const float inv = __builtin_amdgcn_rcpf((float)tz);                      // (v_rcp_f32, 1 ulp: inside the 1.001 and the ex / ey below)
+        const float lx = (float)P.limx, ly = (float)P.limy;
         const float jf = fmaxf(P.fx, P.fy) * inv;
         const float lmax = jf * jf * (2.0f + lx * lx + ly * ly) * (smax * smax) + P.dilation;
         const float rb = (3.0f * sqrtf(2.0f * lmax + 0.3163f) + 1.0f) * 1.001f + 0.5f;
@@ -494,7 +507,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         // S2: Sigma = R S S^T R^T
         const double qw0 = g1.w, qx0 = g2.x, qy0 = g2.y, qz0 = g2.z;
         // (an fp64 division expands to ~35 instructions: one reciprocal per denominator, then multiplies)
-        const double iqn = 1.0 / sqrt(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
+        const double iqn = rsqrt64(qw0 * qw0 + qx0 * qx0 + qy0 * qy0 + qz0 * qz0);
         const double w = qw0 * iqn, x = qx0 * iqn, y = qy0 * iqn, z = qz0 * iqn;
         const double s0 = g1.x, s1 = g1.y, s2 = g1.z;
         const double M00 = (1 - 2 * (y * y + z * z)) * s0, M01 = (2 * (x * y - w * z)) * s1, M02 = (2 * (x * z + w * y)) * s2;
@@ -508,8 +521,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const double S22 = M20 * M20 + M21 * M21 + M22 * M22;
         // S2: EWA projection, cov' = J W Sigma W^T J^T + dilation I
         const double fx = P.fx, fy = P.fy;
-        const double limx = (double)P.clamp * (0.5 * (double)P.width / fx);
-        const double limy = (double)P.clamp * (0.5 * (double)P.height / fy);
+        const double limx = P.limx, limy = P.limy;
         const double itz = 1.0 / tz;
         const double xz = tx * itz, yz = ty * itz;
         const double txc = fmin(limx, fmax(-limx, xz)) * tz;
@@ -571,7 +583,8 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                 const double A64e = (0.5 * 1.4426950408889634) * (double)ca, B64e = 1.4426950408889634 * (double)cb,
                              C64e = (0.5 * 1.4426950408889634) * (double)cc;
                 const double det_e = A64e * C64e - 0.25 * B64e * B64e;
-                const float wx = det_e > 0.0 ? (float)(C64e / det_e) : 3.0e38f, wy = det_e > 0.0 ? (float)(A64e / det_e) : 3.0e38f;   // extent^2 per unit of q2
+                const double idet_e = 1.0 / det_e;                                               // (one reciprocal: the extents are padded below)
+                const float wx = det_e > 0.0 ? (float)(C64e * idet_e) : 3.0e38f, wy = det_e > 0.0 ? (float)(A64e * idet_e) : 3.0e38f;   // extent^2 per unit of q2
                 // what the composite needs to decide which 8x8 quadrants of a tile the splat can reach (k_tile_render):
                 // alpha >= alpha_min  <=>  q2 <= qmax = log2(o / alpha_min); half extents padded generously (the exact quadrant test follows)
                 qmax = __log2f(g0.w) - __log2f(P.alpha_min);
@@ -631,7 +644,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
     if (vis) {
         // S1: view direction in model space (fp64 difference, fp32 polynomial)
         const double dx = mx - P.campos[0], dy = my - P.campos[1], dz = mz - P.campos[2];
-        const double idn = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);
+        const double idn = rsqrt64(dx * dx + dy * dy + dz * dz);
         const float ux = (float)(dx * idn), uy = (float)(dy * idn), uz = (float)(dz * idn);
         const float4* row0 = shq + (chunk * P.sh_rows) * SGS_WAVE + lane;
         float r, g, b;
@@ -656,7 +669,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         // ... and the record holds the ROOTS a = sqrt(A), a k, c = sqrt(|C'|) (with the sign of C': negative = the fp32 conic
         // rounded to an indefinite form), so that the composite evaluates  q2 = U^2 + V^2,  U = a (dx + k dy),  V = c dy  with
         // two fmas for U, one for V and two for the sum (k_tile_render)
-        const double a64 = sqrt(A64 > 0.0 ? A64 : 0.0), c64 = Cp64 < 0.0 ? -sqrt(-Cp64) : sqrt(Cp64);
+        const double a64 = sqrt(A64 > 0.0 ? A64 : 0.0), c64 = copysign(sqrt(fabs(Cp64)), Cp64);
         // the opacity enters the composite's exponent: alpha / alpha_max = min(1, 2^-(q2 + nlo)),  nlo = log2(alpha_max / o)
         const float nlo = __log2f(P.alpha_max) - __log2f(g0.w);
         sp[0] = make_float4(sx, sy, (float)a64, (float)(a64 * k64));

@@ -245,6 +245,7 @@ static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; } 
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline double __builtin_amdgcn_rsq(double x) { return 1.0 / sqrt(x); }
 // Wave-scope fence / barrier: a rendezvous of the wave's fibers orders their LDS accesses.
 #define __builtin_amdgcn_fence(order_, scope_) ((void)0)
 static inline void __builtin_amdgcn_wave_barrier() { (void)__ballot(true); }
