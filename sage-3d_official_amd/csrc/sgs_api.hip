@@ -840,7 +840,8 @@ int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs
             if ((e = hipMalloc(reinterpret_cast<void**>(&keys[k]), (size_t)n * 8)) != hipSuccess) fail("hipMalloc", e);
             else if ((e = hipMalloc(reinterpret_cast<void**>(&idx[k]), (size_t)n * 4)) != hipSuccess) fail("hipMalloc", e);
         }
-        if (rc == SGS_OK && (e = hipMalloc(reinterpret_cast<void**>(&hist), (size_t)256 * nblocks * 4)) != hipSuccess) fail("hipMalloc", e);
+        const unsigned nscan = (256u * nblocks + SGS_RSCAN_SPAN - 1) / SGS_RSCAN_SPAN;          // (hist, then k_radix_scan's span sums)
+        if (rc == SGS_OK && (e = hipMalloc(reinterpret_cast<void**>(&hist), ((size_t)256 * nblocks + nscan) * 4)) != hipSuccess) fail("hipMalloc", e);
         if (rc == SGS_OK && (e = hipMalloc(reinterpret_cast<void**>(&bounds), 6 * 4)) != hipSuccess) fail("hipMalloc", e);
         if (rc == SGS_OK) {
             const unsigned init[6] = {~0u, ~0u, ~0u, 0u, 0u, 0u};
@@ -858,9 +859,9 @@ int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs
             int cur = 0;
             for (int shift = 0; shift < 64; shift += 8, cur ^= 1) {      // 63 key bits: eight stable passes
                 hipLaunchKernelGGL(sgs::k_radix_count, dim3(nblocks), dim3(256), 0, 0, (long long)n, keys[cur], shift, nblocks, hist);
-                hipLaunchKernelGGL(sgs::k_radix_scan, dim3(1), dim3(1024), 0, 0, 256u * nblocks, hist);
+                hipLaunchKernelGGL(sgs::k_radix_scan, dim3(nscan), dim3(1024), 0, 0, 256u * nblocks, hist, hist + (size_t)256 * nblocks);
                 hipLaunchKernelGGL(sgs::k_radix_scatter, dim3(nblocks), dim3(256), 0, 0, (long long)n, keys[cur], idx[cur], keys[cur ^ 1], idx[cur ^ 1],
-                                   shift, nblocks, hist);
+                                   shift, nblocks, hist, hist + (size_t)256 * nblocks);
             }
             d_perm = idx[cur];               // (an even number of passes: back in buffer 0)
             sc->perm_host = (unsigned*)malloc((size_t)n * 4);

@@ -372,3 +372,27 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
             assert np.abs(img - ref).max() < 2e-4 and ref.max() > 0.2
     finally:
         d.close()
+
+
+def test_z_order_sort_of_a_scene_that_spans_several_scan_workgroups():
+    """The upload's radix sort with more digit counters than one k_radix_scan workgroup scans (256 * ceil(n / 2048) > 4096): the laid-out
+    scene, read back by ORIGINAL index, is the input — every Gaussian present exactly once, i.e. the sort produced a permutation — and
+    the frame renders."""
+    rng = np.random.default_rng(5)
+    n = 40_000
+    means = rng.uniform(-3, 3, (n, 3)).astype(np.float32) + np.array([0, 0, 6], np.float32)
+    scales = np.full((n, 3), 0.01, np.float32)
+    quats = np.tile(np.array([1, 0, 0, 0], np.float32), (n, 1))
+    opac = rng.uniform(0.2, 1.0, n).astype(np.float32)
+    sh = rng.uniform(-1, 1, (n, 1, 3)).astype(np.float32)
+    d = emu_harness.EmuRenderer(record_capacity=1 << 20)
+    try:
+        d.upload(means, scales, quats, opac, sh, 0)
+        cam = onp.Camera(48, 32, 40.0, 40.0, 24.0, 16.0, np.eye(4, dtype=np.float32))
+        img, st = d.render(cam)
+        g = d.scene_geom()
+        assert g.shape == (n, 11)
+        assert np.array_equal(g[:, 0:3], means) and np.array_equal(g[:, 3], opac)
+        assert st["n_gaussians"] == n and np.isfinite(img).all() and img.max() > 0.05
+    finally:
+        d.close()
