@@ -848,7 +848,7 @@ int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs
             if ((e = hipMemcpy(bounds, init, sizeof init, hipMemcpyHostToDevice)) != hipSuccess) fail("hipMemcpy", e);
         }
         if (rc == SGS_OK) {
-            const unsigned g1 = (unsigned)std::min<int64_t>(1024, (n + 255) / 256), gn = (unsigned)((n + 255) / 256);
+            const unsigned g1 = (unsigned)std::min<int64_t>(512, (n + 255) / 256), gn = (unsigned)((n + 255) / 256);
             if (packed) {
                 hipLaunchKernelGGL((sgs::k_mean_bounds<true>), dim3(g1), dim3(256), 0, 0, (long long)n, means, Z, bounds);
                 hipLaunchKernelGGL((sgs::k_morton_keys<true>), dim3(gn), dim3(256), 0, 0, (long long)n, means, Z, bounds, keys[0], idx[0]);
