@@ -1584,6 +1584,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     if ((J) != (unsigned)SGS_BATCH) {                                                                  \
         const unsigned long long vb_ = __ballot(valid), lb_ = __ballot((valid) && Tm > 0.0f);          \
         ++pe_eval; pe_empty += vb_ == 0ull; pe_valid += (unsigned)__popcll(vb_); pe_useful += (unsigned)__popcll(lb_); \
+        pe_dead += lb_ == 0ull; pe_few += lb_ != 0ull && __popcll(lb_) <= 2;                               \
     }
 #define SGS_PROF_STAGED_ALL() atomicAdd(&s_pe[4], 1u);
 #define SGS_PROF_STAGED(qb) if ((qb) != 0u) atomicAdd(&s_pe[5], 1u);
@@ -1893,10 +1894,10 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
     unsigned long long pt_rank = 0, pt_bar1 = 0, pt_stage = 0, pt_job = 0, pt_rec = 0;     // sub-phases of the single-batch path (pt_sort = the rest: barrier 2)
-    unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0;
+    unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0, pe_dead = 0, pe_few = 0;    // (dead: no LIVE pixel inside the cut-off; few: one or two)
     const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
-    __shared__ unsigned s_pe[6];
-    if (threadIdx.x < 6) s_pe[threadIdx.x] = 0;
+    __shared__ unsigned s_pe[8];
+    if (threadIdx.x < 8) s_pe[threadIdx.x] = 0;
 #define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
 #else
 #define SGS_PROF_MARK(acc) do { } while (0)
@@ -2459,14 +2460,14 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         lo = hi;
     }
 #ifdef SGS_TILE_PROF
-    if (lane == 0) { atomicAdd(&s_pe[0], pe_eval); atomicAdd(&s_pe[1], pe_empty); atomicAdd(&s_pe[2], pe_valid); atomicAdd(&s_pe[3], pe_useful); }
+    if (lane == 0) { atomicAdd(&s_pe[0], pe_eval); atomicAdd(&s_pe[1], pe_empty); atomicAdd(&s_pe[2], pe_valid); atomicAdd(&s_pe[3], pe_useful); atomicAdd(&s_pe[6], pe_dead); atomicAdd(&s_pe[7], pe_few); }
     __syncthreads();
     if (tid == 0 && prof) {
         unsigned long long* o = prof + (size_t)tile * SGS_PROF_WORDS;
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
         o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = pt_job;
-        o[20] = pt_rec; o[21] = n_refine; o[22] = n_fill; o[23] = 0;
+        o[20] = pt_rec; o[21] = n_refine; o[22] = n_fill; o[23] = (unsigned long long)s_pe[6] | ((unsigned long long)s_pe[7] << 32);
     }
 #endif
     {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)

@@ -21,12 +21,15 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     p = r.debug_buffer(100, np.uint64).reshape(-1, 24).astype(np.float64)
     n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, pjob, prec = p.T[:21]
     nref, nfill = p.T[21], p.T[22]
+    pu = r.debug_buffer(100, np.uint64).reshape(-1, 24)[:, 23]
+    dead, few = (pu & np.uint64(0xffffffff)).astype(np.float64), (pu >> np.uint64(32)).astype(np.float64)
     clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
     for k_, v_ in (('ev', ev), ('val', val), ('use', use), ('stg', stg), ('hit', hit)): TOT[k_] += float(v_.sum())
     print(f"cam {ci}: render {st['ms']['render']*1e3:.0f} us  D={st['d_total']} D_f={st['d_fetched']} | tile-cycles sum: part {part.sum()/1e6:.1f}M sort {sort.sum()/1e6:.1f}M blend {blend.sum()/1e6:.1f}M total {tot.sum()/1e6:.1f}M | "
           f"groups/tile {ng.mean():.2f} batches/tile {nb.mean():.2f} | max tile total {tot.max()/1e3:.0f}k cyc (n={int(n[tot.argmax()])}) | span {(t0+tot).max()-t0.min():.0f} cyc")
     print(f"     blend evaluations (wave x splat): {ev.sum()/1e6:.2f}M = {ev.sum()/max(1,st['d_fetched']):.2f} per consumed record; no pixel inside the cut-off: "
           f"{100*emp.sum()/max(1,ev.sum()):.1f} %; lanes inside the cut-off {100*val.sum()/max(1,64*ev.sum()):.1f} %, of them on live pixels {100*use.sum()/max(1,val.sum()):.1f} %")
+    print(f"     evaluations with NO live pixel inside the cut-off: {100*dead.sum()/max(1,ev.sum()):.1f} %, with one or two: {100*few.sum()/max(1,ev.sum()):.1f} %")
     print(f"     staged splats (single-batch groups): {stg.sum()/1e6:.2f}M, reaching at least one quadrant: {100*hit.sum()/max(1,stg.sum()):.1f} %  (D = {st['d_total']/1e6:.2f}M records, D_f = {st['d_fetched']/1e6:.2f}M)")
     # occupancy over the kernel's span: how many tiles (workgroups) are in flight
     evs = np.concatenate([np.stack([rt0, np.ones_like(rt0)], 1), np.stack([rt1, -np.ones_like(rt0)], 1)])
@@ -41,7 +44,7 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     print(f"     start of a tile, mean cycles: entry -> job arrived {pjob.mean():.0f}, -> records arrived {prec.mean():.0f}, -> partitioned {part.mean():.0f}  (p90: {np.quantile(pjob,0.9):.0f}, {np.quantile(prec,0.9):.0f}, {np.quantile(part,0.9):.0f})")
     order = np.argsort(-tot)[:5]
     for o in order:
-        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} refinements {int(nref[o])} window fills {int(nfill[o])}")
+        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} (no live pixel {int(dead[o])}, 1-2 {int(few[o])}) refinements {int(nref[o])} window fills {int(nfill[o])}")
     # by size class
     for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
         m = (n > lo) & (n <= hi)
