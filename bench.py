@@ -63,7 +63,7 @@ def parse():
                          "9,9,9,9,8,8,8,8 split, or every N-th row")
     ap.add_argument("--rows-f32", action="store_true", help="N>=4: keep the fp32 framebuffer gather as the tile-row headline "
                                                              "(default there: bands packed to uint8 RGBA before the gather)")
-    ap.add_argument("--no-batch", action="store_true", help="camera mode: issue a sweep of <= 32 frames one by one as well, "
+    ap.add_argument("--no-batch", action="store_true", help="camera mode: issue a sweep of <= 128 frames one by one as well, "
                                                              "not as one render_batch call")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
     ap.add_argument("--secondary-timeout", type=float, default=120.0,
@@ -307,7 +307,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    SHORT = 32
+    # sweeps of up to SHORT steps are ONE render_batch call (round 4: with this round's kernels the batch entry is ahead of frames issued one by one on
+    # the lanes at 100 steps too: 4 710-4 740 vs 4 590-4 640 frames/s, same box, profiles/r04zi; it was 32 while the per-frame path won from ~40 frames on)
+    SHORT = int(os.environ.get("SGS_BENCH_SHORT", "128"))
     batch_frames = torch.zeros((min(SHORT, max(K, W, 8)), height, width, 3), dtype=torch.float32, device=device) \
         if pipelined and not args.no_batch and K <= SHORT else None
 
@@ -319,8 +321,8 @@ def main():
         data-path collective.  Returns this rank's per-frame average statistics; every frame is checked for overflow."""
         if short_sweep(count):
             # a short sweep is ONE call of the batch entry (the generate_images.py loop, SURVEY A4): frame groups of four per
-            # set of launches fill and drain the pipeline faster than frames issued one by one (0.235 vs 0.256 ms/frame at
-            # 20 frames; from ~40 frames on the per-frame path below is ahead)
+            # set of launches fill and drain the pipeline faster than frames issued one by one (round 3: 0.235 vs 0.256 ms/frame at
+            # 20 frames; round 4: 0.212 vs 0.217 at 100)
             n = count
             if warming[0]:           # the batch path rotates over eight sets of intermediates (4 frames x 2 streams): touch them
                 n = max(count, 8)    # all before the clock starts (buffers are allocated on first use), whatever W is
