@@ -108,7 +108,7 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
     w, h = int(resolution[0]), int(resolution[1])
     sequences, total = [], 0
     pool = ThreadPoolExecutor(max_workers=max(1, int(encode_workers))) if write else None
-    pending = []                 # [(handle, trajectory id, first index, frames, directory, names)]: copies in flight
+    pending = []                 # [(handle, [(trajectory id, index, path)])]: copies in flight
     jobs = []
 
     def encode(rgb, path):
@@ -117,34 +117,30 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
 
     def drain(keep):
         while len(pending) > keep:
-            hnd, tid, c0, b, tdir, names = pending.pop(0)
+            hnd, items = pending.pop(0)
             host = hnd.wait()                                     # [chunk,H,W,4] pinned; valid until the ring comes round again
-            for k in range(b):
+            for k, (tid, idx, path) in enumerate(items):
                 rgb = host[k, :, :, :3]
                 if on_frame is not None:
-                    on_frame(tid, c0 + k, rgb)
+                    on_frame(tid, idx, rgb)
                 if pool is not None:
-                    jobs.append(pool.submit(encode, np.ascontiguousarray(rgb), os.path.join(tdir, names[c0 + k])))
+                    jobs.append(pool.submit(encode, np.ascontiguousarray(rgb), path))
 
-    ring = None
+    # The scene's waypoints are ONE work list cut into chunks, whatever trajectory they belong to: a trajectory holds a dozen or two
+    # sampled points (generate_actions.py:586-592), and a batch per trajectory would fill and drain the GPU's frame pipeline every time —
+    # the reference's loop (generate_images.py:408-436) renders them one after the other within a scene just the same.
+    work = []                    # (trajectory id, index, camera, file path)
+    scheduled = set()
     for tr in trajectories:
         tdir = os.path.join(out_dir, f"trajectory_{tr['trajectory_id']}")
         names = [f"{scene_id}_{tr['trajectory_id']}_{i:03d}.jpg" for i in range(len(tr["points"]))]
-        done = os.path.isdir(tdir) and all(os.path.exists(os.path.join(tdir, n)) for n in names)
+        done = tdir in scheduled or (os.path.isdir(tdir) and all(os.path.exists(os.path.join(tdir, n)) for n in names))
         if (not done or force) and names:
+            scheduled.add(tdir)
             if write:
                 os.makedirs(tdir, exist_ok=True)
-            cams = cameras_for(tr["points"], resolution)
-            if ring is None:
-                ring = renderer.host_frames((chunk, h, w, 4), depth=2)
-                frames = None
-            for c0 in range(0, len(cams), chunk):
-                part = cams[c0:c0 + chunk]
-                drain(1)                                          # at most one copy in flight beside the batch being rendered
-                # [B,H,W,3] on the GPU; ONE pack and ONE device-to-host copy per chunk (B stacked images are one tall image)
-                frames = renderer.render_batch(part, scene, out=frames if frames is not None and frames.shape[0] >= len(part) else None)
-                buf = frames if frames.shape[0] == chunk else torch_pad(frames, chunk)
-                pending.append((ring.submit(buf, n=len(part)), tr["trajectory_id"], c0, len(part), tdir, names))
+            for i, cam in enumerate(cameras_for(tr["points"], resolution)):
+                work.append((tr["trajectory_id"], i, cam, os.path.join(tdir, names[i])))
         total += len(names)
         sequences.append({"scene_id": scene_id, "trajectory_id": tr["trajectory_id"],
                           "instruction_index": tr["instruction_index"], "frame_filenames": names,
@@ -152,6 +148,17 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
                                                          "rotation": p["rotation"]} for p in tr["points"]],
                           "sampling_info": {"sampled_points_count": len(names), "generated_images_count": len(names),
                                             "data_source": "sage_gs.sweep"}})
+    if work:
+        ring = renderer.host_frames((chunk, h, w, 4), depth=2)
+        frames = None
+        for c0 in range(0, len(work), chunk):
+            part = work[c0:c0 + chunk]
+            drain(1)                                              # at most one copy in flight beside the batch being rendered
+            # [B,H,W,3] on the GPU; ONE pack and ONE device-to-host copy per chunk (B stacked images are one tall image)
+            frames = renderer.render_batch([it[2] for it in part], scene,
+                                           out=frames if frames is not None and frames.shape[0] >= len(part) else None)
+            buf = frames if frames.shape[0] == chunk else torch_pad(frames, chunk)
+            pending.append((ring.submit(buf, n=len(part)), [(it[0], it[1], it[3]) for it in part]))
     drain(0)
     for j in jobs:
         j.result()                                                # (an encoder error surfaces here)

@@ -390,3 +390,59 @@ def test_compressed_encoder_round_trip_with_sh(tmp_path):
     assert np.abs(sh2[:, 0] - sh[:, 0]).max() <= 0.5 / 255 / ply.SH_C0 + 1e-5
     dot = np.abs(np.sum(q * quats, axis=1))
     assert dot.min() > 1 - 3e-6 * 1023                      # rotations agree to the 10-bit step
+
+
+def test_sweep_batches_run_across_trajectories(tmp_path):
+    """sweep.run cuts ONE work list per scene into GPU batches: three trajectories of 5, 7 and 4 waypoints with chunk = 8 are two batches
+    of 8, every frame reaches on_frame (and the encoder) under its own trajectory / index / file name, in order, and a trajectory id that
+    occurs twice is rendered once.  (A stand-in renderer that paints frame k of a batch with its camera's x position: no GPU.)"""
+    import torch
+
+    class Handle:
+        def __init__(self, host):
+            self.host = host
+
+        def wait(self):
+            return self.host
+
+    class Ring:
+        def __init__(self, shape):
+            self.shape = shape
+
+        def submit(self, buf, n):
+            host = np.zeros(self.shape, np.uint8)
+            host[:n, :, :, :3] = np.clip(buf[:n].numpy() * 255.0, 0, 255).astype(np.uint8)
+            return Handle(host)
+
+    class Fake:
+        batches = []
+
+        def host_frames(self, shape, depth=2):
+            return Ring(shape)
+
+        def render_batch(self, cams, scene, out=None):
+            self.batches.append(len(cams))
+            f = torch.zeros((len(cams), cams[0].height, cams[0].width, 3))
+            for k, c in enumerate(cams):
+                f[k] = float(np.linalg.inv(np.asarray(c.view, np.float64).reshape(4, 4))[0, 3]) / 100.0      # the camera's x, as a grey level
+            return f
+
+    def traj(tid, n, x0):
+        return {"trajectory_id": tid, "instruction_index": 0,
+                "points": [{"point": i, "position": [x0 + i, 0.0, 1.2], "rotation": [0.0, 0.0, 0.0, 1.0]} for i in range(n)]}
+    trs = [traj("a", 5, 10), traj("b", 7, 30), traj("a", 5, 10), traj("c", 4, 60)]
+    seen = []
+    fake = Fake()
+    n = sweep.run(fake, None, trs, "0042", str(tmp_path / "img"), resolution=(32, 24), chunk=8,
+                  on_frame=lambda tid, i, rgb: seen.append((tid, i, int(rgb[0, 0, 0]))))
+    assert fake.batches == [8, 8]
+    assert [(t, i) for t, i, _ in seen] == [("a", i) for i in range(5)] + [("b", i) for i in range(7)] + [("c", i) for i in range(4)]
+    x_of = {"a": 10, "b": 30, "c": 60}
+    assert all(abs(v - round((x_of[t] + i) / 100.0 * 255.0)) <= 1 for t, i, v in seen)
+    assert n == 21                                                    # (the metadata lists the repeated trajectory as the reference does)
+    for t, cnt in (("a", 5), ("b", 7), ("c", 4)):
+        assert sorted(os.listdir(tmp_path / "img" / f"trajectory_{t}")) == [f"0042_{t}_{i:03d}.jpg" for i in range(cnt)]
+    # a second run finds every file and renders nothing
+    fake.batches.clear()
+    sweep.run(fake, None, trs, "0042", str(tmp_path / "img"), resolution=(32, 24), chunk=8)
+    assert fake.batches == []
