@@ -312,6 +312,43 @@ def test_3m_scene_properties(drv, big_scene):
         assert differs.mean() < 0.02 and np.abs(again - full).max() < 0.25 and (~tie_tile).sum() > 1000
 
 
+def test_3m_scene_rigid_motion_invariance(drv, big_scene):
+    """BASELINE configs[2] at its real size, SH degree 0 evaluated (the higher bands live in the model frame): the scene and the camera moved by
+    the SAME rigid motion give the same frame.  Not bit for bit — every mean, covariance and view vector is computed from different
+    floats — but N_v and D to a few parts in 10^5 and all but a sliver of the pixels to 1e-3 (the rest: decisions within rounding of a
+    threshold, bounded by the largest single contribution)."""
+    from scipy.spatial.transform import Rotation
+    sc, cams = big_scene
+    means, scales, quats, opac, sh = sc.as_tuple()[:5]
+    cfg = onp.Config(sh_degree=0)
+    drv.upload(*sc.as_tuple())
+    ref = {}
+    for cam in (cams[1], cams[6]):
+        ref[id(cam)] = drv.render(_ocam(cam, sc), cfg)
+    rot = Rotation.from_euler("zyx", [37.0, -21.0, 63.0], degrees=True)
+    Q = rot.as_matrix(); t = np.array([0.7, -1.3, 2.1])
+    qx, qy, qz, qw = rot.as_quat()
+    a = np.array([qw, qx, qy, qz]); b = quats.astype(np.float64)
+    moved_q = np.stack([a[0] * b[:, 0] - a[1] * b[:, 1] - a[2] * b[:, 2] - a[3] * b[:, 3],
+                        a[0] * b[:, 1] + a[1] * b[:, 0] + a[2] * b[:, 3] - a[3] * b[:, 2],
+                        a[0] * b[:, 2] - a[1] * b[:, 3] + a[2] * b[:, 0] + a[3] * b[:, 1],
+                        a[0] * b[:, 3] + a[1] * b[:, 2] - a[2] * b[:, 1] + a[3] * b[:, 0]], 1).astype(np.float32)
+    moved_m = (means.astype(np.float64) @ Q.T + t).astype(np.float32)
+    drv.upload(moved_m, scales, moved_q, opac, sh, *sc.as_tuple()[5:])
+    inv = np.eye(4); inv[:3, :3] = Q.T; inv[:3, 3] = -Q.T @ t                     # model' -> model
+    for cam in (cams[1], cams[6]):
+        img0, st0 = ref[id(cam)]
+        oc = _ocam(cam, sc)
+        oc2 = onp.Camera(oc.width, oc.height, oc.fx, oc.fy, oc.cx, oc.cy, (np.asarray(oc.view, np.float64) @ inv).astype(np.float32))
+        img1, st1 = drv.render(oc2, cfg)
+        # (measured: N_v identical, D 13 and 8 of 6.5 M apart, 1.5e-4 / 1.8e-4 of the pixels beyond 1e-3, largest move 0.008 — a few times that is allowed)
+        assert abs(st1["n_visible"] - st0["n_visible"]) <= 1e-5 * st0["n_visible"] and abs(st1["d_total"] - st0["d_total"]) <= 2e-5 * st0["d_total"]
+        d = np.abs(img1 - img0).max(axis=2)
+        print(f"[parity] rigid motion at 3 M: N_v {st0['n_visible']} -> {st1['n_visible']}, D {st0['d_total']} -> {st1['d_total']}, pixels moved by > 1e-3: "
+              f"{(d > 1e-3).mean():.2e}, > 1e-5: {(d > 1e-5).mean():.2e}, max {d.max():.4f}")
+        assert (d > 1e-3).mean() < 1e-3 and d.max() < 0.05 and img0.max() > 0.2, f"{(d > 1e-3).mean():.2e} of the pixels moved by more than 1e-3 (max {d.max():.3f})"
+
+
 def test_room_500k_1080p_config2(drv):
     """BASELINE configs[1]: make_room(500 000, seed 1) at 1920x1080, SH degree 3.  Two poses: the full comparison with the
     oracle (counts, offsets, queue order, splat attributes, pixels) on two bands of tile rows each — the oracle finishes a
