@@ -23,6 +23,11 @@ namespace sgs {
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
 __device__ __forceinline__ unsigned long long lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
+// how many lanes BELOW this one are set in a wave mask: v_mbcnt_lo + v_mbcnt_hi (two instructions; the mask-and-popcount form is six and keeps a
+// 64-bit lane mask alive, which the compiler then hoists to the top of every loop nest that uses it)
+__device__ __forceinline__ unsigned lanes_below(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 
 // The XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0).  Each tile queue has one sub-queue per XCD:
 // the records an XCD's workgroups emit into a queue are contiguous, so that XCD's L2 can write-combine
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void k_radix_scatter(long long n, const unsign
             const unsigned long long bal = __ballot(valid && bit);
             peers &= bit ? bal : ~bal;
         }
-        const unsigned rank = (unsigned)__popcll(peers & lanemask_lt(lane));
+        const unsigned rank = lanes_below(peers);
         const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
         unsigned dst = 0;
         if (valid && rank == 0) dst = atomicAdd(&s_cur[wave][d], (unsigned)__popcll(peers));
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
     for (int w = 0; w < SGS_CULL_THREADS / SGS_WAVE; ++w) { before += w < wave ? s_wcnt[w] : 0u; total += s_wcnt[w]; }
     if (tid == 0) s_base = total ? atomicAdd(&S.st->n_live, total) : 0u;
     __syncthreads();
-    if (live) S.live_list[s_base + before + (unsigned)__popcll(m & lanemask_lt(lane))] = (unsigned)chunk;
+    if (live) S.live_list[s_base + before + lanes_below(m)] = (unsigned)chunk;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -655,7 +660,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             if (lane == leader) base = atomicAdd(&st->n_big, (unsigned)__popcll(wants));
             base = __shfl(base, leader);
             if (big) {
-                const unsigned k = base + (unsigned)__popcll(wants & lanemask_lt(lane));
+                const unsigned k = base + lanes_below(wants);
                 if (k < SGS_BIG_CAP) big_list[k] = (unsigned)pos; else big = false;
             }
         }
@@ -1021,7 +1026,7 @@ __device__ __forceinline__ void bin_walk(const SuperGrid& SG, const uint4* __res
                         unsigned base = 0;
                         if (lane == leader) base = atomicAdd(&s_arr[row + tx], (unsigned)__popcll(m));
                         base = __shfl(base, leader);
-                        if ((m >> lane) & 1ull) srec[base + (unsigned)__popcll(m & lanemask_lt(lane))] = br;
+                        if ((m >> lane) & 1ull) srec[base + lanes_below(m)] = br;
                     }
                 }
             }
@@ -1139,7 +1144,7 @@ __global__ __launch_bounds__(SGS_BIN_THREADS) void k_bin_count(const FrameGroup 
                     tl[u] = (unsigned)(i0 + u * 64 + lane);
                     c[u] = tl[u] < (unsigned)used ? s_cnt[tl[u]] : 0u;
                     const unsigned long long m = __ballot(c[u] != 0u);
-                    pre[u] = tot + (unsigned)__popcll(m & lanemask_lt(lane));
+                    pre[u] = tot + lanes_below(m);
                     tot += (unsigned)__popcll(m);
                 }
                 if (tot == 0u) continue;                                // (wave-uniform)
@@ -1437,7 +1442,7 @@ __device__ __forceinline__ void radix_pass(const unsigned* src_k, const unsigned
             const unsigned long long bal = __ballot(valid && bit);
             peers &= bit ? bal : ~bal;
         }
-        const unsigned rank = (unsigned)__popcll(peers & lanemask_lt(lane));
+        const unsigned rank = lanes_below(peers);
         const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
         unsigned base = 0;
         if (valid && rank == 0) base = atomicAdd(&sh.hist[wave][d], (unsigned)__popcll(peers));
@@ -1692,7 +1697,7 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         for (int gw = 0; gw < 4; ++gw) {                                                               \
             const unsigned long long mq = uniform_u64(s_ball[par][wave][gw]);                          \
             if ((mq >> lane) & 1ull)                                                                   \
-                lst[cntq + (unsigned)__popcll(mq & lanemask_lt(lane))] = ((unsigned)gw * 64u + (unsigned)lane) << 3;        \
+                lst[cntq + lanes_below(mq)] = ((unsigned)gw * 64u + (unsigned)lane) << 3;        \
             cntq += (unsigned)__popcll(mq);                                                            \
         }                                                                                              \
         if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned)(SGS_BATCH << 3);         /* inert tail */ \
@@ -1985,7 +1990,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         for (int w = 0; w < 4; ++w) { if (w < wave) { ex += s_wsum[w]; nb += s_wne[w]; } n_ne += s_wne[w]; }
         s_bcnt[tid] = ex;                             // scatter cursor
         if (c != 0u) {
-            const unsigned p = nb + (unsigned)__popcll(nem & lanemask_lt(lane));
+            const unsigned p = nb + lanes_below(nem);
             s_ne_end[p] = ex + c; s_ne_bkt[p] = (unsigned short)tid;
         }
         __syncthreads();
