@@ -61,8 +61,13 @@ def parse():
     ap.add_argument("--bands", choices=("balanced", "even", "interleave"), default="balanced",
                     help="tile-row shards: contiguous bands re-cut by cost from the previous batch (default), the even "
                          "9,9,9,9,8,8,8,8 split, or every N-th row")
-    ap.add_argument("--rows-f32", action="store_true", help="N>=4: keep the fp32 framebuffer gather as the tile-row headline "
-                                                             "(default there: bands packed to uint8 RGBA before the gather)")
+    ap.add_argument("--rows-f32", action="store_true", help="(accepted for round-3/4 command lines; fp32 is the tile-row headline at every N now)")
+    ap.add_argument("--rows-rgba8", action="store_true",
+                    help="N>1: make the uint8-RGBA gather (bands packed on every rank, 4-byte pixels travel) the tile-row headline; "
+                         "default: the fp32 gather north_star names at EVERY N (one metric along the 1/2/4/8 curve), uint8 under also_measured")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N>1: skip the check made before anything is timed — rank 0 renders pose 0 un-sharded and compares it BIT FOR BIT with "
+                         "the frame gathered from the N ranks' bands (single-frame and batched exchange); reported as `verify`")
     ap.add_argument("--no-batch", action="store_true", help="camera mode: issue a sweep of <= 128 frames one by one as well, "
                                                              "not as one render_batch call")
     ap.add_argument("--no-secondary", action="store_true", help="N>1: skip the second (other-mode) measurement")
@@ -291,10 +296,10 @@ def main():
     frames = [torch.zeros((height, width, 3), dtype=torch.float32, device=device) for _ in range(4 if pipelined else 1)]
     frame = frames[0]
     sharded = sharded_f32 = sharded_head = None
-    # N >= 4: the bands travel as uint8 RGBA (the array get_rgba() hands the reference's callers) in the HEADLINE — fp32 bands
-    # into rank 0 are ~25 MB per 1080p frame, i.e. all seven of its xGMI links at the frame rates a 4- or 8-way split reaches;
-    # the fp32 gather is then timed afterwards (also_measured.rows_f32).  N = 2: fp32 headline, rgba8 afterwards.
-    head_rgba8 = world >= 4 and args.bands != "interleave" and not args.rows_f32
+    # ONE metric along the 1/2/4/8-GPU curve: the headline gathers fp32 bands (north_star's output) at every N; the bands as
+    # uint8 RGBA (the array get_rgba() hands the reference's callers: a third of the bytes into rank 0) are timed afterwards
+    # (also_measured.rows_rgba8).  Rounds 3-4 switched the headline's payload to uint8 from N = 4 on: a curve of two metrics.
+    head_rgba8 = world > 1 and args.rows_rgba8 and args.bands != "interleave"
     if world > 1:
         sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
         sharded_head = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8") if head_rgba8 else sharded_f32
@@ -434,7 +439,62 @@ def main():
         guard = threading.Timer(args.secondary_timeout, bail_rows)
         guard.daemon = True
         guard.start()
+
+    def verify_rows():
+        """N > 1, before anything is timed: the frame gathered from the N ranks' bands against rank 0's own un-sharded render of
+        the same pose, BIT FOR BIT — through the single-frame exchange and through the batched, double-buffered one the timed
+        sweep uses (fp32 bands; and the uint8 gather against pack_rgba8 of the un-sharded frame).  Every rank takes part in the
+        exchanges; rank 0 compares and prints one line on stderr.  A mismatch does not stop the run: it is in the JSON line
+        (`verify.ok` false) and the judge / the driver can see that the number belongs to wrong frames."""
+        sel = [cams[pose(i)] for i in range(3)]
+        res = {"ok": True, "frames_checked": 0, "mismatching_pixels": 0, "max_abs_diff": 0.0,
+               "backend": dist.get_backend(), "ranks": dist.get_world_size(),
+               "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+               "what": "gathered frame == rank 0's un-sharded render of the same pose, bit for bit (torch.equal); single-frame exchange, "
+                       "batched exchange of 3 frames, and the uint8-RGBA gather against pack_rgba8 of the un-sharded frame"}
+        refs = []
+        if rank == 0:
+            for c in sel:
+                ref = torch.zeros((height, width, 3), dtype=torch.float32, device=device)
+                r.render(c, gs, out=ref)
+                refs.append(ref)
+
+        def check(got, ref):
+            res["frames_checked"] += 1
+            if not torch.equal(got, ref):
+                d = (got.float() - ref.float()).abs()
+                res["ok"] = False
+                res["mismatching_pixels"] += int((d.reshape(d.shape[0], d.shape[1], -1).amax(-1) > 0).sum().item())
+                res["max_abs_diff"] = max(res["max_abs_diff"], float(d.max().item()))
+        vs = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=False, batch=4)
+        fr = vs.render(sel[0], gs)                                  # single-frame exchange (even bands)
+        if rank == 0:
+            check(fr, refs[0])
+        g = vs.render_batch(sel, gs)                                # the batched exchange of the timed sweep
+        vs.finish()
+        if rank == 0:
+            for b in range(len(sel)):
+                check(g.frame(b), refs[b])
+        if args.bands != "interleave":
+            v8 = ShardedRenderer(r, height, width, balance=False, batch=4, output="rgba8")
+            g8 = v8.render_batch(sel, gs)
+            v8.finish()
+            if rank == 0:
+                for b in range(len(sel)):
+                    check(g8.frame(b), r.pack_rgba8(refs[b]))
+            del v8
+        del vs
+        fence()
+        if rank == 0:
+            print(f"[verify] backend={res['backend']} rccl_ranks={res['rccl_ranks']} of {world}: {res['frames_checked']} gathered frames "
+                  f"{'bit-identical to' if res['ok'] else 'DIFFER from'} rank 0's un-sharded renders"
+                  + ("" if res["ok"] else f" ({res['mismatching_pixels']} pixels, max |d| {res['max_abs_diff']:.3g})"), file=sys.stderr, flush=True)
+        return res
+
+    verify = None
     try:
+        if world > 1 and not args.no_verify:
+            verify = verify_rows()
         elapsed, avg = measure(run_rows if rows_primary else run_cameras, W, K, timing)
     except Exception as e:             # noqa: BLE001
         if guard is None:
@@ -515,7 +575,9 @@ def main():
             # what the headline value means, so that lines of different rounds are compared knowingly:
             #   1 (rounds 1-2)  N > 1: fp32 bands gathered;  2 (round 3)  N >= 4: bands gathered as uint8 RGBA (fp32 under also_measured.rows_f32);
             #   3 (round 4)     + an untimed pre-heat of the same sweep before the W warm-up steps (preheat_steps; --preheat-ms 0 = off)
-            "metric_version": 3,
+            #   4 (round 5)     N > 1: fp32 bands gathered at EVERY N again (uint8 under also_measured.rows_rgba8; --rows-rgba8 swaps them)
+            "metric_version": 4,
+            "verify": verify,
             "upload_ms": upload_ms,
             "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
                             "gather_us_per_frame": gather_us, "what": "ranks = the size the communicator reports; gather_us_per_frame = the "

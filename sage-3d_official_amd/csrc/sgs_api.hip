@@ -94,36 +94,9 @@ struct sgs_ctx {
     int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (SGS_EXP_GRID_ENV)
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
     int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP (SGS_PRE_GRID): its waves loop over the live list
-    int win_tiles_max = SGS_WT;              // largest binning window.  SGS_WINDOW_TILES=16384 lets bands of > 8192 tiles (4K) use the
-                                             // 64-KB window: binning alone 380 -> 305 us at 3840x2160, but such workgroups overlap worse
-                                             // with the other frames in flight (sweep 1717 -> 1657 frames/s), so it is opt-in
     bool morton = true;                      // Z-order the scene at upload (SGS_MORTON=0 keeps the caller's order): a chunk of 64
                                              // Gaussians is then a compact patch, which is what makes the per-chunk bounds
                                              // (k_chunk_bounds / chunk_outside) worth testing — trained scenes come in no spatial order
-    // The software pipeline of pipelined full frames (pipe_push / pipe_flush below): step t launches ONE grid that holds the projection of
-    // frame t and the composite of frame t-2 (k_fused) on stream A while the binning of frame t-1 runs on stream B.
-    bool fuse = false;                       // SGS_FUSE=1: pipelined full frames go through the software pipelines below (default: they rotate over the lanes, one kernel per stage)
-    int fuse_lds_pad = 0;                    // SGS_FUSE_LDS_PAD: bytes of dynamic LDS added to k_fused's workgroups (fewer of them per CU)
-    struct PipeFrame { FrameGroup G; bool need_tf = false; int slot = 0; bool in_batch = false; };
-    static constexpr int kPipeMax = 3, kPipes = 3;
-    int pipe_depth = 2;                      // SGS_FUSE_DEPTH (2 or 3): the composite of frame t - depth rides with the projection of frame t; the
-                                             // binning of a frame has depth - 1 steps to finish (depth 3: two binning streams alternate)
-    int n_pipes = 2;                         // SGS_FUSE_PIPES (1 or 2): independent software pipelines, frames dealt to them in turn — while one
-                                             // waits for a binning chain the other's grid has the chip
-    bool pipe_b_prio = false;                // SGS_FUSE_B_PRIO=1: the binning streams are created with the highest stream priority
-    bool pipe_serial = false;                // SGS_FUSE_SERIAL=1 (profiling): everything on stream A — k_fused's duration ALONE in a trace
-    struct Pipe {
-        PipeFrame f[kPipeMax];               // frames projected (and being binned) whose composite has not been launched: oldest first
-        int n = 0;
-        long long t = 0;                     // frames pushed so far: frame t uses the intermediates of lane lane0 + t % (depth + 1)
-        int lane0 = 0;
-        hipStream_t sA = nullptr, sB[2] = {}, sC = nullptr;       // grid / binning (frame t: sB[t % (depth - 1)]) / control
-        hipEvent_t evF[kPipeMax + 1] = {}, evB[kPipeMax + 1] = {}, evC[kPipeMax + 1] = {};   // per lane: projection launched / binning / live list
-        hipEvent_t fork = nullptr, done = nullptr;
-        bool busy = false;                   // has work in flight that no synchronisation has collected
-    } pipes[kPipes];
-    long long pipe_pushed = 0;               // frames pushed over all pipes (frame k goes to pipe k % n_pipes)
-    bool pipe_status_stale = false;          // frames of the pipes have completed whose status words are not in the host mirror yet
     unsigned long long* row_acc = nullptr;   // records queued per frame tile row, summed over the frames since the last
                                              // sgs_row_records(reset) — what cost-balanced tile-row bands are cut from
     const sgs_scene* last_scene = nullptr;
@@ -455,135 +428,6 @@ void note_last(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
     ctx->last_pixels = pixel_rows * cam->width;
 }
 
-// ---- frames in flight as a software pipeline -------------------------------------------------------------------------------------
-// Frame t:  P(t) = cull + projection,  B(t) = the six binning launches,  R(t) = sort + composite;  P -> B -> R.
-//   stream A (lane 0's):  ... [wait B(t-2)]  cull(t)  k_fused{ P(t) , R(t-2) }  [evF(t)] ...
-//   stream B (lane 1's):  ... [wait evF(t)]  B(t)  [evB(t)] ...
-// so B(t-1) runs beside k_fused{P(t), R(t-2)}: the binning's latency-bound launches hide behind a grid that keeps both the vector units
-// (composite waves) and HBM (projection waves) busy on every CU (sgs_kernels.h, k_fused).  A frame's output is complete two pushes
-// later, or after pipe_flush (sgs_frame_sync / the end of a batch), which launches the composites still owed as plain k_tile_render.
-int pipe_streams(sgs_ctx* ctx, sgs_ctx::Pipe& Q) {
-    if (Q.sA) return SGS_OK;
-    int lo = 0, hi = 0;                      // (numerically lower = more urgent; both 0 when the device has no priorities)
-    if (ctx->pipe_b_prio) SGS_HIP(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SGS_HIP(ctx, hipStreamCreateWithFlags(&Q.sA, hipStreamNonBlocking));
-    SGS_HIP(ctx, hipStreamCreateWithFlags(&Q.sC, hipStreamNonBlocking));
-    for (int k = 0; k < ctx->pipe_depth - 1; ++k) {
-        if (ctx->pipe_b_prio) SGS_HIP(ctx, hipStreamCreateWithPriority(&Q.sB[k], hipStreamNonBlocking, hi));
-        else SGS_HIP(ctx, hipStreamCreateWithFlags(&Q.sB[k], hipStreamNonBlocking));
-    }
-    for (int l = 0; l <= sgs_ctx::kPipeMax; ++l) {
-        SGS_HIP(ctx, hipEventCreateWithFlags(&Q.evF[l], hipEventDisableTiming));
-        SGS_HIP(ctx, hipEventCreateWithFlags(&Q.evB[l], hipEventDisableTiming));
-        SGS_HIP(ctx, hipEventCreateWithFlags(&Q.evC[l], hipEventDisableTiming));
-    }
-    SGS_HIP(ctx, hipEventCreateWithFlags(&Q.fork, hipEventDisableTiming));
-    SGS_HIP(ctx, hipEventCreateWithFlags(&Q.done, hipEventDisableTiming));
-    Q.lane0 = (int)(&Q - ctx->pipes) * (ctx->pipe_depth + 1);
-    return SGS_OK;
-}
-void pipe_destroy(sgs_ctx::Pipe& Q) {
-    for (hipStream_t q : {Q.sA, Q.sC, Q.sB[0], Q.sB[1]}) if (q) (void)hipStreamDestroy(q);
-    for (int l = 0; l <= sgs_ctx::kPipeMax; ++l)
-        for (hipEvent_t e : {Q.evF[l], Q.evB[l], Q.evC[l]}) if (e) (void)hipEventDestroy(e);
-    if (Q.fork) (void)hipEventDestroy(Q.fork);
-    if (Q.done) (void)hipEventDestroy(Q.done);
-}
-int pipes_pending(const sgs_ctx* ctx) { int n = 0; for (const sgs_ctx::Pipe& Q : ctx->pipes) n += Q.n; return n; }
-
-// the composite of a pipe's oldest frame, alone or (SP != nullptr) in one grid with the projection of a later frame
-int pipe_composite(sgs_ctx* ctx, sgs_ctx::Pipe& Q, const FrameSlot* SP, const sgs_scene* scene_p) {
-    hipStream_t sA = Q.sA;
-    sgs_ctx::PipeFrame& F = Q.f[0];
-    const FrameSlot& SR = F.G.s[0];
-    const int lane_r = (int)((Q.t - Q.n) % (ctx->pipe_depth + 1));
-    SGS_HIP(ctx, hipStreamWaitEvent(sA, Q.evB[lane_r], 0));
-    const unsigned ntiles = (unsigned)((SR.P.row_end - SR.P.row_begin) * SR.P.gx);
-    if (SP && ntiles > 0 && SP->P.n_chunks > 0) {
-        const unsigned grid = ntiles + (unsigned)((SP->P.n_chunks + 3) / 4);
-        if (F.need_tf) hipLaunchKernelGGL((sgs::k_fused<true>), dim3(grid), dim3(256), (size_t)ctx->fuse_lds_pad, sA, SR, *SP, scene_p->geom, scene_p->shq);
-        else hipLaunchKernelGGL((sgs::k_fused<false>), dim3(grid), dim3(256), (size_t)ctx->fuse_lds_pad, sA, SR, *SP, scene_p->geom, scene_p->shq);
-    } else {
-        launch_composite(F.G, 1, sA, false, false, F.need_tf);
-        if (SP && SP->P.n_chunks > 0) {     // (a frame without tiles: nothing to fuse the projection with)
-            FrameGroup GP; memset(&GP, 0, sizeof GP);
-            GP.geom = scene_p->geom; GP.shq = scene_p->shq; GP.cbound = scene_p->cbound; GP.row_acc = ctx->row_acc; GP.s[0] = *SP;
-            hipLaunchKernelGGL((sgs::k_preprocess<false>), dim3((unsigned)((SP->P.n_chunks + 3) / 4), 1u), dim3(256), 0, sA, GP);
-        }
-    }
-    if (!F.in_batch) ctx->pipe_status_stale = true;     // (the status words are fetched in one copy when the caller synchronises)
-    for (int k = 0; k + 1 < Q.n; ++k) Q.f[k] = Q.f[k + 1];
-    --Q.n;
-    return SGS_OK;
-}
-
-// launch the composites the pipes still owe (oldest first); a pipe's frames are complete when its `done` event is
-int pipe_flush(sgs_ctx* ctx) {
-    int rc;
-    for (sgs_ctx::Pipe& Q : ctx->pipes) {
-        if (Q.n == 0) continue;
-        while (Q.n > 0) if ((rc = pipe_composite(ctx, Q, nullptr, nullptr)) != SGS_OK) return rc;
-        SGS_HIP(ctx, hipGetLastError());
-        SGS_HIP(ctx, hipEventRecord(Q.done, Q.sA));
-        Q.busy = true;
-    }
-    return SGS_OK;
-}
-// host-wait for the pipes (after pipe_flush)
-int pipe_drain(sgs_ctx* ctx) {
-    for (sgs_ctx::Pipe& Q : ctx->pipes)
-        if (Q.busy) { SGS_HIP(ctx, hipEventSynchronize(Q.done)); Q.busy = false; }
-    return SGS_OK;
-}
-// make `stream` wait for the pipes' frames (after pipe_flush): their intermediates are lanes other paths use as well
-int pipe_order_before(sgs_ctx* ctx, hipStream_t stream) {
-    for (sgs_ctx::Pipe& Q : ctx->pipes)
-        if (Q.busy) SGS_HIP(ctx, hipStreamWaitEvent(stream, Q.done, 0));
-    return SGS_OK;
-}
-
-int pipe_push(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg, int row_begin, int row_end,
-              float* out_rgb, int slot, hipStream_t caller_stream, bool in_batch) {
-    int rc;
-    sgs_ctx::Pipe& Q = ctx->pipes[ctx->pipe_pushed % ctx->n_pipes];
-    if ((rc = pipe_streams(ctx, Q)) != SGS_OK) return rc;
-    // depth 1: the pipe is ONE stream — k_fused{P(t), R(t-1)}, then B(t) — and the overlap comes from several such pipes side by side
-    hipStream_t sA = Q.sA, sB = (ctx->pipe_serial || ctx->pipe_depth == 1) ? sA : Q.sB[Q.t % (ctx->pipe_depth - 1)], sC = ctx->pipe_serial ? sA : Q.sC;
-    const int lane = (int)(Q.t % (ctx->pipe_depth + 1));
-    sgs_ctx::PipeFrame N;
-    float* outs[1] = {out_rgb};
-    if ((rc = build_group(ctx, N.G, scene, cam, 1, cfg, row_begin, row_end, outs, slot, nullptr, Q.lane0 + lane)) != SGS_OK) return rc;
-    N.need_tf = need_tf_of(cfg, nullptr); N.slot = slot; N.in_batch = in_batch;
-    // Stream C (control): the frame's status word cleared and its live list made (k_chunk_cull: 6 us) BESIDE the grid stream A is
-    // running — on stream A the two cost a launch gap each, with no k_fused running, per frame.  The lane's previous frame
-    // (t - depth - 1) must be past its binning, the last reader of the lane's live list and masks.
-    if (!in_batch) {
-        // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
-        SGS_HIP(ctx, hipEventRecord(Q.fork, caller_stream));
-        SGS_HIP(ctx, hipStreamWaitEvent(sC, Q.fork, 0));
-    }
-    if (Q.t > ctx->pipe_depth) SGS_HIP(ctx, hipStreamWaitEvent(sC, Q.evB[lane], 0));
-    if (!in_batch) SGS_HIP(ctx, hipMemsetAsync(N.G.s[0].st, 0, sizeof(FrameStatus), sC));
-    ctx->slot_timed[slot] = false;
-    launch_cull(N.G, 1, sC);
-    SGS_HIP(ctx, hipEventRecord(Q.evC[lane], sC));
-    SGS_HIP(ctx, hipStreamWaitEvent(sA, Q.evC[lane], 0));
-    if (Q.n == ctx->pipe_depth) {
-        if ((rc = pipe_composite(ctx, Q, &N.G.s[0], scene)) != SGS_OK) return rc;      // k_fused{ P(t), R(t - depth) }
-    } else if (N.G.s[0].P.n_chunks > 0) {
-        hipLaunchKernelGGL((sgs::k_preprocess<false>), dim3((unsigned)((N.G.s[0].P.n_chunks + 3) / 4), 1u), dim3(256), 0, sA, N.G);
-    }
-    SGS_HIP(ctx, hipEventRecord(Q.evF[lane], sA));
-    SGS_HIP(ctx, hipStreamWaitEvent(sB, Q.evF[lane], 0));
-    if ((rc = launch_binning(ctx, N.G, 1, sB, nullptr)) != SGS_OK) return rc;
-    SGS_HIP(ctx, hipEventRecord(Q.evB[lane], sB));
-    SGS_HIP(ctx, hipGetLastError());
-    Q.f[Q.n++] = N;
-    ++Q.t; ++ctx->pipe_pushed;
-    note_last(ctx, scene, cam, N.G.s[0].P, slot, Q.lane0 + lane, false, caller_stream);
-    return SGS_OK;
-}
-
 // Enqueue a GROUP of nf <= SGS_MAX_GROUP frames of one scene — same resolution, same tile rows, one camera each — as
 // ONE set of five launches (blockIdx.y = frame; sgs_common.h FrameGroup).  Frame f uses the intermediates of lane
 // set0 + f and status slot slot0 + f; the launches go to `stream`.
@@ -596,7 +440,6 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
                   int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
                   float* out_aux, bool pipelined, bool in_batch, int set0, int stream_lane = -1) {
     int rc;
-    if (pipes_pending(ctx) > 0 && (rc = pipe_flush(ctx)) != SGS_OK) return rc;      // (frames of the software pipelines: their composites first)
     // The stream: a pipelined frame's own lane's; a batch's groups rotate over the streams of lanes 0 .. group_lanes-1 — the
     // SAME streams single pipelined frames use.  (r03y: the groups used to run on the streams of lanes 0 and 4; a process that
     // had issued one batch and then pipelined single frames owned four lane streams + the caller's, the runtime maps streams onto
@@ -614,10 +457,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
         SGS_HIP(ctx, hipEventRecord(L.fork, caller_stream));
         SGS_HIP(ctx, hipStreamWaitEvent(L.stream, L.fork, 0));
-        // (and after the software pipelines' frames, which use the lanes' intermediates from streams of their own)
-        if ((rc = pipe_order_before(ctx, L.stream)) != SGS_OK) return rc;
     } else if (!pipelined) {
-        if ((rc = pipe_order_before(ctx, caller_stream)) != SGS_OK) return rc;
         for (int f = 0; f < nf; ++f)               // these lanes' buffers may still be in use by a pipelined frame
             if (ctx->lanes[set0 + f].busy) SGS_HIP(ctx, hipStreamWaitEvent(caller_stream, ctx->lanes[set0 + f].done, 0));
     }
@@ -746,18 +586,11 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->row_acc), sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMemset", e);
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("hipStreamSynchronize", e);
+    // the tuning variables INTEGRATION.md §5 documents — nothing else is read from the environment
     if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
-    if (const char* env = getenv("SGS_WINDOW_TILES")) ctx->win_tiles_max = atoi(env) >= SGS_WT_BIG ? SGS_WT_BIG : SGS_WT;
     if (const char* env = getenv("SGS_EXP_GRID")) ctx->exp_grid = std::min(65535, std::max(8, atoi(env)));
     if (const char* env = getenv("SGS_PRE_GRID")) ctx->pre_grid = std::max(256, atoi(env));
     if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
-    if (const char* env = getenv("SGS_FUSE")) ctx->fuse = atoi(env) != 0;
-    if (const char* env = getenv("SGS_FUSE_DEPTH")) ctx->pipe_depth = std::min(3, std::max(1, atoi(env)));
-    if (const char* env = getenv("SGS_FUSE_PIPES")) ctx->n_pipes = std::min((int)sgs_ctx::kPipes, std::max(1, atoi(env)));
-    if (ctx->n_pipes * (ctx->pipe_depth + 1) > kMaxLanes) ctx->n_pipes = kMaxLanes / (ctx->pipe_depth + 1);
-    if (const char* env = getenv("SGS_FUSE_B_PRIO")) ctx->pipe_b_prio = atoi(env) != 0;
-    if (const char* env = getenv("SGS_FUSE_SERIAL")) ctx->pipe_serial = atoi(env) != 0;
-    if (const char* env = getenv("SGS_FUSE_LDS_PAD")) ctx->fuse_lds_pad = std::min(64 << 10, std::max(0, atoi(env)));
     if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_GROUP")) ctx->group = std::min(std::min(kMaxLanes, SGS_MAX_GROUP), std::max(1, atoi(env)));
     if (const char* env = getenv("SGS_GROUP_LANES")) ctx->group_lanes = std::max(1, atoi(env));
@@ -773,7 +606,6 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
 int sgs_destroy(sgs_ctx* ctx) {
     if (!ctx) return SGS_OK;
     (void)hipSetDevice(ctx->device);
-    (void)pipe_flush(ctx);
     (void)hipDeviceSynchronize();
     for (Lane& L : ctx->lanes) {
         void* bufs[] = {L.splats, L.vismask, L.bigmask, L.big_list, L.binrec, L.live_list, L.tile_count, L.tile_offset, L.tile_order,
@@ -784,7 +616,6 @@ int sgs_destroy(sgs_ctx* ctx) {
         if (L.fork) (void)hipEventDestroy(L.fork);
         if (L.done) (void)hipEventDestroy(L.done);
     }
-    for (sgs_ctx::Pipe& Q : ctx->pipes) pipe_destroy(Q);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->row_acc) (void)hipFree(ctx->row_acc);
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
@@ -801,7 +632,6 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records) {
     if (!ctx) return SGS_ERR_INVALID;
     if (max_records <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "max_records must be positive");
     (void)hipSetDevice(ctx->device);
-    (void)pipe_flush(ctx);
     (void)hipDeviceSynchronize();
     ctx->rec_cap_wanted = max_records;
     for (Lane& L : ctx->lanes) {      // force reallocation at the requested size (lanes other than 0: on next use)
@@ -986,7 +816,7 @@ int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int
 
 int sgs_scene_free(sgs_ctx* ctx, sgs_scene* scene) {
     if (!scene) return SGS_OK;
-    if (ctx) { (void)hipSetDevice(ctx->device); (void)pipe_flush(ctx); (void)hipDeviceSynchronize(); }
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipDeviceSynchronize(); }
     if (scene->geom) (void)hipFree(scene->geom);
     if (scene->shq) (void)hipFree(scene->shq);
     if (scene->cbound) (void)hipFree(scene->cbound);
@@ -1000,14 +830,8 @@ int sgs_frame_sync(sgs_ctx* ctx, sgs_stats* stats) {
     if (!ctx) return SGS_ERR_INVALID;
     if (ctx->last_slot < 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "no frame has been issued");
     SGS_HIP(ctx, hipSetDevice(ctx->device));
-    { int rc_ = pipe_flush(ctx); if (rc_ != SGS_OK) return rc_; }
     SGS_HIP(ctx, hipStreamSynchronize(ctx->last_stream));
     { int rc_ = drain_lanes(ctx); if (rc_ != SGS_OK) return rc_; }
-    { int rc_ = pipe_drain(ctx); if (rc_ != SGS_OK) return rc_; }
-    if (ctx->pipe_status_stale) {            // the software pipeline's frames: every status word in one copy (nothing is in flight now)
-        SGS_HIP(ctx, hipMemcpy(ctx->h_status, ctx->d_status, sizeof(FrameStatus) * kStatusRing, hipMemcpyDeviceToHost));
-        ctx->pipe_status_stale = false;
-    }
     collect(ctx, ctx->last_slot, stats, ctx->last_n, ctx->last_tiles, ctx->last_pixels, ctx->last_sh_rows, ctx->last_timed);
     // every frame issued since the previous synchronisation is checked, not just the last one
     int bad = -1, n_bad = 0;
@@ -1059,11 +883,6 @@ int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
         const bool pipelined = (cfg.flags & SGS_FLAG_PIPELINED) && (cfg.flags & SGS_FLAG_ASYNC) && ctx->n_lanes > 1 &&
                                !(cfg.flags & SGS_FLAG_FULL_SORT);
         int lane = 0;
-        if (pipelined && ctx->fuse && !out_aux && !(cfg.flags & SGS_FLAG_STATS)) {
-            // a frame of the software pipeline (per-stage events are not available there: the stages of different frames share launches)
-            if ((rc = pipe_push(ctx, scene, cam, cfg, tile_row_begin, tile_row_end, out_rgb, slot, stream, false)) != SGS_OK) return rc;
-            return SGS_OK;
-        }
         if (pipelined) { lane = ctx->next_lane; ctx->next_lane = (ctx->next_lane + 1) % ctx->n_lanes; }
         float* outs[1] = {out_rgb};
         if ((rc = enqueue_group(ctx, scene, cam, 1, cfg, tile_row_begin, tile_row_end, outs, slot, stream, timed, out_aux,
@@ -1128,25 +947,6 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
         int64_t px[kStatusRing]; int tl[kStatusRing];
         // once per chunk of frames, not once per frame: zero the status slots, fork the group streams from the caller's
         SGS_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(FrameStatus) * (size_t)cn, stream));
-        // full frames (or wide bands) go through the software pipeline: one frame per step, k_fused{P(t), R(t-2)} beside B(t-1);
-        // narrow bands — a rank's share of a tile-row-sharded frame, where the launches themselves are the cost — as frame groups
-        const bool piped = lanes && ctx->fuse && !(cfg.flags & SGS_FLAG_STATS) && 2 * (re0 - rb0) >= (cams[c0].height + SGS_TILE - 1) / SGS_TILE;
-        if (piped) {
-            if ((rc = ensure_lane_stream(ctx, ctx->lanes[0])) != SGS_OK) return rc;
-            SGS_HIP(ctx, hipEventRecord(ctx->lanes[0].fork, stream));
-            for (int q = 0; q < ctx->n_pipes; ++q) {
-                if ((rc = pipe_streams(ctx, ctx->pipes[q])) != SGS_OK) return rc;
-                SGS_HIP(ctx, hipStreamWaitEvent(ctx->pipes[q].sC, ctx->lanes[0].fork, 0));      // (stream A follows stream C: evC)
-                if (ctx->pipe_serial) SGS_HIP(ctx, hipStreamWaitEvent(ctx->pipes[q].sA, ctx->lanes[0].fork, 0));
-            }
-            for (int i = 0; i < cn; ++i) {
-                if ((rc = pipe_push(ctx, scene, &cams[c0 + i], cfg, rb0, re0, out_rgb + (size_t)(c0 + i) * (size_t)frame_stride, i, stream, true)) != SGS_OK)
-                    return rc;
-                px[i] = ctx->last_pixels; tl[i] = ctx->last_tiles;
-            }
-            if ((rc = pipe_flush(ctx)) != SGS_OK) return rc;
-            if ((rc = pipe_drain(ctx)) != SGS_OK) return rc;
-        } else
         if (lanes) {
             if ((rc = ensure_lane_stream(ctx, ctx->lanes[0])) != SGS_OK) return rc;
             SGS_HIP(ctx, hipEventRecord(ctx->lanes[0].fork, stream));
@@ -1161,7 +961,7 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
         const int n_streams = lanes ? std::min(GL, (cn + F - 1) / F) : 1;
         int left[kMaxLanes];                            // frames each stream still has to issue
         for (int sidx = 0; sidx < n_streams; ++sidx) left[sidx] = cn / n_streams + (sidx < cn % n_streams ? 1 : 0);
-        for (int i = 0, g = 0; i < cn && !piped; ++g) {
+        for (int i = 0, g = 0; i < cn; ++g) {
             const int sidx = g % n_streams;
             const int nf = std::min(F, left[sidx]);
             if (nf <= 0) continue;
@@ -1176,7 +976,7 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
             i += nf;
         }
         // ... wait for the lanes and fetch every frame's status in one copy
-        if (lanes && !piped) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl].stream));
+        if (lanes) for (int gl = 0; gl < GL; ++gl) SGS_HIP(ctx, hipStreamSynchronize(ctx->lanes[gl].stream));
         SGS_HIP(ctx, hipStreamSynchronize(stream));
         if ((rc = drain_lanes(ctx)) != SGS_OK) return rc;           // (frames issued outside this call)
         SGS_HIP(ctx, hipMemcpy(ctx->h_status, ctx->d_status, sizeof(FrameStatus) * (size_t)cn, hipMemcpyDeviceToHost));

@@ -24,8 +24,7 @@
 #ifndef SGS_PIN_VGPR
 #define SGS_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #endif
-#define SGS_WT 8192                 // tiles per binning window: per-workgroup counters live in LDS (32 KB) ...
-#define SGS_WT_BIG 16384            // ... or 64 KB (SGS_WINDOW_TILES=16384, bands of more than SGS_WT tiles: 4K in two windows, not four)
+#define SGS_WT 8192                 // super-tiles per binning window: per-workgroup counters live in LDS (32 KB)
 #define SGS_BIN_THREADS 512
 #define SGS_BIN_BLOCKS 512          // binning workgroups (2 per CU); each owns ranges b, b+B, b+2B, ...
 #define SGS_MAX_WINDOWS 16          // ceil(tiles / SGS_WT) the queues support: 131072 tiles (8192x4096 px)

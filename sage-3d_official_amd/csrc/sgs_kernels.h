@@ -2512,46 +2512,6 @@ __global__ __launch_bounds__(256, AUX ? 4 : SGS_RENDER_WGS) void k_tile_render(c
     render_tile<AUX, STATS, TF>(G.s[blockIdx.y], blockIdx.x);
 }
 
-// ---- frames in flight, by construction: k_fused = the composite of one frame + the projection of a later one ------------------
-// The composite is bound by vector issue slots (~0.8 busy) and leaves HBM idle; k_preprocess streams the scene at ~4 TB/s and leaves
-// the vector units idle (~0.35 busy).  Launched as two kernels on two streams they overlap badly: a composite workgroup holds 96
-// VGPRs per lane on every SIMD and five of them fill the register file, so the other kernel's workgroups only ever get the slots
-// the dispatcher happens to hand them between two composite workgroups (r03d: in-flight durations 1.6-2.5x the durations alone,
-// a sweep's frame time = preprocess + render + 20 us).  Here the two are ONE grid whose workgroups are dealt in a fixed ratio:
-// workgroup b of the launch is a projection workgroup (four chunks of the LATER frame's live list, one per wave) when
-// floor((b+1) nP / tot) > floor(b nP / tot), else the composite of tile-order position b - floor(b nP / tot) of the EARLIER frame
-// — nP = ceil(n_live / 4) read from the later frame's status word (k_chunk_cull has run), tot = tiles + nP — so every CU holds
-// the same mix of HBM-bound and issue-bound waves from the first workgroup to the last, whatever the dispatcher does.
-// The host launches tiles + ceil(n_chunks / 4) workgroups (n_live is not known there); the ones past tot end at once.
-template <bool TF>
-__global__ __launch_bounds__(256, SGS_RENDER_WGS) void k_fused(const FrameSlot SR, const FrameSlot SP, const float4* __restrict__ geom,
-                                                               const float4* __restrict__ shq) {
-    const unsigned b = blockIdx.x;
-    const unsigned n_live = SP.st->n_live;
-    const unsigned nP = (n_live + 3u) >> 2;
-    const unsigned nR = (unsigned)((SR.P.row_end - SR.P.row_begin) * SR.P.gx);
-    const unsigned tot = nR + nP;
-    if (b >= tot) return;                                      // (workgroup-uniform)
-    // floor(b nP / tot) for b and b + 1: a float estimate, corrected against the exact 64-bit products (uniform scalar work)
-    const float r_tot = 1.0f / (float)tot;
-    auto share = [&](unsigned x) {
-        const unsigned long long lhs = (unsigned long long)x * nP;
-        unsigned e = (unsigned)((float)x * (float)nP * r_tot);
-        while ((unsigned long long)e * tot > lhs) --e;
-        while ((unsigned long long)(e + 1u) * tot <= lhs) ++e;
-        return e;
-    };
-    const unsigned ip0 = share(b), ip1 = share(b + 1u);
-    if (ip1 > ip0) {
-        const unsigned k0 = ip0 * 4u + (threadIdx.x >> 6);
-        if (k0 < n_live)                                       // (wave-uniform)
-            preprocess_chunk(SP.P, geom, shq, SP.splats, SP.vismask, SP.bigmask, SP.big_list, SP.binrec, SP.st, (long long)SP.live_list[k0],
-                             (int)(threadIdx.x & 63));
-        return;
-    }
-    render_tile<false, false, TF>(SR, b - ip0);
-}
-
 // ------------------------------------------------------------------------------------------------
 // fp32 RGB -> uint8 RGBA, alpha 255; values clamped to [0,1], round to nearest.
 __global__ __launch_bounds__(256) void k_pack_rgba8(const float* __restrict__ rgb,

@@ -80,16 +80,9 @@ def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(640, 368))
 
 
-def test_two_binning_windows(drv, monkeypatch):
-    # 129 x 65 = 8385 tiles > SGS_WT (8192): the binning kernels walk two LDS windows ...
+def test_wide_band_of_tiles(drv):
+    # 129 x 65 = 8385 tiles (more than SGS_WT super-tile counters would be, were they per tile): one window of 33 x 17 super-tiles
     pc.case_full_grid_splat(drv, res=(2064, 1040))
-    # ... or one 16 k-tile window (dynamic LDS) when the big window is enabled
-    monkeypatch.setenv("SGS_WINDOW_TILES", "16384")
-    d = emu_harness.EmuRenderer()
-    try:
-        pc.case_full_grid_splat(d, res=(2064, 1040))
-    finally:
-        d.close()
 
 
 def test_depth_and_coverage_outputs(drv):
@@ -178,70 +171,6 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
     lib.check(lib.sgs_render_batch_strided(ctx, drv.scene, arr, len(cams), C.byref(cfg2), r0, r1, base, slab_rows * 96 * 3, None, None), ctx)
     for i in range(len(cams)):
         assert (slabs[i, :32] == seq[i][16:48]).all() and (slabs[i, 32:] == -1.0).all()
-
-
-@pytest.mark.parametrize("pipes,depth", [(1, 2), (2, 2), (2, 3)])
-def test_software_pipeline_frames_equal_sequential_frames(monkeypatch, pipes, depth):
-    """SGS_FUSE=1: pipelined frames go through the software pipelines of sgs_api.hip — k_fused{projection of frame t, composite of frame
-    t - depth} on one stream, the binning of the frames in between on another.  Frames of DIFFERENT resolutions and bands share a grid
-    there, a non-black background takes the other instantiation, an ordinary frame in the middle flushes the pipes: every frame must
-    equal the frame rendered alone, bit for bit."""
-    import ctypes as C
-    from sage_gs import _capi
-    monkeypatch.setenv("SGS_FUSE", "1"); monkeypatch.setenv("SGS_FUSE_PIPES", str(pipes)); monkeypatch.setenv("SGS_FUSE_DEPTH", str(depth))
-    d = emu_harness.EmuRenderer(record_capacity=1 << 20)
-    try:
-        scene, _ = onp.config1_scene(n=2500, seed=11)
-        d.upload(*scene)
-        lib, ctx = d.lib, d.ctx
-        cams, rows = [], []
-        for k in range(9):
-            V = np.eye(4, dtype=np.float32); V[0, 3] = 0.12 * k - 0.4; V[1, 3] = 0.05 * (k % 3)
-            w, h = ((96, 80), (64, 112), (130, 50))[k % 3]
-            cams.append(onp.Camera(w, h, 0.7 * w, 0.7 * w, w / 2.0, h / 2.0, V))
-            rows.append((0, -1) if k % 4 else (1, 3))                      # every fourth frame: a band of tile rows
-        for bg in ((0.0, 0.0, 0.0), (0.25, 0.5, 0.125)):
-            seq = []
-            for c, rw in zip(cams, rows):
-                o = np.full((c.height, c.width, 3), -1.0, np.float32)
-                seq.append(_render_bg(d, c, rw, bg, o, 0))
-            outs = [np.full((c.height, c.width, 3), -1.0, np.float32) for c in cams]
-            for i, (c, rw, o) in enumerate(zip(cams, rows, outs)):
-                _render_bg(d, c, rw, bg, o, _capi.FLAG_ASYNC | _capi.FLAG_PIPELINED)
-                if i == 5:                                                 # an ordinary frame while the pipes hold frames
-                    mid = np.full((cams[0].height, cams[0].width, 3), -1.0, np.float32)
-                    _render_bg(d, cams[0], rows[0], bg, mid, 0)
-                    assert (mid == seq[0]).all()
-            st = _capi.SgsStats()
-            lib.check(lib.sgs_frame_sync(ctx, C.byref(st)), ctx)
-            assert st.d_total > 0
-            for i, (a, b) in enumerate(zip(seq, outs)):
-                assert (a == b).all(), f"bg {bg}: pipelined frame {i} differs from the frame rendered alone"
-        # the batch entry (full frames -> the pipes as well)
-        same = [c for c in cams if (c.width, c.height) == (96, 80)]
-        arr = (_capi.SgsCamera * len(same))(*[_capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy,
-                                                                 np.asarray(c.view, np.float32).reshape(4, 4).tolist()) for c in same])
-        batch = np.zeros((len(same), 80, 96, 3), np.float32)
-        stats = (_capi.SgsStats * len(same))()
-        cfg = lib.default_config()
-        lib.check(lib.sgs_render_batch(ctx, d.scene, arr, len(same), C.byref(cfg), 0, -1, batch.ctypes.data, stats, None), ctx)
-        for i, c in enumerate(same):
-            single, st1 = d.render(c, stats=False)
-            assert (batch[i] == single).all() and stats[i].d_total == st1["d_total"] and stats[i].n_visible == st1["n_visible"]
-    finally:
-        d.close()
-
-
-def _render_bg(d, cam, rows, bg, out, flags):
-    import ctypes as C
-    from sage_gs import _capi
-    c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float32).reshape(4, 4).tolist())
-    k = d.lib.default_config()
-    for i in range(3):
-        k.bg[i] = bg[i]
-    k.flags = flags
-    d.lib.check(d.lib.sgs_render(d.ctx, d.scene, C.byref(c), C.byref(k), rows[0], rows[1], out.ctypes.data, None, None), d.ctx)
-    return out
 
 
 def test_batch_on_a_fresh_context_survives_overflowing_frames():
