@@ -57,12 +57,16 @@ class GsCamera:
         """float32 [H,W,3] on the GPU (linear RGB) — for consumers that stay on the device."""
         return self._r.render(self._camera(), self._scene, config=self._config)
 
-    def get_rgba(self) -> np.ndarray:
+    def get_rgba(self, copy: bool = True) -> np.ndarray:
         """uint8 [H,W,4], alpha 255 — what `cam.get_rgba()` returns (simple_env.py:1380; generate_images.py:428).  Render, pack and
-        the copy into a PINNED host buffer are one stream-ordered sequence with a single wait (Renderer.render_rgba8_host); the
-        array is renderer-owned, as Isaac Sim's is: callers copy what they keep (generate_images.py:431 `.copy()`,
-        simple_env.py:1386 `.astype`), and it stays valid until the next-but-one frame."""
-        return self._r.render_rgba8_host(self._camera(), self._scene, config=self._config)
+        the copy into a PINNED host buffer are one stream-ordered sequence with a single wait (Renderer.render_rgba8_host).
+
+        copy=True (default): a fresh array per call (a 640x480x4 memcpy, ~50 us) — safe for a stereo pair, several cameras on one
+        renderer, or a caller that keeps its last N observations.  copy=False: a VIEW of the renderer's pinned ring of depth 2, which all
+        cameras of one resolution on this renderer SHARE — the third get_rgba() at that resolution, from any of them, overwrites the
+        first; for the reference's own callers, which copy at once (generate_images.py:431 `.copy()`, simple_env.py:1386 `.astype`)."""
+        img = self._r.render_rgba8_host(self._camera(), self._scene, config=self._config)
+        return img.copy() if copy else img
 
     def _rgb_depth(self):
         """(rgb [H,W,3] float32 on the GPU, depth [H,W] float32 on the GPU): depth = the scene's expected view depth along

@@ -1,5 +1,13 @@
-"""The Isaac Sim side of the seam, as far as SAGE-3D's two render callers touch it — so that
-`simple_env.py` / `generate_images.py`-style code runs against the MI355X renderer WITHOUT an edit:
+"""The Isaac Sim side of the seam, as far as SAGE-3D's two render callers touch it.  Scope, precisely:
+the CALL SET OF generate_images.py's frame generator (recorded from a run of the reference itself: tests/golden/isaac_call_trace.json,
+replayed against this module by tests/test_next_rows.py) and the camera / world / stage calls of simple_env.py's render path listed
+below run against the MI355X renderer without an edit.  NOT covered: the rest of simple_env.py's simulator surface — `Usd.PrimRange`,
+`UsdGeom.Xformable`, the `UsdPhysics` collision APIs, `carb.settings`, `omni.replicator` / `omni.syntheticdata` / viewport modules
+(simple_env.py:457, 585-670): `install()` registers `pxr.Usd` / `UsdPhysics` / `Sdf` as EMPTY namespaces so that import lines
+resolve, and a call into them raises AttributeError.  SimpleVLNEnv as a whole therefore does not construct against this shim; its
+get_rgb()-shaped callers are served through adapter.GsCamera directly.
+
+    reference call                                              (file:line)                          here
 
     reference call                                              (file:line)                          here
     ----------------------------------------------------------  -----------------------------------  ---------------------------------

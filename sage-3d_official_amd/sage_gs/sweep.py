@@ -6,9 +6,10 @@ Input : `action_groundtruth.json` — `groundtruth_data[].{trajectory_id, instru
         generate_images.py:180-227).
 Work  : per trajectory, eye height forced to 1.2 m and the stored rotation passed as the Isaac orientation
         (generate_images.py:417-421), all frames of a trajectory rendered as ONE batch on the GPU.
-Output: `<out>/trajectory_<id>/<scene>_<traj>_<idx:03d>.jpg` and `<out>/image_metadata.json` with the
-        reference's fields (generate_images.py:414,572-609); existing trajectories are skipped unless
-        --force (the reference's file-existence resume, :229-286).
+Output: `<out>/images/trajectory_<id>/<scene>_<traj>_<idx:03d>.jpg` and `<out>/image_metadata.json` with the
+        reference's fields (generate_images.py:308-309,395,414,572-609 — the file set a recorded run of the reference wrote is
+        tests/golden/isaac_call_trace.json `files_written`); existing trajectories are skipped unless --force (the reference's
+        file-existence resume, :229-286).
 
     python -m sage_gs.sweep --scene scene.ply --actions action_groundtruth.json --scene-id 0001 --out frames/
 
@@ -60,7 +61,8 @@ def scenes_of_instance(action_root, instance_id: int = 0, total_instances: int =
 
 def find_scene_file(scene_root, scene_id: str):
     """(path, compressed?) of a scene's Gaussians under scene_root: `<id>.ply`, `<id>/3dgs.ply`, or the PlayCanvas-compressed
-    `<id>_compressed.ply` / `<id>/3dgs_compressed.ply` (README.md:210-231), or whatever `<id>.usda` references (adapter.open_stage)."""
+    `<id>_compressed.ply` / `<id>/3dgs_compressed.ply` (README.md:210-231).  (A stage file `<id>.usda` is resolved by
+    adapter.open_stage / parse_scene_usda, not here.)"""
     for rel, comp in ((f"{scene_id}.ply", False), (os.path.join(scene_id, "3dgs.ply"), False),
                       (f"{scene_id}_compressed.ply", True), (os.path.join(scene_id, "3dgs_compressed.ply"), True)):
         path = os.path.join(scene_root, rel)
@@ -97,19 +99,24 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
         chunk=64, on_frame=None, write=True, encode_workers=8):
     """Renders every trajectory (one GPU batch per `chunk` poses) and writes the reference's output layout.
     on_frame(trajectory_id, index, rgb uint8 [H,W,3]) — optional — sees each frame as it is handed to the JPEG encoder
-    (the array `cam.get_rgba()[:, :, :3]` would be in generate_images.py:428-432).
+    (the array `cam.get_rgba()[:, :, :3]` would be in generate_images.py:428-432).  The array is a VIEW of a pinned ring buffer that
+    is overwritten two chunks later: a callback that keeps frames must copy them (as generate_images.py:431 does).
 
     The host side is a two-deep pipeline: chunk i is packed to uint8 on the GPU and copied into a PINNED buffer on a copy stream
     while chunk i+1 is rendered (Renderer.host_frames), and its JPEGs are encoded by `encode_workers` threads (libjpeg releases the
     GIL) while the GPU works on — in the reference each frame is rendered, read back and encoded strictly in turn
-    (generate_images.py:408-436).  write=False skips the encoder (throughput of the render + readback path alone)."""
+    (generate_images.py:408-436).  write=False skips the encoder (throughput of the render + readback path alone).
+    Back-pressure: at most 4 x encode_workers frames wait for (or are in) the encoder — the GPU produces several thousand frames/s, eight
+    PIL threads encode 1-1.5 k/s, and every queued frame holds its own 2.4 MB (1024x768) copy: unbounded, a scene of a few thousand
+    waypoints held gigabytes per process.  The pool is shut down on every exit path."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(out_dir, exist_ok=True)
     w, h = int(resolution[0]), int(resolution[1])
     sequences, total = [], 0
     pool = ThreadPoolExecutor(max_workers=max(1, int(encode_workers))) if write else None
     pending = []                 # [(handle, [(trajectory id, index, path)])]: copies in flight
-    jobs = []
+    jobs = []                    # encoder futures not yet collected, oldest first (bounded: see the docstring)
+    max_jobs = 4 * max(1, int(encode_workers))
 
     def encode(rgb, path):
         from PIL import Image
@@ -124,46 +131,50 @@ def run(renderer, scene, trajectories, scene_id, out_dir, resolution=CAMERA_RESO
                 if on_frame is not None:
                     on_frame(tid, idx, rgb)
                 if pool is not None:
+                    while len(jobs) >= max_jobs:
+                        jobs.pop(0).result()                      # the encoders are behind: wait for the oldest frame (its error surfaces here)
                     jobs.append(pool.submit(encode, np.ascontiguousarray(rgb), path))
 
-    # The scene's waypoints are ONE work list cut into chunks, whatever trajectory they belong to: a trajectory holds a dozen or two
-    # sampled points (generate_actions.py:586-592), and a batch per trajectory would fill and drain the GPU's frame pipeline every time —
-    # the reference's loop (generate_images.py:408-436) renders them one after the other within a scene just the same.
-    work = []                    # (trajectory id, index, camera, file path)
-    scheduled = set()
-    for tr in trajectories:
-        tdir = os.path.join(out_dir, f"trajectory_{tr['trajectory_id']}")
-        names = [f"{scene_id}_{tr['trajectory_id']}_{i:03d}.jpg" for i in range(len(tr["points"]))]
-        done = tdir in scheduled or (os.path.isdir(tdir) and all(os.path.exists(os.path.join(tdir, n)) for n in names))
-        if (not done or force) and names:
-            scheduled.add(tdir)
-            if write:
-                os.makedirs(tdir, exist_ok=True)
-            for i, cam in enumerate(cameras_for(tr["points"], resolution)):
-                work.append((tr["trajectory_id"], i, cam, os.path.join(tdir, names[i])))
-        total += len(names)
-        sequences.append({"scene_id": scene_id, "trajectory_id": tr["trajectory_id"],
-                          "instruction_index": tr["instruction_index"], "frame_filenames": names,
-                          "trajectory_sampled_points": [{"point_id": p["point"], "position": p["position"],
-                                                         "rotation": p["rotation"]} for p in tr["points"]],
-                          "sampling_info": {"sampled_points_count": len(names), "generated_images_count": len(names),
-                                            "data_source": "sage_gs.sweep"}})
-    if work:
-        ring = renderer.host_frames((chunk, h, w, 4), depth=2)
-        frames = None
-        for c0 in range(0, len(work), chunk):
-            part = work[c0:c0 + chunk]
-            drain(1)                                              # at most one copy in flight beside the batch being rendered
-            # [B,H,W,3] on the GPU; ONE pack and ONE device-to-host copy per chunk (B stacked images are one tall image)
-            frames = renderer.render_batch([it[2] for it in part], scene,
-                                           out=frames if frames is not None and frames.shape[0] >= len(part) else None)
-            buf = frames if frames.shape[0] == chunk else torch_pad(frames, chunk)
-            pending.append((ring.submit(buf, n=len(part)), [(it[0], it[1], it[3]) for it in part]))
-    drain(0)
-    for j in jobs:
-        j.result()                                                # (an encoder error surfaces here)
-    if pool is not None:
-        pool.shutdown()
+    try:
+        # The scene's waypoints are ONE work list cut into chunks, whatever trajectory they belong to: a trajectory holds a dozen or two
+        # sampled points (generate_actions.py:586-592), and a batch per trajectory would fill and drain the GPU's frame pipeline every time —
+        # the reference's loop (generate_images.py:408-436) renders them one after the other within a scene just the same.
+        work = []                    # (trajectory id, index, camera, file path)
+        scheduled = set()
+        for tr in trajectories:
+            tdir = os.path.join(out_dir, "images", f"trajectory_{tr['trajectory_id']}")      # generate_images.py:308,395
+            names = [f"{scene_id}_{tr['trajectory_id']}_{i:03d}.jpg" for i in range(len(tr["points"]))]
+            done = tdir in scheduled or (os.path.isdir(tdir) and all(os.path.exists(os.path.join(tdir, n)) for n in names))
+            if (not done or force) and names:
+                scheduled.add(tdir)
+                if write:
+                    os.makedirs(tdir, exist_ok=True)
+                for i, cam in enumerate(cameras_for(tr["points"], resolution)):
+                    work.append((tr["trajectory_id"], i, cam, os.path.join(tdir, names[i])))
+            total += len(names)
+            sequences.append({"scene_id": scene_id, "trajectory_id": tr["trajectory_id"],
+                              "instruction_index": tr["instruction_index"], "frame_filenames": names,
+                              "trajectory_sampled_points": [{"point_id": p["point"], "position": p["position"],
+                                                             "rotation": p["rotation"]} for p in tr["points"]],
+                              "sampling_info": {"sampled_points_count": len(names), "generated_images_count": len(names),
+                                                "data_source": "sage_gs.sweep"}})
+        if work:
+            ring = renderer.host_frames((chunk, h, w, 4), depth=2)
+            frames = None
+            for c0 in range(0, len(work), chunk):
+                part = work[c0:c0 + chunk]
+                drain(1)                                              # at most one copy in flight beside the batch being rendered
+                # [B,H,W,3] on the GPU; ONE pack and ONE device-to-host copy per chunk (B stacked images are one tall image)
+                frames = renderer.render_batch([it[2] for it in part], scene,
+                                               out=frames if frames is not None and frames.shape[0] >= len(part) else None)
+                buf = frames if frames.shape[0] == chunk else torch_pad(frames, chunk)
+                pending.append((ring.submit(buf, n=len(part)), [(it[0], it[1], it[3]) for it in part]))
+        drain(0)
+        for j in jobs:
+            j.result()                                            # (an encoder error surfaces here)
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
     meta = {"scene_id": scene_id, "scene_name": scene_id, "total_image_sequences": len(sequences),
             "frames_per_sequence": "variable_based_on_action_sampling", "image_resolution": list(resolution),
             "camera_settings": {"focal_length": CAMERA_FOCAL_LENGTH, "height": CAMERA_HEIGHT},

@@ -17,6 +17,11 @@
   config1_golden.npz — a small BASELINE config-1 frame from the fp64 NumPy oracle (image, tile offsets,
                        queue order, per-splat rects): pins the oracle against regressions and gives the GPU
                        tests a fixture that does not depend on running the oracle.
+  isaac_call_trace.json — the reference's frame generator itself (generate_images.SequentialFastImageGenerator.process_single_file,
+                       generate_images.py:292-560) RUN here on a four-waypoint trajectory behind RECORDING stand-ins for the Isaac Sim
+                       modules it imports: every call it makes on SimulationApp / omni.usd / open_stage / World / Camera / pxr, in order,
+                       with its arguments — plus the files it wrote.  tests/test_next_rows.py replays that sequence against
+                       sage_gs.isaac_shim: the protocol the shim must serve is DATA recorded from the reference, not a transcription.
 Only DATA is written; no reference source text is copied.
 """
 import copy
@@ -178,6 +183,125 @@ def usda_fixture():
     print("usda_golden.json:", out["gauss"]["arcs"], len(out["gauss"]["attrs"]), "attrs;", out["scene_collision"]["arcs"])
 
 
+def isaac_trace_fixture():
+    """isaac_call_trace.json: what the reference's image generator asks of Isaac Sim, recorded by running it."""
+    import contextlib
+    import io
+    import tempfile
+    import types
+    events = []
+
+    def js(v):
+        if isinstance(v, np.ndarray):
+            return {"ndarray": v.astype(np.float64).tolist(), "dtype": str(v.dtype)}
+        if isinstance(v, (np.floating, np.integer)):
+            return v.item()
+        if isinstance(v, (list, tuple)):
+            return [js(x) for x in v]
+        if isinstance(v, dict):
+            return {str(k): js(x) for k, x in v.items()}
+        if isinstance(v, Rec):
+            return {"ref": v._name}
+        if isinstance(v, (str, int, float, bool)) or v is None:
+            return v
+        return {"repr": type(v).__name__}
+
+    class Rec:
+        """an object that records every call made on it (and on what those calls return)"""
+        _results = {}
+
+        def __init__(self, name):
+            object.__setattr__(self, "_name", name)
+
+        def __getattr__(self, attr):
+            return Rec(f"{self._name}.{attr}")
+
+        def __call__(self, *a, **kw):
+            events.append({"call": self._name, "args": js(list(a)), "kwargs": js(kw)})
+            res = Rec._results.get(self._name, None)
+            if callable(res):
+                return res(*a, **kw)
+            if self._name in Rec._results:
+                return res
+            return Rec(self._name + "()")
+
+        def __bool__(self):
+            return True
+
+    frame_no = [0]
+
+    def fake_rgba():
+        frame_no[0] += 1
+        img = np.zeros((768, 1024, 4), np.uint8); img[..., 3] = 255; img[..., 0] = frame_no[0]
+        return img
+    Rec._results = {
+        "open_stage": lambda **kw: os.path.exists(kw.get("usd_path", "")),
+        "Camera().get_rgba": fake_rgba,
+        "omni.usd.get_context().get_stage().GetPrimAtPath": lambda path: Rec("prim") if path != "/World/EnvLight" else None,
+    }
+    mods = {}
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name); m.__dict__.update(attrs); mods[name] = m
+        return m
+    mod("omni"); mod("omni.isaac"); mod("omni.isaac.core.utils")
+    mod("omni.isaac.kit", SimulationApp=Rec("SimulationApp"))
+    mod("omni.usd", get_context=Rec("omni.usd.get_context"))
+    mod("omni.isaac.core", World=Rec("World"))
+    mod("omni.isaac.core.utils.stage", open_stage=Rec("open_stage"))
+    mod("omni.isaac.sensor", Camera=Rec("Camera"))
+    mod("pxr", Gf=Rec("Gf"), UsdGeom=Rec("UsdGeom"), UsdLux=Rec("UsdLux"))
+    mods["omni"].usd = mods["omni.usd"]
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    sys.path.insert(0, os.path.join(REF, "data_pipeline", "training_data_construction"))
+    points = [{"point_id": i, "position": [1.0 + 0.1 * i, 2.0, 0.3], "rotation": [math.cos(0.2 * i), 0.0, 0.0, math.sin(0.2 * i)]} for i in range(4)]
+    try:
+        with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+            import generate_images as gi
+            os.makedirs(os.path.join(td, "traj", "0042")); os.makedirs(os.path.join(td, "usda")); os.makedirs(os.path.join(td, "actions", "0042"))
+            open(os.path.join(td, "usda", "0042.usda"), "w").write("#usda 1.0\n")
+            json.dump({"scenes": [{"scene_id": "0042", "samples": [{"trajectory_id": "7", "points": [], "instructions": ["go to the sofa"]}]}]},
+                      open(os.path.join(td, "traj", "0042", "train_trajectories_0042.json"), "w"))
+            json.dump({"groundtruth_data": [{"trajectory_id": "7", "instruction_index": 0, "sampled_points": points}]},
+                      open(os.path.join(td, "actions", "0042", "action_groundtruth.json"), "w"))
+            gen = gi.SequentialFastImageGenerator(os.path.join(td, "traj"), os.path.join(td, "usda"), os.path.join(td, "out"),
+                                                  action_root=os.path.join(td, "actions"), force=True)
+            files = gen.find_all_trajectory_files()
+            n_import = len(events)                 # (SimulationApp({...}) happens at import time)
+            ok = gen.process_single_file(files[0])
+            written = sorted(os.path.relpath(os.path.join(d, f), os.path.join(td, "out")) for d, _, fs in os.walk(os.path.join(td, "out")) for f in fs)
+            meta = json.load(open(os.path.join(td, "out", "0042", "image_metadata.json")))
+            # paths inside the trace are the temp dir's: keep them relative
+            for e in events:
+                for k, v in list(e["kwargs"].items()):
+                    if isinstance(v, str) and v.startswith(td):
+                        e["kwargs"][k] = os.path.relpath(v, td)
+            consts = {"CAMERA_RESOLUTION": list(gi.CAMERA_RESOLUTION), "CAMERA_FOCAL_LENGTH": gi.CAMERA_FOCAL_LENGTH, "CAMERA_HEIGHT": gi.CAMERA_HEIGHT,
+                      "WORLD_STEP_COUNT": gi.WORLD_STEP_COUNT, "RENDER_STEP_COUNT": gi.RENDER_STEP_COUNT}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        sys.modules.pop("generate_images", None)
+    assert ok, "the reference's process_single_file reported failure"
+
+    def strip(v):                  # the metadata as data: drop absolute paths and timestamps
+        if isinstance(v, dict):
+            return {k: strip(x) for k, x in v.items() if k != "source_files" and not any(t in k.lower() for t in ("time", "path", "dir"))}
+        if isinstance(v, list):
+            return [strip(x) for x in v]
+        return v
+    json.dump({"source": "generate_images.SequentialFastImageGenerator.process_single_file (generate_images.py:292-560) run behind recording stand-ins "
+                         "for the Isaac Sim modules; tests/golden/make_golden.py isaac_trace_fixture",
+               "constants": consts, "sampled_points": points, "events_at_import": n_import, "events": events,
+               "files_written": written, "image_metadata": strip(meta)},
+              open(os.path.join(HERE, "isaac_call_trace.json"), "w"), indent=1)
+    print("isaac_call_trace.json:", len(events), "calls,", len(written), "files written")
+
+
 def config1_fixture():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_np as onp
@@ -208,5 +332,6 @@ if __name__ == "__main__":
         pose_fixture()
         pose_env_fixture()
         usda_fixture()
+        isaac_trace_fixture()
     if "--reference-only" not in sys.argv:
         config1_fixture()

@@ -749,11 +749,27 @@ def test_gscamera_adapter_against_the_oracle(drv):
         assert d.dtype == np.float32 and d.min() >= 0.1 and d.max() <= 6.5
         assert np.abs(d[hit] - np.clip(exp, 0.1, 6.5)).max() < 2e-3 * 6.5
         assert (d[cov < 1e-5] == 6.5).all()
+    # get_rgba() hands out a fresh array by default: a SECOND camera of the same resolution on this renderer (a stereo pair) and later
+    # frames leave an observation the caller kept intact; copy=False is the renderer's shared pinned ring, which comes round after two
+    cam2 = GsCamera(drv.r, scene, prim_path="/World/Right", frequency=30, resolution=(320, 240))
+    cam2.initialize()
+    pts = _pose_points(4)
+    for c_, pt in ((cam, pts[0]), (cam2, pts[1])):
+        pos, orient = cc.datagen_pose(pt)
+        c_.set_world_pose(position=np.array(pos, np.float32), orientation=np.array(orient, np.float32))
+    first = cam.get_rgba()
+    keep = first.copy()
+    views = [cam2.get_rgba(), cam.get_rgba(), cam2.get_rgba()]
+    assert (first == keep).all() and not np.shares_memory(first, views[1]) and (views[0] == views[2]).all() and (views[1] == keep).all()
+    v0 = cam.get_rgba(copy=False)
+    cam2.get_rgba(copy=False)
+    v2 = cam.get_rgba(copy=False)
+    assert np.shares_memory(v0, v2) and (v2 == keep).all()          # (the ring of depth 2: the third frame lands in the first one's buffer)
     scene.free()
 
 
 def test_sweep_driver_against_the_oracle(drv, tmp_path):
-    """f-2: action_groundtruth.json -> trajectory_<id>/<scene>_<traj>_<idx>.jpg + image_metadata.json in the reference's
+    """f-2: action_groundtruth.json -> images/trajectory_<id>/<scene>_<traj>_<idx>.jpg + image_metadata.json in the reference's
     layout, AND every frame handed to the JPEG encoder equals the ORACLE's render of that waypoint's view to one uint8
     level (waypoints: poses produced by the reference's own trajectory code, tests/golden/pose_golden.json)."""
     import json, os
@@ -770,7 +786,7 @@ def test_sweep_driver_against_the_oracle(drv, tmp_path):
     n = sweep.run(drv.r, scene, sweep.load_trajectories(str(ap)), "0007", str(out), resolution=(256, 192),
                   on_frame=lambda tid, i, rgb: seen.__setitem__((tid, i), rgb.copy()))
     assert n == 5 and sorted(seen) == [("3", i) for i in range(5)]
-    files = sorted(os.listdir(out / "trajectory_3"))
+    files = sorted(os.listdir(out / "images" / "trajectory_3"))
     assert files == [f"0007_3_{i:03d}.jpg" for i in range(5)]
     meta = json.load(open(out / "image_metadata.json"))
     assert meta["scene_id"] == "0007" and meta["image_resolution"] == [256, 192] and meta["camera_settings"] == {"focal_length": 8.0, "height": 1.2}
@@ -783,6 +799,6 @@ def test_sweep_driver_against_the_oracle(drv, tmp_path):
         safe = aux["margin"] >= 1e-4
         d = np.abs(seen[("3", i)].astype(int) - _u8(ref).astype(int))
         assert d[safe].max() <= 1 and d.max() <= 4, f"sweep frame {i} vs the oracle"
-        im = np.asarray(Image.open(out / "trajectory_3" / files[i]))
+        im = np.asarray(Image.open(out / "images" / "trajectory_3" / files[i]))
         assert im.shape == (192, 256, 3) and np.abs(im.astype(int) - seen[("3", i)].astype(int)).mean() < 3.0      # JPEG q95
     scene.free()

@@ -222,12 +222,15 @@ class _FakeRenderer:
 
 
 def test_isaac_shim_runs_the_reference_frame_loop_unchanged(tmp_path, monkeypatch):
-    """The call sequence of generate_images.py:318-350 (scene set-up) and :408-436 (frame loop), written exactly as the reference
-    writes it — its own import lines, resolved by isaac_shim.install() — against a fake renderer: the stage's .usda is parsed, the
-    Gaussians beside the referenced USDZ are loaded with the prim's model->world transform and uploaded ONCE, every frame is drawn
-    from the pose the loop set (z forced to 1.2, the stored rotation as the Isaac orientation), with the lens the loop set."""
+    """The calls the reference's frame generator makes on Isaac Sim — RECORDED by running generate_images.SequentialFastImageGenerator.
+    process_single_file itself behind recording stand-ins (tests/golden/make_golden.py isaac_trace_fixture -> isaac_call_trace.json: 47
+    calls for a four-waypoint trajectory) — replayed one by one against sage_gs.isaac_shim with a fake renderer: the stage's .usda is
+    parsed, the Gaussians beside the referenced USDZ are loaded with the prim's model->world transform and uploaded ONCE, every frame is
+    drawn from the pose the loop set (z forced to 1.2, the stored rotation as the Isaac orientation), with the lens the loop set."""
     import sys
     from sage_gs import isaac_shim, scenes
+    trace = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "isaac_call_trace.json")))
+    K = trace["constants"]
     # a scene stage as sage3d_usda_builder writes it (tests/golden/usda_golden.json holds the shape), its USDZ, the .ply beside it
     scene_dir = tmp_path / "InteriorGS_usdz"; scene_dir.mkdir()
     (scene_dir / "0042.usdz").write_bytes(b"")
@@ -246,56 +249,62 @@ def test_isaac_shim_runs_the_reference_frame_loop_unchanged(tmp_path, monkeypatc
     saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("omni", "pxr", "isaacsim")}
     isaac_shim.configure(renderer=fake)
     isaac_shim._state["loader"] = None
+    images, results, world = [], [], None
     try:
         assert isaac_shim.install(force=True)
-        # ---- generate_images.py:24-33, verbatim -------------------------------------------------------------------------------
-        from omni.isaac.kit import SimulationApp
-        simulation_app = SimulationApp({"headless": True})
-        import omni.usd
-        from omni.isaac.core import World
-        from omni.isaac.core.utils.stage import open_stage
-        from omni.isaac.sensor import Camera
-        from pxr import Gf, UsdGeom, UsdLux
-        CAMERA_RESOLUTION, CAMERA_FOCAL_LENGTH, CAMERA_HEIGHT, WORLD_STEP_COUNT, RENDER_STEP_COUNT = (1024, 768), 8.0, 1.2, 5, 3
-        file_info = {"usd_file": str(usda)}
-        # ---- :320-350 ---------------------------------------------------------------------------------------------------------
-        omni.usd.get_context().close_stage()
-        assert not open_stage(usd_path=str(tmp_path / "missing.usda"))          # the reference's failure mode: False
-        assert open_stage(usd_path=file_info["usd_file"])
-        stage = omni.usd.get_context().get_stage()
-        if not stage.GetPrimAtPath("/World/EnvLight"):
-            dome = UsdLux.DomeLight.Define(stage, "/World/EnvLight")
-            dome.CreateIntensityAttr(30000.0)
-            dome.CreateColorAttr(Gf.Vec3f(1.0, 1.0, 1.0))
-        world = World()
-        world.reset()
-        for _ in range(WORLD_STEP_COUNT):
-            world.step(render=True)
-        sensor_cam_path = "/World/NaVILACamera"
-        cam = Camera(prim_path=sensor_cam_path, frequency=30, resolution=CAMERA_RESOLUTION)
-        cam.initialize()
-        cam_prim = stage.GetPrimAtPath(sensor_cam_path)
-        usd_cam = UsdGeom.Camera(cam_prim)
-        usd_cam.GetFocalLengthAttr().Set(CAMERA_FOCAL_LENGTH)
-        # ---- :408-436 ---------------------------------------------------------------------------------------------------------
-        points = [{"position": [1.0 + 0.1 * i, 2.0, 0.3], "rotation": [float(np.cos(0.2 * i)), 0.0, 0.0, float(np.sin(0.2 * i))]} for i in range(4)]
-        images = []
-        for frame_idx, point in enumerate(points):
-            position = np.array(point["position"], dtype=np.float32)
-            position[2] = CAMERA_HEIGHT
-            cam.set_world_pose(position=position, orientation=np.array(point["rotation"], dtype=np.float32))
-            for _ in range(RENDER_STEP_COUNT):
-                world.step(render=True)
-            img = cam.get_rgba()
-            assert img is not None and img.size > 0
-            images.append(img[:, :, :3].copy())
-        world.clear()
-        simulation_app.close()
+        import importlib
+        # the names the reference imports (the recorder registered its stand-ins under exactly these module attributes)
+        roots = {"SimulationApp": importlib.import_module("omni.isaac.kit").SimulationApp, "omni.usd": importlib.import_module("omni.usd"),
+                 "World": importlib.import_module("omni.isaac.core").World, "open_stage": importlib.import_module("omni.isaac.core.utils.stage").open_stage,
+                 "Camera": importlib.import_module("omni.isaac.sensor").Camera}
+        pxr = importlib.import_module("pxr")
+        roots.update(Gf=pxr.Gf, UsdGeom=pxr.UsdGeom, UsdLux=pxr.UsdLux)
+        assert not roots["open_stage"](usd_path=str(tmp_path / "missing.usda"))          # the reference's failure mode: False
+        store = dict(roots)
+
+        def lookup(name):
+            if name in store:
+                return store[name]
+            head, _, attr = name.rpartition(".")
+            assert head, f"the trace names {name!r}, which nothing returned"
+            return getattr(lookup(head), attr)
+
+        def decode(v):
+            if isinstance(v, dict) and "ndarray" in v:
+                return np.array(v["ndarray"], dtype=v["dtype"])
+            if isinstance(v, dict) and "ref" in v:
+                return lookup(v["ref"])
+            if isinstance(v, list):
+                return [decode(x) for x in v]
+            return v
+        for ev in trace["events"]:
+            args = [decode(a) for a in ev["args"]]
+            kwargs = {k: decode(v) for k, v in ev["kwargs"].items()}
+            if "usd_path" in kwargs:
+                kwargs["usd_path"] = str(tmp_path / kwargs["usd_path"])
+            if "resolution" in kwargs:
+                kwargs["resolution"] = tuple(kwargs["resolution"])
+            res = lookup(ev["call"])(*args, **kwargs)
+            store[ev["call"] + "()"] = res
+            results.append((ev["call"], res))
+            if ev["call"].endswith(".GetPrimAtPath") and res:
+                store["prim"] = res
+            if ev["call"] == "open_stage":
+                assert res, "the recorded run opened its stage"
+            if ev["call"] == "World":
+                world = res
+            if ev["call"] == "Camera().get_rgba":
+                assert res is not None and res.size > 0
+                images.append(res[:, :, :3].copy())
     finally:
         for k in [k for k in sys.modules if k.split(".")[0] in ("omni", "pxr", "isaacsim")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
         isaac_shim._state.update(renderer=None, stage=None, app=None)
+    points = trace["sampled_points"]
+    CAMERA_RESOLUTION, CAMERA_HEIGHT = tuple(K["CAMERA_RESOLUTION"]), K["CAMERA_HEIGHT"]
+    WORLD_STEP_COUNT, RENDER_STEP_COUNT = K["WORLD_STEP_COUNT"], K["RENDER_STEP_COUNT"]
+    assert CAMERA_RESOLUTION == (1024, 768) and K["CAMERA_FOCAL_LENGTH"] == 8.0 and CAMERA_HEIGHT == 1.2
     # one upload of the stage's Gaussians, with the prim's transform; freed when the stage closed
     assert len(fake.uploads) == 1
     g = fake.uploads[0]
@@ -441,8 +450,52 @@ def test_sweep_batches_run_across_trajectories(tmp_path):
     assert all(abs(v - round((x_of[t] + i) / 100.0 * 255.0)) <= 1 for t, i, v in seen)
     assert n == 21                                                    # (the metadata lists the repeated trajectory as the reference does)
     for t, cnt in (("a", 5), ("b", 7), ("c", 4)):
-        assert sorted(os.listdir(tmp_path / "img" / f"trajectory_{t}")) == [f"0042_{t}_{i:03d}.jpg" for i in range(cnt)]
+        assert sorted(os.listdir(tmp_path / "img" / "images" / f"trajectory_{t}")) == [f"0042_{t}_{i:03d}.jpg" for i in range(cnt)]
     # a second run finds every file and renders nothing
     fake.batches.clear()
     sweep.run(fake, None, trs, "0042", str(tmp_path / "img"), resolution=(32, 24), chunk=8)
     assert fake.batches == []
+
+
+def test_sweep_writes_the_files_a_recorded_run_of_the_reference_wrote(tmp_path):
+    """The reference's generator, run on a four-waypoint trajectory behind recording stand-ins (tests/golden/isaac_call_trace.json), wrote
+    `<scene>/images/trajectory_<id>/<scene>_<traj>_<idx:03d>.jpg` + `<scene>/image_metadata.json`; sweep.run on the same sampled points
+    must write the same file set, and every metadata field the two share must carry the same value (the reference adds the instruction
+    text and its own processing notes, which come from files the sweep driver does not read)."""
+    import torch
+    trace = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "isaac_call_trace.json")))
+
+    class Handle:
+        def __init__(self, host):
+            self.host = host
+
+        def wait(self):
+            return self.host
+
+    class Fake:
+        def host_frames(self, shape, depth=2):
+            fake = self
+
+            class Ring:
+                def submit(self, buf, n):
+                    host = np.zeros(shape, np.uint8)
+                    host[:n, :, :, :3] = np.clip(buf[:n].numpy() * 255.0, 0, 255).astype(np.uint8)
+                    return Handle(host)
+            return Ring()
+
+        def render_batch(self, cams, scene, out=None):
+            return torch.zeros((len(cams), cams[0].height, cams[0].width, 3))
+    actions = tmp_path / "action_groundtruth.json"
+    json.dump({"groundtruth_data": [{"trajectory_id": "7", "instruction_index": 0, "sampled_points": trace["sampled_points"]}]}, open(actions, "w"))
+    out = tmp_path / "out" / "0042"
+    n = sweep.run(Fake(), None, sweep.load_trajectories(str(actions)), "0042", str(out), chunk=4)
+    assert n == len(trace["sampled_points"])
+    written = sorted(os.path.relpath(os.path.join(d, f), tmp_path / "out") for d, _, fs in os.walk(tmp_path / "out") for f in fs)
+    assert written == trace["files_written"]
+    ours, ref = json.load(open(out / "image_metadata.json")), trace["image_metadata"]
+    for k in ("scene_id", "scene_name", "total_image_sequences", "frames_per_sequence", "image_resolution", "camera_settings"):
+        assert ours[k] == ref[k], k
+    so, sr = ours["sequences"][0], ref["sequences"][0]
+    for k in ("scene_id", "trajectory_id", "instruction_index", "frame_filenames", "trajectory_sampled_points"):
+        assert so[k] == sr[k], k
+    assert so["sampling_info"]["sampled_points_count"] == sr["sampling_info"]["sampled_points_count"] == so["sampling_info"]["generated_images_count"]
