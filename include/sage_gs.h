@@ -235,8 +235,11 @@ enum {
     SGS_BUF_SLOT_IDS     = 2,      /* uint32[S]    slot i holds Gaussian i: i if live this frame, 0xFFFFFFFF if culled; S = ceil(N/64)*64 */
     SGS_BUF_CHUNK_SKIPPED = 4,     /* uint8[ceil(N/64)]  1 = the 64-Gaussian chunk (in layout order) was skipped by its bounds */
     SGS_BUF_SPLATS       = 3,      /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
-    SGS_BUF_SCENE_GEOM   = 5       /* float[N][11] of the LAST RENDERED scene as the device holds it, by original index: mean xyz, opacity, scale xyz,
+    SGS_BUF_SCENE_GEOM   = 5,      /* float[N][11] of the LAST RENDERED scene as the device holds it, by original index: mean xyz, opacity, scale xyz,
                                     * quaternion wxyz (as uploaded / as dequantised from a compressed payload) */
+    SGS_BUF_SCENE_SH     = 6       /* float[N][3 (d+1)^2] of the LAST RENDERED scene, by original index, [coefficient][channel]: the SH coefficients the
+                                    * projection kernel evaluates — the fp32 rows as uploaded, or (a scene uploaded from the compressed payload, which
+                                    * keeps its 8-bit coefficients as bytes in HBM) those bytes dequantised exactly as the kernel does */
 };
 int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes);
 

@@ -35,7 +35,8 @@ struct Scratch {
 
 struct sgs_scene {
     int64_t n = 0, n_chunks = 0;
-    int sh_degree = 0, sh_rows = 0;
+    int sh_degree = 0, sh_rows = 0;     // sh_rows: 16-byte rows of SH per Gaussian (12 at degree 3; 4 when sh_packed)
+    bool sh_packed = false;             // uploaded from the compressed payload: the 8-bit coefficients stay bytes in HBM (k_scene_layout<true>)
     float4* geom = nullptr;
     float4* shq = nullptr;
     float4* cbound = nullptr;           // per chunk: bounding sphere of the means + largest scale (k_chunk_bounds)
@@ -302,7 +303,7 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.limx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx); P.limy = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
     P.rec_capacity = L.rec_cap;
     P.job_capacity = (int32_t)std::min<int64_t>(L.job_cap, 0x7fffffff);
-    P.flags = cfg.flags;
+    P.flags = (cfg.flags & ~SGS_PFLAG_SH_PACKED) | (scene->sh_packed ? SGS_PFLAG_SH_PACKED : 0u);
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
         const double lx = P.limx, ly = P.limy;
         P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
@@ -718,11 +719,12 @@ int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs
 }
 
 // a new scene object with its device buffers
-int new_scene(sgs_ctx* ctx, int64_t n, int sh_degree, sgs_scene** out) {
+int new_scene(sgs_ctx* ctx, int64_t n, int sh_degree, bool sh_packed, sgs_scene** out) {
     sgs_scene* sc = new (std::nothrow) sgs_scene;
     if (!sc) SGS_FAIL(ctx, SGS_ERR_OOM, "out of host memory");
     const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
-    sc->n = n; sc->n_chunks = (n + 63) / 64; sc->sh_degree = sh_degree; sc->sh_rows = (nf + 3) / 4;
+    sc->n = n; sc->n_chunks = (n + 63) / 64; sc->sh_degree = sh_degree; sc->sh_packed = sh_packed;
+    sc->sh_rows = sh_packed ? (12 + (nf - 3) + 15) / 16 : (nf + 3) / 4;      // packed: 12 B of fp32 DC + one byte per higher coefficient
     const size_t npad = (size_t)std::max<int64_t>(sc->n_chunks, 1) * 64;
     hipError_t e;
     if ((e = hipMalloc(reinterpret_cast<void**>(&sc->geom), npad * SGS_GEOM_ROWS * sizeof(float4))) != hipSuccess ||
@@ -765,7 +767,7 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     sgs_scene* sc = nullptr;
     int rc;
-    if ((rc = new_scene(ctx, n, sh_degree, &sc)) != SGS_OK) return rc;
+    if ((rc = new_scene(ctx, n, sh_degree, false, &sc)) != SGS_OK) return rc;
     if (n > 0) {
         const int nf = 3 * (sh_degree + 1) * (sh_degree + 1);
         const void* src[5] = {means, scales, quats, opacities, sh};
@@ -797,7 +799,7 @@ int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     sgs_scene* sc = nullptr;
     int rc;
-    if ((rc = new_scene(ctx, n, z->sh_degree, &sc)) != SGS_OK) return rc;
+    if ((rc = new_scene(ctx, n, z->sh_degree, true, &sc)) != SGS_OK) return rc;
     if (n > 0) {
         const void* src[3] = {z->chunks, z->packed, z->sh};
         const size_t bytes[3] = {(size_t)z->n_chunks * 18 * 4, (size_t)n * 16, (size_t)n * 3 * k_rest};
@@ -1060,6 +1062,7 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_SPLATS: elem = 48; have = n_slots * elem; break;          // the 12-word view documented in sage_gs.h
         case SGS_BUF_CHUNK_SKIPPED: have = n_chunks; break;
         case SGS_BUF_SCENE_GEOM: have = ctx->last_scene ? ctx->last_n * 11 * 4 : 0; break;
+        case SGS_BUF_SCENE_SH: have = ctx->last_scene ? ctx->last_n * 3 * (ctx->last_scene->sh_degree + 1) * (ctx->last_scene->sh_degree + 1) * 4 : 0; break;
         case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
@@ -1092,6 +1095,29 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
             if ((int64_t)(i + 1) * 11 * 4 > n) continue;
             float* o = dst + (size_t)i * 11;
             o[0] = g0.x; o[1] = g0.y; o[2] = g0.z; o[3] = g0.w; o[4] = g1.x; o[5] = g1.y; o[6] = g1.z; o[7] = g1.w; o[8] = g2.x; o[9] = g2.y; o[10] = g2.z;
+        }
+    }
+    if (what == SGS_BUF_SCENE_SH) {
+        const sgs_scene* sc = ctx->last_scene;
+        const int nf = 3 * (sc->sh_degree + 1) * (sc->sh_degree + 1), rows_n = sc->sh_rows;
+        std::vector<float4> rows((size_t)n_slots * rows_n), g2((size_t)n_slots);
+        hipError_t e = hipMemcpy(rows.data(), sc->shq, rows.size() * sizeof(float4), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+        std::vector<float4> geo((size_t)n_slots * SGS_GEOM_ROWS);
+        if ((e = hipMemcpy(geo.data(), sc->geom, geo.size() * sizeof(float4), hipMemcpyDeviceToHost)) != hipSuccess) SGS_FAIL(ctx, SGS_ERR_HIP, "hipMemcpy: %s", hipGetErrorString(e));
+        float* dst = (float*)host_dst;
+        std::vector<unsigned> w((size_t)rows_n * 4);
+        for (int64_t p = 0; p < ctx->last_n; ++p) {
+            const int64_t chunk = p >> 6, lane = p & 63;
+            unsigned i; memcpy(&i, &geo[(size_t)((chunk * SGS_GEOM_ROWS + 2) * 64 + lane)].w, 4);       // the original index
+            if ((int64_t)(i + 1) * nf * 4 > n) continue;
+            for (int r = 0; r < rows_n; ++r) memcpy(&w[(size_t)4 * r], &rows[(size_t)((chunk * rows_n + r) * 64 + lane)], 16);
+            float* o = dst + (size_t)i * nf;
+            if (!sc->sh_packed) memcpy(o, w.data(), (size_t)nf * 4);
+            else {      // 12 B of fp32 DC, then a byte per coefficient: v / 32 - 4 + 1 / 64, exact in fp32 (sgs_kernels.h sgs_sh_byte)
+                memcpy(o, w.data(), 12);
+                for (int j = 0; j < nf - 3; ++j) o[3 + j] = (float)((w[(size_t)3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu) * (1.0f / 32.0f) + (-4.0f + 1.0f / 64.0f);
+            }
         }
     }
     if (what == SGS_BUF_CHUNK_SKIPPED) {

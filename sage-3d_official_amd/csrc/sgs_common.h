@@ -48,6 +48,7 @@
 #define SGS_PROF_WORDS 24            // profiling build: words per tile in the tile_prof buffer
 #define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
 
+#define SGS_PFLAG_SH_PACKED 0x80000000u   // FrameParams.flags, set by the library (never by a caller's sgs_config): the scene's SH rows are packed bytes
 // Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).
 struct FrameParams {
     float view[12];                 // rows 0..2 of the model->camera matrix (row-major 3x4)
@@ -59,7 +60,8 @@ struct FrameParams {
     int32_t width, height, gx, gy;
     int32_t row_begin, row_end;     // tile rows rendered by this call
     int32_t sh_degree;              // degree evaluated
-    int32_t sh_rows;                // float4 rows per Gaussian stored in the scene (by scene degree)
+    int32_t sh_rows;                // 16-byte rows per Gaussian stored in the scene (by scene degree): fp32 coefficients, or — SGS_PFLAG_SH_PACKED,
+                                    // a scene uploaded from the compressed payload — fp32 DC + one byte per higher coefficient
     int64_t n;                      // Gaussians
     int64_t n_chunks;               // ceil(n / 64)
     int32_t n_ranges;               // ceil(n / SGS_RANGE)

@@ -115,12 +115,16 @@ __device__ __forceinline__ void unpack_gaussian(const PackedScene& Z, long long 
     const float k0 = 1.0f / 0.28209479177387814f;               // colour = 0.5 + C0 dc
     g.dc[0] = (sgs_lerp(cr, c[12], c[15]) - 0.5f) * k0; g.dc[1] = (sgs_lerp(cg, c[13], c[16]) - 0.5f) * k0; g.dc[2] = (sgs_lerp(cb, c[14], c[17]) - 0.5f) * k0;
 }
+// An 8-bit SH coefficient of the compressed payload: the centre of its truncation bin, (v / 256 - 0.5) * 8 + 4 / 256 = v / 32 - 4 + 1 / 64
+// (sage_gs/ply.py load_compressed_ply) — every value a multiple of 1 / 64 below 4 in magnitude, so the ONE fma is exact in fp32 and equal,
+// bit for bit, to the four-step form: the layout kernel (scenes inflated to fp32 rows) and k_preprocess (scenes that keep the bytes in
+// HBM, below) decode to the same floats.
+__device__ __forceinline__ float sgs_sh_byte(unsigned v) { return __builtin_fmaf((float)v, 1.0f / 32.0f, -4.0f + 1.0f / 64.0f); }
 // SH coefficient k (0 .. 3 (k_rest + 1) - 1, Gaussian-major [coefficient][channel] as the renderer takes them) of Gaussian i
 __device__ __forceinline__ float unpack_sh(const PackedScene& Z, long long i, const UnpackedG& g, int k) {
     const int coef = k / 3, ch = k - 3 * coef;
     if (coef == 0) return g.dc[ch];
-    const unsigned char v = Z.sh[i * (3 * Z.k_rest) + ch * Z.k_rest + (coef - 1)];
-    return ((float)v * (1.0f / 256.0f) - 0.5f) * 8.0f + 4.0f / 256.0f;
+    return sgs_sh_byte((unsigned)Z.sh[i * (3 * Z.k_rest) + ch * Z.k_rest + (coef - 1)]);
 }
 
 // floats <-> unsigned keys that order the same way (atomicMin / atomicMax on the bits)
@@ -305,12 +309,37 @@ __global__ __launch_bounds__(256) void k_scene_layout(long long n, int n_sh_floa
     geom[(chunk * SGS_GEOM_ROWS + 0) * SGS_WAVE + lane] = g0;
     geom[(chunk * SGS_GEOM_ROWS + 1) * SGS_WAVE + lane] = g1;
     geom[(chunk * SGS_GEOM_ROWS + 2) * SGS_WAVE + lane] = g2;
+    if (PACKED) {
+        // A compressed scene KEEPS its 8-bit SH in HBM: per Gaussian the byte string [dc r, g, b as fp32 (12 B)] [the 3 k_rest coefficient
+        // bytes in the renderer's order, byte 3 (coef - 1) + channel] padded to 16-byte rows — 64 B per Gaussian at degree 3 (4 rows) where
+        // the fp32 layout streams 192 B (12 rows) every frame.  k_preprocess dequantises (eval_sh<DEG, true>): the same floats, bit for bit.
+        const int nb = 3 * Z.k_rest;
+        for (int r = 0; r < sh_rows; ++r) {
+            unsigned w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int wi = 4 * r + c;                               // word of the byte string
+                if (wi < 3) w[c] = i >= 0 ? __float_as_uint(u.dc[wi]) : 0u;
+                else {
+                    unsigned x = 0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const int j = 4 * (wi - 3) + b;                 // coefficient byte j = 3 (coef - 1) + channel
+                        if (i >= 0 && j < nb) x |= (unsigned)Z.sh[i * nb + (j % 3) * Z.k_rest + j / 3] << (8 * b);
+                    }
+                    w[c] = x;
+                }
+            }
+            shq[(chunk * sh_rows + r) * SGS_WAVE + lane] = make_float4(__uint_as_float(w[0]), __uint_as_float(w[1]), __uint_as_float(w[2]), __uint_as_float(w[3]));
+        }
+        return;
+    }
     for (int r = 0; r < sh_rows; ++r) {
         float v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int k = 4 * r + c;
-            v[c] = (i >= 0 && k < n_sh_floats) ? (PACKED ? unpack_sh(Z, i, u, k) : sh[i * n_sh_floats + k]) : 0.f;
+            v[c] = (i >= 0 && k < n_sh_floats) ? sh[i * n_sh_floats + k] : 0.f;
         }
         shq[(chunk * sh_rows + r) * SGS_WAVE + lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
@@ -412,16 +441,29 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
 
 // ------------------------------------------------------------------------------------------------
 // S1: SH colour.  `row0` points at this lane's float4 in row 0 of its chunk; rows are 64 float4 apart.
-template <int DEG>
+// PACKED: the rows hold a compressed scene's byte string (k_scene_layout<true>): 12 B of fp32 DC, then one byte per coefficient.
+template <int DEG, bool PACKED>
 __device__ __forceinline__ void eval_sh(const float4* __restrict__ row0, float x, float y, float z,
                                         float& out_r, float& out_g, float& out_b) {
     constexpr int NF = 3 * (DEG + 1) * (DEG + 1);
-    constexpr int ROWS = (NF + 3) / 4;
-    float c[ROWS * 4];
+    constexpr int ROWS = PACKED ? (12 + (NF - 3) + 15) / 16 : (NF + 3) / 4;
+    float c[PACKED ? NF + 4 : ROWS * 4];
+    if (PACKED) {
+        unsigned w[ROWS * 4];
 #pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-        const float4 v = row0[r * SGS_WAVE];
-        c[4 * r] = v.x; c[4 * r + 1] = v.y; c[4 * r + 2] = v.z; c[4 * r + 3] = v.w;
+        for (int r = 0; r < ROWS; ++r) {
+            const float4 v = row0[r * SGS_WAVE];
+            w[4 * r] = __float_as_uint(v.x); w[4 * r + 1] = __float_as_uint(v.y); w[4 * r + 2] = __float_as_uint(v.z); w[4 * r + 3] = __float_as_uint(v.w);
+        }
+        c[0] = __uint_as_float(w[0]); c[1] = __uint_as_float(w[1]); c[2] = __uint_as_float(w[2]);
+#pragma unroll
+        for (int j = 0; j < NF - 3; ++j) c[3 + j] = sgs_sh_byte((w[3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);     // (v_cvt_f32_ubyteN + one fma)
+    } else {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const float4 v = row0[r * SGS_WAVE];
+            c[4 * r] = v.x; c[4 * r + 1] = v.y; c[4 * r + 2] = v.z; c[4 * r + 3] = v.w;
+        }
     }
     float res[3];
 #pragma unroll
@@ -675,11 +717,18 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float ux = (float)(dx * idn), uy = (float)(dy * idn), uz = (float)(dz * idn);
         const float4* row0 = shq + (chunk * P.sh_rows) * SGS_WAVE + lane;
         float r, g, b;
-        switch (P.sh_degree) {
-            case 0: eval_sh<0>(row0, ux, uy, uz, r, g, b); break;
-            case 1: eval_sh<1>(row0, ux, uy, uz, r, g, b); break;
-            case 2: eval_sh<2>(row0, ux, uy, uz, r, g, b); break;
-            default: eval_sh<3>(row0, ux, uy, uz, r, g, b); break;
+        if (P.flags & SGS_PFLAG_SH_PACKED) {         // a compressed scene: 8-bit coefficients, dequantised here (wave-uniform branch)
+            switch (P.sh_degree) {
+                case 0: eval_sh<0, true>(row0, ux, uy, uz, r, g, b); break;
+                case 1: eval_sh<1, true>(row0, ux, uy, uz, r, g, b); break;
+                case 2: eval_sh<2, true>(row0, ux, uy, uz, r, g, b); break;
+                default: eval_sh<3, true>(row0, ux, uy, uz, r, g, b); break;
+            }
+        } else switch (P.sh_degree) {
+            case 0: eval_sh<0, false>(row0, ux, uy, uz, r, g, b); break;
+            case 1: eval_sh<1, false>(row0, ux, uy, uz, r, g, b); break;
+            case 2: eval_sh<2, false>(row0, ux, uy, uz, r, g, b); break;
+            default: eval_sh<3, false>(row0, ux, uy, uz, r, g, b); break;
         }
         const float depth = (float)tz;
         // the record of the composite (sgs_common.h): constants folded per splat, not per (splat, tile) or per pixel

@@ -15,7 +15,7 @@ STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
 FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL, FLAG_NO_CHUNK_CULL = 1, 2, 4, 8, 16, 32, 64
 BACKEND_CPU, BACKEND_HIP = 0, 1
-BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM = 0, 1, 2, 3, 4, 5
+BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM, BUF_SCENE_SH = 0, 1, 2, 3, 4, 5, 6
 
 ERR_NAMES = {-1: "SGS_ERR_INVALID", -2: "SGS_ERR_HIP", -3: "SGS_ERR_OOM", -4: "SGS_ERR_OVERFLOW",
              -5: "SGS_ERR_BACKEND"}

@@ -82,6 +82,10 @@ class EmuRenderer:
         """float [N,11] of the scene as the device holds it (after one frame): mean, opacity, scale, quaternion wxyz."""
         return self.debug(_capi.BUF_SCENE_GEOM, np.float32).reshape(-1, 11)
 
+    def scene_sh(self):
+        """float [N, K, 3] of the scene's SH coefficients as the projection kernel evaluates them (after one frame)."""
+        return self.debug(_capi.BUF_SCENE_SH, np.float32).reshape(self.n, -1, 3)
+
     def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
                chunk_cull=True, stats=True):
         flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL

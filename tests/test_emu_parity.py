@@ -299,6 +299,15 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
             assert np.allclose(g[:, 7:11], arrays[2], atol=2e-6)
             assert st["n_visible"] == st_ref["n_visible"] and abs(st["d_total"] - st_ref["d_total"]) <= 2      # (a rect edge may move with a 1e-6 scale change)
             assert np.abs(img - ref).max() < 2e-4 and ref.max() > 0.2
+            # The compressed scene keeps its 8-bit SH as BYTES in HBM and k_preprocess dequantises per frame: the coefficients it evaluates
+            # (SGS_BUF_SCENE_SH) are NumPy's decode exactly, and the frame equals — bit for bit — the frame of the SAME device-decoded arrays
+            # uploaded as fp32 rows (the inflated layout of rounds 1-4).
+            shd = d.scene_sh()
+            assert shd.shape == arrays[4].shape and np.array_equal(shd[:, 1:], arrays[4][:, 1:]) and np.allclose(shd[:, 0], arrays[4][:, 0], atol=1e-6)
+            d.upload(g[:, 0:3].copy(), g[:, 4:7].copy(), g[:, 7:11].copy(), g[:, 3].copy(), shd, deg)
+            img32, st32 = d.render(cam)
+            assert np.array_equal(img32, img) and st32["d_total"] == st["d_total"] and st32["n_visible"] == st["n_visible"]
+            assert st["bytes"]["preprocess"] < st32["bytes"]["preprocess"] or deg == 0     # (algorithmic bytes: 4 rows of SH per visible Gaussian instead of 12)
     finally:
         d.close()
 

@@ -678,6 +678,46 @@ def test_compressed_ply_scene_against_the_oracle(drv, tmp_path, deg):
     scene.free()
 
 
+@pytest.mark.parametrize("deg", [3, 2, 1, 0])
+def test_compressed_scene_keeps_its_sh_bytes_in_hbm_and_renders_the_same_frames(drv, tmp_path, deg):
+    """A scene uploaded from the compressed payload keeps its 8-bit SH coefficients as BYTES in HBM (64 B per Gaussian at degree 3 where
+    the fp32 rows take 192 B) and k_preprocess dequantises them every frame.  The same scene as fp32 rows — the device-decoded geometry
+    (SGS_BUF_SCENE_GEOM) and the dequantised coefficients (SGS_BUF_SCENE_SH) uploaded through sgs_scene_upload, the layout of rounds 1-4
+    — must render the SAME frames, bit for bit, with identical N_v / D / D_f; the coefficients are NumPy's decode of the bytes exactly."""
+    from sage_gs import ply, scenes
+    from sage_gs import _capi
+    import torch
+    from sage_gs.renderer import Gaussians
+    sc = scenes.make_room(120_000, seed=4)
+    m, s_, q, o, sh, _ = sc.as_tuple()
+    key = np.lexsort((m[:, 0] // 0.5, m[:, 1] // 0.5, m[:, 2] // 0.5))
+    m, s_, q, o, sh = m[key], s_[key], q[key], o[key], sh[key][:, :(deg + 1) ** 2]
+    path = str(tmp_path / f"room_packed_{deg}.ply")
+    ply.save_compressed_ply(path, m, s_, q, o, sh, deg)
+    chunks, packed, shb, deg_file = ply.read_compressed_payload(path)
+    assert deg_file == deg
+    scene_c = drv.r.upload_compressed(chunks, packed, shb, deg, model_to_world=sc.model_to_world)
+    cams = scenes.room_cameras(sc, 1024, 768, n_positions=2, n_yaw=4, seed=4)[:5]
+    frames, stats = [], []
+    for cam in cams:
+        frames.append(drv.r.render(cam, scene_c, stats=True).clone()); stats.append(dict(drv.r.last_stats))
+    g = drv.r.debug_buffer(_capi.BUF_SCENE_GEOM, np.float32).reshape(-1, 11)
+    shd = drv.r.debug_buffer(_capi.BUF_SCENE_SH, np.float32).reshape(len(m), -1, 3)
+    if deg > 0:
+        want = (shb.reshape(len(m), 3, -1).transpose(0, 2, 1).astype(np.float32) / 256.0 - 0.5) * 8.0 + 4.0 / 256.0      # ply.load_compressed_ply's decode
+        assert np.array_equal(shd[:, 1:], want.astype(np.float32))
+    scene_c.free()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    scene_f = drv.r.upload(Gaussians(t(g[:, 0:3]), t(g[:, 4:7]), t(g[:, 7:11]), t(g[:, 3]), t(shd), deg, sc.model_to_world))
+    for cam, f, st in zip(cams, frames, stats):
+        f32 = drv.r.render(cam, scene_f, stats=True)
+        st32 = drv.r.last_stats
+        assert bool((f32 == f).all()) and float(f.max()) > 0.2
+        assert (st32["n_visible"], st32["d_total"], st32["d_fetched"]) == (st["n_visible"], st["d_total"], st["d_fetched"]) and st["n_visible"] > 1_000
+        assert deg == 0 or st["bytes"]["preprocess"] < st32["bytes"]["preprocess"]
+    scene_f.free()
+
+
 def test_ply_scene_at_full_size(drv, tmp_path):
     """f-1 at the size of configs[2]: a 3 M-Gaussian scene (trained-3DGS statistics, SH degree 3: a 744-MB file) written to
     a standard 3DGS PLY and read back; the loaded arrays go through `scenes.scene_from_arrays` + `ply.to_gaussians` (the
