@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SGS_VERSION 110            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
+#define SGS_VERSION 111            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
                                     * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points): a caller compiled against
                                     * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
                                     * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
@@ -129,6 +129,8 @@ typedef struct sgs_stats {
     float ms_total;                /* first launch -> last launch (SGS_FLAG_TIMING)      */
     int64_t bytes[SGS_NUM_STAGES]; /* algorithmic bytes per stage         */
     int64_t d_super;       /* D_s: records in the super-tile queues (level 1 of the binning) */
+    int64_t n_deep_windows; /* windows of tile queues that the composite culled against the tile's live pixels BEFORE ranking / staging (tiles that
+                            * kept consuming batches; never with SGS_FLAG_STATS) — version 111 */
 } sgs_stats;
 
 int sgs_version(void);

@@ -514,6 +514,7 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     stats->n_tiles = ntiles;
     stats->max_tile_len = (int32_t)s.max_tile_len;
     stats->n_spill_tiles = (int32_t)s.class_count[3];
+    stats->n_deep_windows = (int64_t)s.n_deep;
     stats->retries = ctx->last_retries;
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;

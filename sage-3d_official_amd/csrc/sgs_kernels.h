@@ -1880,6 +1880,12 @@ __device__ __forceinline__ float4 sgs_live_rect(unsigned long long m, float x0, 
 #ifndef SGS_REFINE_SPAN
 #define SGS_REFINE_SPAN 1024          // records of a long queue's ordered copy that one refinement re-partitions (at least the bucket that asked)
 #endif
+#ifndef SGS_DEEP_LIVE
+#define SGS_DEEP_LIVE 48u             // ... and only while at most this many of its 256 pixels are live (more: too many records survive the cull)
+#endif
+#ifndef SGS_DEEP_AFTER
+#define SGS_DEEP_AFTER 3u             // a tile past this many batches culls whole resident windows against its live pixels before it ranks or stages anything
+#endif
 #ifndef SGS_LAZY_WINDOWS
 #define SGS_LAZY_WINDOWS 2u           // windows a long queue fills by scanning itself before its bucket-ordered copy is made (k_tile_render)
 #endif
@@ -1937,18 +1943,21 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     __shared__ unsigned short s_c_bkt[SGS_NB];
     __shared__ unsigned s_cs[12];                              // ... and its scalars / the refinement's state (CS_*)
     __shared__ unsigned long long s_ball[2][4][4];    // [batch parity][quadrant][gathering wave]
-    __shared__ unsigned s_any[2];                     // some pixel still unfinished after batch (by parity)
+    __shared__ unsigned s_any[2];                     // pixels still unfinished after batch (by parity)
     __shared__ unsigned s_hyper[2];                   // the batch holds a splat with an indefinite conic: exact trips (by parity)
     // the rectangle of every quadrant's pixels that are still live (tile pixels; written by the quadrant's wave after each
     // batch): a tile that keeps consuming batches for a few pixels that never saturate — a gap in the scene, a window —
     // then stages and walks only the splats that can reach THOSE pixels, not the whole 8x8 quadrant
     __shared__ float4 s_lrect[4];
     __shared__ unsigned s_used[4];
+    __shared__ unsigned long long s_skey[SGS_BATCH + 8];      // deep tiles: the records of a window that can reach a live pixel (+ sentinels)
+    __shared__ unsigned s_nsurv;
 #ifdef SGS_TILE_PROF
     // profiling build only (lib/libsage_gs_prof.so): per-tile shader-clock cycles of each phase
     unsigned long long pt0 = clock64(), pt_part = 0, pt_sort = 0, pt_blend = 0, pn_groups = 0, pn_batches = 0, ptm;
     unsigned long long pt_rank = 0, pt_bar1 = 0, pt_stage = 0, pt_job = 0, pt_rec = 0;     // sub-phases of the single-batch path (pt_sort = the rest: barrier 2)
     unsigned pe_eval = 0, pe_empty = 0, pe_valid = 0, pe_useful = 0, pe_dead = 0, pe_few = 0;    // (dead: no LIVE pixel inside the cut-off; few: one or two)
+    unsigned long long pn_deep_try = 0, pn_deep_ok = 0, pn_deep_surv = 0;                          // deep-tile culls attempted / taken, survivors of the taken ones
     const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
     __shared__ unsigned s_pe[8];
     if (threadIdx.x < 8) s_pe[threadIdx.x] = 0;
@@ -2162,6 +2171,8 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     unsigned e_next = 0, lo = 0;         // next non-empty bucket (index into s_ne_*) / its queue position
     unsigned win_lo = 0, win_hi = in_lds ? n : 0u;   // queue range resident in s_q (the whole queue when it fits)
     unsigned n_refine = 0u, no_refine_at = 0xffffffffu;
+    unsigned n_live_px = 256u;           // pixels of the tile still live after the last batch (uniform)
+    unsigned deep_hold = 0u;             // groups for which the deep-tile cull is not attempted (uniform): its last attempt left more than a batch
     unsigned n_fill = 0u;                // windows of a long queue filled so far (uniform; reported by the profiling build)
     (void)n_refine; (void)n_fill;
     while (lo < n && (!tile_done || full_sort)) {
@@ -2327,9 +2338,83 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         // Common case — the group is a single batch: every lane owns one record, issues the gather of ITS
         // splat first, ranks its record against the group while the loads are in flight, and stores the
         // splat at staging[rank].  No sorted index list, no exposed gather latency.
-        const bool direct = cnt <= SGS_BATCH && !tile_done && !full_sort;
+        //
+        // DEEP TILES.  A tile that is still consuming batches after SGS_DEEP_AFTER of them keeps going for a few pixels that never
+        // saturate — a gap between surfaces, a doorway — and from then on reads most of its queue: 14 batches at 1080p, 190 at
+        // 320x240, where ONE such tile is the kernel's critical path (r04u: 4.0 M of a frame's 4.0 M cycles).  What it pays per batch is
+        // fixed — a gather's round trip to HBM, the ranking of 256 records, their staging and quadrant tests, two barriers — for the
+        // two or three dozen splats that can still reach a live pixel.  So such a tile first CULLS the whole resident window (up to
+        // SGS_QCAP records: the rest of an in-LDS queue, or a long queue's window of whole buckets) against the live rectangles — four
+        // records per lane, only the 32 bytes of the splat the test reads — and the survivors' keys are compacted into s_skey.  They are a
+        // single batch (else: the ordinary path): ranked by their full keys (depth bits, index — so bucket boundaries and oversized buckets
+        // no longer matter), staged and blended by the code below, unchanged.  A culled splat has no pixel it could change (the quadrant
+        // test is conservative, and the live set only shrinks), so the frame is the same bit for bit.  Not with STATS: D_f is a queue
+        // position, which survivors do not carry (the tests hold the frames of the two instantiations against each other).
+        const unsigned long long* kk_d = s_q + (lo - win_lo);
+        unsigned cnt_d = cnt, hi_d = hi, e_next_d = e_next;
+        bool parted_d = parted;
+        if (!STATS && !full_sort && !tile_done && parted && it >= SGS_DEEP_AFTER && n_live_px <= SGS_DEEP_LIVE && deep_hold == 0u && hi <= win_hi && win_hi - lo > cnt) {
+            const unsigned wcnt = win_hi - lo;            // (<= SGS_QCAP)
+#ifdef SGS_TILE_PROF
+            ++pn_deep_try;
+#endif
+            if (tid == 0) s_nsurv = 0u;
+            unsigned wfit = 0;                            // the window's last bucket: the buckets from e0 on that end inside it
+#pragma unroll
+            for (int r = 0; r < SGS_NB / 64; ++r) {
+                const unsigned e = e0 + (unsigned)(r * 64 + lane);
+                wfit += (unsigned)__popcll(__ballot(e < n_ne && s_ne_end[e] <= win_hi));
+            }
+            __syncthreads();
+            for (unsigned r0 = 0; r0 < wcnt; r0 += 512u) {                       // two records per lane in flight
+                unsigned long long kq[2]; float4 qA[2]; float qc[2], qm[2]; float2 qh[2]; bool hv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned i = r0 + (unsigned)tid + 256u * (unsigned)u;
+                    hv[u] = i < wcnt;
+                    kq[u] = hv[u] ? s_q[lo - win_lo + i] : ~0ull;
+                    const float4* const sp = reinterpret_cast<const float4*>(splats + (hv[u] ? (unsigned)kq[u] : 0u));
+                    qA[u] = sp[0]; qc[u] = *reinterpret_cast<const float*>(sp + 1);
+                    qh[u] = reinterpret_cast<const float2*>(sp + 2)[1]; qm[u] = *reinterpret_cast<const float*>(sp + 3);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    unsigned qb4 = 0u;
+                    if (hv[u] && qm[u] > 0.0f) {
+                        const float rx = qA[u].x - tile_fx, ry = qA[u].y - tile_fy;
+                        qb4 = sgs_quadrant_extent(rx, ry, qh[u].x, qh[u].y, s_lrect);
+                        if (qb4 && !loose_cull) qb4 &= sgs_quadrant_hits_roots(rx, ry, qA[u].z, qA[u].w, qc[u], qm[u], s_lrect);
+                    }
+                    const unsigned long long sm = __ballot(qb4 != 0u);
+                    if (sm != 0ull) {                     // one LDS atomic per wave and slot
+                        unsigned sb = 0u;
+                        if (lane == __ffsll((long long)sm) - 1) sb = atomicAdd(&s_nsurv, (unsigned)__popcll(sm));
+                        sb = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)sb, __ffsll((long long)sm) - 1));
+                        const unsigned pos = sb + lanes_below(sm);
+                        if (qb4 != 0u && pos < (unsigned)SGS_BATCH) s_skey[pos] = kq[u];
+                    }
+                }
+            }
+            __syncthreads();
+            const unsigned ns = s_nsurv;                  // (uniform)
+            SGS_PROF_MARK(pt_bar1);                       // (profiling build: the cycles of the cull)
+#ifdef SGS_TILE_PROF
+            if (ns <= (unsigned)SGS_BATCH) { ++pn_deep_ok; pn_deep_surv += ns; }
+#endif
+            if (ns <= (unsigned)SGS_BATCH) {
+                if (tid == 0) atomicAdd(&st->n_deep, 1u);
+                if (tid < 8) s_skey[ns + (unsigned)tid] = ~0ull;          // the sentinels of the 8-wide ranking walk
+                kk_d = s_skey; cnt_d = ns; parted_d = false; hi_d = win_hi; e_next_d = e0 + wfit;
+                __syncthreads();
+                if (ns == 0u) { lo = hi_d; e_next = e_next_d; continue; }          // nothing in this window can reach a live pixel
+            } else deep_hold = 2u;                        // too many pixels still live: the ordinary path for this group and the next
+        } else if (deep_hold != 0u) --deep_hold;
+        const bool direct = cnt_d <= SGS_BATCH && !tile_done && !full_sort;
         if (direct) {
-            const unsigned long long* kk = s_q + (lo - win_lo);
+            const unsigned long long* kk = kk_d;
+            const unsigned cnt = cnt_d, hi = hi_d;
+            const bool parted = parted_d;
+            e_next = e_next_d;
             const unsigned par = it & 1u;
             const bool have = (unsigned)tid < cnt;
             const unsigned long long mine = have ? kk[tid] : ~0ull;
@@ -2405,11 +2490,11 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
             const unsigned long long live_m = __ballot(Tm > 0.0f);
             const bool still_live = live_m != 0ull;
             if (lane == 0) {
-                if (still_live) atomicOr(&s_any[par], 1u);
+                if (still_live) atomicAdd(&s_any[par], (unsigned)__popcll(live_m));
                 s_lrect[wave] = sgs_live_rect(live_m, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));   // (read after the barrier)
             }
             __syncthreads();
-            tile_done = s_any[par] == 0u;
+            n_live_px = s_any[par]; tile_done = n_live_px == 0u;
             if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;    // consumed: ready for the batch after next
             ++it;
             // a tile that keeps consuming batches is on the kernel's critical path: let its waves win the issue
@@ -2498,11 +2583,11 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                 const unsigned long long live_m = __ballot(Tm > 0.0f);
                 const bool still_live = live_m != 0ull;
                 if (lane == 0) {
-                    if (still_live) atomicOr(&s_any[par], 1u);
+                    if (still_live) atomicAdd(&s_any[par], (unsigned)__popcll(live_m));
                     s_lrect[wave] = sgs_live_rect(live_m, (float)((wave & 1) * 8), (float)((wave >> 1) * 8));
                 }
                 __syncthreads();                 // batch consumed by every wave, liveness posted
-                tile_done = s_any[par] == 0u;    // uniform
+                n_live_px = s_any[par]; tile_done = n_live_px == 0u;    // uniform
                 if (tid < 32) reinterpret_cast<unsigned*>(&s_ball[par][0][0])[tid] = 0u;   // (the single-batch path ORs into it)
                 if (it == 0) __builtin_amdgcn_s_setprio(1); else if (it == 1) __builtin_amdgcn_s_setprio(2); else if (it == 3) __builtin_amdgcn_s_setprio(3);
 #ifdef SGS_TILE_PROF
@@ -2521,7 +2606,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         o[0] = n; o[1] = pt_part; o[2] = pt_sort; o[3] = pt_blend; o[4] = pn_groups; o[5] = pn_batches;
         o[6] = clock64() - pt0; o[7] = pt0;
         o[8] = s_pe[0]; o[9] = s_pe[1]; o[10] = s_pe[2]; o[11] = s_pe[3]; o[12] = s_pe[4]; o[13] = s_pe[5]; o[14] = prt0; o[15] = wall_clock64(); o[16] = pt_rank; o[17] = pt_bar1; o[18] = pt_stage; o[19] = pt_job;
-        o[20] = pt_rec; o[21] = n_refine; o[22] = n_fill; o[23] = (unsigned long long)s_pe[6] | ((unsigned long long)s_pe[7] << 32);
+        o[20] = pt_rec; o[21] = n_refine | (pn_deep_try << 16) | (pn_deep_ok << 32); o[22] = n_fill | (pn_deep_surv << 16); o[23] = (unsigned long long)s_pe[6] | ((unsigned long long)s_pe[7] << 32);
     }
 #endif
     {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)

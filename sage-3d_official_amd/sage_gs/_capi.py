@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-ABI_VERSION = 110        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
+ABI_VERSION = 111        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
@@ -57,7 +57,7 @@ class SgsStats(C.Structure):
                 ("d_fetched", C.c_int64), ("n_pixels", C.c_int64), ("n_tiles", C.c_int32),
                 ("max_tile_len", C.c_int32), ("n_spill_tiles", C.c_int32), ("retries", C.c_int32),
                 ("ms", C.c_float * NUM_STAGES), ("ms_total", C.c_float),
-                ("bytes", C.c_int64 * NUM_STAGES), ("d_super", C.c_int64)]
+                ("bytes", C.c_int64 * NUM_STAGES), ("d_super", C.c_int64), ("n_deep_windows", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("ms", "bytes")}

@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Round-5 probe (GPU box): stage times ALONE and the pipelined rate of the bench's sweep, for the library SAGE_GS_LIB names
 (A/B of variants in one box visit), on the fp32-uploaded scene and/or the scene uploaded from the compressed payload.
-    python scripts/r05_probe.py [fp32] [packed] [lowres] [n=24]"""
+    python scripts/r05_probe.py [fp32] [packed] [lowres] [n=24] [libs=a.so,b.so,...]     (libs: several variants in ONE process, names under build/variants/)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-from sage_gs import Renderer, scenes
+from sage_gs import Renderer, scenes, _capi
 
 args = sys.argv[1:]
 modes = [a for a in args if a in ("fp32", "packed")] or ["fp32"]
@@ -17,6 +17,7 @@ sc = scenes.cached_room(3_000_000, seed=2)
 STAGES = ("preprocess", "count", "emit", "render")
 poses = [(i * 77) % 256 for i in range(5, 105)]
 tag = os.path.basename(os.environ.get("SAGE_GS_LIB", "default"))
+LIBS = next((a[5:].split(",") for a in args if a.startswith("libs=")), [None])
 
 
 def alone(r, gs, cams, buf, n):
@@ -55,26 +56,31 @@ def latency(r, gs, cams, buf, n=32):
     return np.percentile(lat, 50), np.percentile(lat, 90)
 
 
-r = Renderer(dev, record_capacity=96 << 20)
 g_dev = scenes.to_gaussians(sc, dev)
-for mode in modes:
-    if mode == "packed":
-        from bench import quantise_on_gpu
-        dv = quantise_on_gpu(g_dev)
-        gs = r.upload_compressed(dv[0], dv[1], dv[2], sc.sh_degree, model_to_world=sc.model_to_world)
-        del dv
+for libname in LIBS:
+    if libname is None:
+        r = Renderer(dev, record_capacity=96 << 20)
     else:
-        gs = r.upload(g_dev)
-    for (w, h) in ([(1920, 1080)] + ([(640, 480), (320, 240)] if "lowres" in args else [])):
-        cams = scenes.room_cameras(sc, w, h, n_positions=4, n_yaw=64, seed=2)
-        ring = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(4)]
-        a = alone(r, gs, cams, ring[0], N)
-        line = f"[{tag}] {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
-        if (w, h) == (1920, 1080):
-            line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame"
+        tag = libname
+        r = Renderer(dev, record_capacity=96 << 20, lib=_capi.Lib(os.path.join(ROOT, "build", "variants", libname if libname.endswith(".so") else libname + ".so")))
+    for mode in modes:
+        if mode == "packed":
+            from bench import quantise_on_gpu
+            dv = quantise_on_gpu(g_dev)
+            gs = r.upload_compressed(dv[0], dv[1], dv[2], sc.sh_degree, model_to_world=sc.model_to_world)
+            del dv
         else:
-            p50, p90 = latency(r, gs, cams, ring[0])
-            line += f" | latency p50 {p50:.3f} p90 {p90:.3f} ms"
-        print(line, flush=True)
-    gs.free()
-r.close()
+            gs = r.upload(g_dev)
+        for (w, h) in ([(1920, 1080)] + ([(640, 480), (320, 240)] if "lowres" in args else [])):
+            cams = scenes.room_cameras(sc, w, h, n_positions=4, n_yaw=64, seed=2)
+            ring = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(4)]
+            a = alone(r, gs, cams, ring[0], N)
+            line = f"[{tag}] {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
+            if (w, h) == (1920, 1080):
+                line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame"
+            else:
+                p50, p90 = latency(r, gs, cams, ring[0])
+                line += f" | latency p50 {p50:.3f} p90 {p90:.3f} ms"
+            print(line, flush=True)
+        gs.free()
+    r.close()

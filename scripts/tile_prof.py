@@ -20,7 +20,10 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     st = dict(r.last_stats); st["d_fetched"] = d_f
     p = r.debug_buffer(100, np.uint64).reshape(-1, 24).astype(np.float64)
     n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, pjob, prec = p.T[:21]
-    nref, nfill = p.T[21], p.T[22]
+    praw = r.debug_buffer(100, np.uint64).reshape(-1, 24)
+    nref, nfill = (praw[:, 21] & np.uint64(0xffff)).astype(np.float64), (praw[:, 22] & np.uint64(0xffff)).astype(np.float64)
+    dtry, dok = ((praw[:, 21] >> np.uint64(16)) & np.uint64(0xffff)).astype(np.float64), ((praw[:, 21] >> np.uint64(32)) & np.uint64(0xffff)).astype(np.float64)
+    dsurv = (praw[:, 22] >> np.uint64(16)).astype(np.float64)
     pu = r.debug_buffer(100, np.uint64).reshape(-1, 24)[:, 23]
     dead, few = (pu & np.uint64(0xffffffff)).astype(np.float64), (pu >> np.uint64(32)).astype(np.float64)
     clk = 1e-3 * tot.sum() / max(1e-9, 1.0)   # cycles
@@ -42,9 +45,10 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     print(f"     tiles finished by: 50 % {q[0]:.0f} us, 90 % {q[1]:.0f} us, 99 % {q[2]:.0f} us, all {q[3]:.0f} us; tiles started after 50 % of the span: {100 * (rt0 - evs[0, 0] > 0.5 * span).mean():.1f} %")
     print(f"     single-batch path, cycle sums: rank (records resident -> ranked) {prank.sum()/1e6:.0f}M, barrier 1 {pbar1.sum()/1e6:.0f}M, stage (gather wait + extents + quadrant test) {pstage.sum()/1e6:.0f}M, barrier 2 {sort.sum()/1e6:.0f}M; partition {part.sum()/1e6:.0f}M; blend {blend.sum()/1e6:.0f}M; total {tot.sum()/1e6:.0f}M")
     print(f"     start of a tile, mean cycles: entry -> job arrived {pjob.mean():.0f}, -> records arrived {prec.mean():.0f}, -> partitioned {part.mean():.0f}  (p90: {np.quantile(pjob,0.9):.0f}, {np.quantile(prec,0.9):.0f}, {np.quantile(part,0.9):.0f})")
-    order = np.argsort(-tot)[:5]
+    print(f"     deep-tile culls: attempted {int(dtry.sum())} (tiles {int((dtry > 0).sum())}), taken {int(dok.sum())}, survivors per taken window {dsurv.sum() / max(1.0, dok.sum()):.0f}; cull cycles {pbar1.sum()/1e6:.1f}M")
+    order = np.argsort(-tot)[:8]
     for o in order:
-        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} (no live pixel {int(dead[o])}, 1-2 {int(few[o])}) refinements {int(nref[o])} window fills {int(nfill[o])}")
+        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} (no live pixel {int(dead[o])}, 1-2 {int(few[o])}) refinements {int(nref[o])} window fills {int(nfill[o])} deep {int(dok[o])}/{int(dtry[o])} surv {int(dsurv[o])} cull {pbar1[o]/1e3:.0f}k")
     # by size class
     for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
         m = (n > lo) & (n <= hi)

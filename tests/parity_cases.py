@@ -50,6 +50,10 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     img_plain, st_plain = drv.render(cam, cfg, rows, stats=False)
     assert (img_plain == img).all() and st_plain["d_total"] == st["d_total"] and st_plain["n_visible"] == st["n_visible"] \
         and st_plain["d_fetched"] == 0, f"{what}: the frame depends on whether D_f is counted"
+    # (the instantiation without D_f is also the only one that takes the deep-tile path: windows of a long-lived tile culled against its
+    #  live pixels before anything is ranked — the comparison above holds the two paths against each other, bit for bit)
+    assert st["n_deep_windows"] == 0
+    st["n_deep_windows_plain"] = st_plain["n_deep_windows"]
     # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
     # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
     drv.row_records(0, reset=True)
@@ -367,6 +371,41 @@ def case_sort_classes(drv, sizes=(700, 2500, 6000, 9500)):
         cam = onp.Camera(32, 32, 32.0, 32.0, 16.0, 16.0, np.eye(4, dtype=np.float32))
         img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what=f"sort class n={n}")
         assert st["max_tile_len"] == n
+
+
+def case_deep_tile(drv, n_back=6000):
+    """Tiles that keep consuming batches for a few pixels: three opaque layers saturate every pixel of a 32x32 image except a 5x5 hole
+    per tile, and thousands of splats behind them are visible only through the holes.  After SGS_DEEP_AFTER batches such a tile culls every
+    resident window of its queue against the live pixels BEFORE ranking / staging (k_tile_render, deep tiles) and blends the survivors as one
+    batch: the frame must equal the oracle's AND the frame of the ordinary path (the D_f-counting instantiation) bit for bit — both
+    checked by check_against_oracle — and the path must actually have run."""
+    rng = np.random.default_rng(21)
+    ys, xs = np.mgrid[0:32, 0:32]
+    hole = ((xs % 16 >= 8) & (xs % 16 <= 12) & (ys % 16 >= 3) & (ys % 16 <= 7))
+    px, py = xs[~hole].astype(np.float64), ys[~hole].astype(np.float64)
+    f, c = 32.0, 16.0
+    front = []
+    for z in (1.0, 1.05, 1.1):
+        front.append(np.stack([(px - c + 0.5) * z / f, (py - c + 0.5) * z / f, np.full(px.shape, z)], 1))
+    nb = n_back
+    zb = rng.uniform(2.0, 40.0, nb)
+    back = np.stack([rng.uniform(-15.5, 15.5, nb) * zb / f, rng.uniform(-15.5, 15.5, nb) * zb / f, zb], 1)
+    means = np.concatenate(front + [back]).astype(np.float32)
+    nf = means.shape[0] - nb
+    scales = np.concatenate([np.repeat((0.55 * means[:nf, 2] / f)[:, None], 3, 1),                # ~0.55 px: covers its own pixel
+                             np.repeat((rng.uniform(0.6, 2.5, nb) * zb / f)[:, None], 3, 1)]).astype(np.float32)
+    quats = rng.normal(size=(means.shape[0], 4)).astype(np.float32)
+    opac = np.concatenate([np.full(nf, 0.999), rng.uniform(0.05, 0.6, nb)]).astype(np.float32)
+    sh = rng.normal(size=(means.shape[0], 1, 3)).astype(np.float32)
+    perm = rng.permutation(means.shape[0])
+    scene = (means[perm], scales[perm], quats[perm], opac[perm], sh[perm], 0)
+    cam = onp.Camera(32, 32, f, f, c, c, np.eye(4, dtype=np.float32))
+    img, st, aux, _ = check_against_oracle(drv, scene, cam, what="deep tile")
+    assert st["max_tile_len"] > 1024 and st["n_deep_windows_plain"] >= 4, (st["max_tile_len"], st["n_deep_windows_plain"])
+    # most pixels stopped inside the front layers, the holes read on deep into the queue
+    stopped = float((aux["final_T"] < 1e-3).mean())
+    assert stopped > 0.5 and st["d_fetched"] > 0.1 * st["d_total"], (stopped, st["d_fetched"], st["d_total"], st["n_deep_windows_plain"])
+    print(f"[deep tile] {st['n_deep_windows_plain']} windows culled first; {100 * stopped:.0f} % of the pixels stopped; D_f / D = {st['d_fetched'] / st['d_total']:.2f}")
 
 
 def case_big_depth_bucket(drv, n_slab=3000):

@@ -76,6 +76,10 @@ def test_sort_classes(drv):
     pc.case_sort_classes(drv, sizes=(700, 2500, 9500))
 
 
+def test_deep_tile(drv):
+    pc.case_deep_tile(drv, n_back=5000)
+
+
 def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(640, 368))
 

@@ -161,6 +161,10 @@ def test_sort_classes(drv):
     pc.case_sort_classes(drv, sizes=(700, 2500, 6000, 9500, 20000))
 
 
+def test_deep_tile(drv):
+    pc.case_deep_tile(drv, n_back=12000)
+
+
 def test_full_grid_splat(drv):
     pc.case_full_grid_splat(drv, res=(1920, 1080))
     pc.case_full_grid_splat(drv, res=(3840, 2160))
