@@ -40,7 +40,16 @@ sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-VALU_PEAK_LANE_OPS = 78.6e12    # 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz (the 157 TFLOP/s fp32 peak counts an FMA twice)
+# The VALU ceiling, MEASURED (scripts/ubench2.hip, in-kernel s_memtime / s_memrealtime clocks; profiles/r05b_ubench2_table.txt): shader cycles per
+# wave64 instruction and SIMD, independent streams, 8 / 5 waves per SIMD (5 = what k_tile_render's 96 VGPRs and 31 KB of LDS allow):
+#   v_fma_f32 2.40 / 2.62 (datasheet: 2.0 — SIMD-32)   v_mul 2.29 / 2.43   v_exp, v_rcp 8.2 / 8.3   v_med3, v_max, v_pk_fma, any SGPR operand 4.2-4.3
+#   v_cmp 4.4 / 4.65   ds_read_b32/b64 (broadcast or per lane) 8.4 / 8.8 per SIMD = 2.1 per CU   ds_read_b128 16 = 4 per CU
+#   one wave alone on its SIMD issues a VALU instruction every 7.26 cycles, two waves every 3.63: three or more are needed to reach the ceiling
+#   the blend trip of k_tile_render (4 splats: 66 VALU + 21 LDS reads, the product's own macros) in isolation: 528 / 302 / 272 / 251 / 240 / 223
+#   cycles per trip and SIMD at 1 / 2 / 3 / 4 / 5 / 8 waves per SIMD (its LDS reads alone: 180; its arithmetic alone: 250-260)
+VALU_CYC_PER_INST = {"v_fma_f32_w8": 2.40, "v_fma_f32_w5": 2.62, "datasheet": 2.0}
+TRIP_CYCLES_W5 = 240.0
+VALU_PEAK_LANE_OPS = 256 * 4 * 64 * 2.4e9 / VALU_CYC_PER_INST["v_fma_f32_w8"]      # 65.5e12: the measured v_fma_f32 issue rate at 2.4 GHz
 POSE_STRIDE = 77
 
 
@@ -632,7 +641,26 @@ def main():
                         if vi and ms_dom > 0:
                             valu = {"inst_per_launch": vi, "lane_ops_per_s": vi * 64.0 / (ms_dom * 1e-3),
                                     "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS,
+                                    "peak_basis": "measured: one v_fma_f32 per 2.40 shader cycles and SIMD at 8 waves per SIMD (2.62 at the kernel's 5; datasheet 2.0), "
+                                                  "1024 SIMDs x 64 lanes at 2.4 GHz — scripts/ubench2.hip, profiles/r05b_ubench2_table.txt",
+                                    "cycles_per_inst": VALU_CYC_PER_INST,
+                                    # valu_busy (SQ_ACTIVE_INST_VALU) books every VALU instruction as ONE quad-cycle = 4 cycles of its SIMD whatever it
+                                    # costs; frac books it at the measured v_fma rate: the two describe the same instruction count,
+                                    #   valu_busy / frac ~ (4 / 2.40) x (2.4 GHz / the clock the profiled pass ran at)
+                                    "reconciliation": {"valu_busy_books_cycles_per_inst": 4.0, "frac_books_cycles_per_inst": VALU_CYC_PER_INST["v_fma_f32_w8"],
+                                                       "valu_busy_over_frac_expected": 4.0 / VALU_CYC_PER_INST["v_fma_f32_w8"],
+                                                       "valu_busy_over_frac": (valu_busy / (vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS)) if valu_busy else None,
+                                                       "what": "neither is 'time the VALU could not have been used': the kernel's instruction MIX costs more than v_fma "
+                                                               "(v_exp 8.2, clamp / compare forms 4.2-4.6 cycles) and its blend also drives the CU's LDS pipe to ~75 % "
+                                                               "(21 broadcast reads per trip at 2.1 cycles per CU)"},
                                     "basis": "SQ_INSTS_VALU of the committed PMC passes of this pose set / ms_alone"}
+                            if lane_use and lane_use.get("evaluations") and lane_use.get("poses"):
+                                # what the blend alone costs at the measured rate of its own instruction stream: (wave, splat) evaluations / 4 per trip
+                                # x 240 cycles per trip and SIMD (5 waves per SIMD) over 1024 SIMDs at 2.4 GHz — the part of ms_alone no schedule removes
+                                ev = lane_use["evaluations"] / max(1, len(str(lane_use["poses"]).split(",")))
+                                valu["blend"] = {"evaluations_per_frame": ev, "trip_cycles_w5": TRIP_CYCLES_W5,
+                                                 "floor_ms": ev / 4.0 * TRIP_CYCLES_W5 / 1024.0 / 2.4e9 * 1e3,
+                                                 "what": "wave x splat evaluations of the profiled poses (profiling build) / 4 per trip x the trip's measured cost in isolation"}
                 except Exception:
                     traffic = None
             out["roofline"] = {
@@ -660,7 +688,7 @@ def main():
                 "gpu_ms_per_frame_in_flight": avg["ms_total"] if avg is not None else None,
                 "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
                 "events_on_every_nth_frame": max(1, args.event_stride),
-                "note": "the composite is bound by VALU issue slots (one wave instruction per 4 cycles and SIMD; valu_busy), not by HBM; ms_alone = a "
+                "note": "the composite is bound by instruction issue (VALU + the CU's LDS pipe: roofline.valu, DESIGN.md §4.1), not by HBM; ms_alone = a "
                         "launch with nothing else running; ms_in_flight = HIP-event span inside the timed region, where frames "
                         "overlap (not a kernel duration: it includes waiting for the lane's previous kernel)"}
         if latency:

@@ -165,11 +165,19 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
  *                          (11-10-11), packed_color (8-8-8-8), in THIS order
  *   sh[n][3 * ((d+1)^2-1)] the `sh` element's uint8 properties f_rest_*, in file order (channel-major); NULL at degree 0
  * sage_gs/ply.py (read_compressed_payload) produces exactly these from a file.  n_chunks must be ceil(n / 256). */
+enum { SGS_SH_DECODE_BIN_CENTRE = 0, SGS_SH_DECODE_LINEAR255 = 1, SGS_SH_DECODE_BIN_CENTRE_ENDS = 2 };
 typedef struct sgs_compressed_scene {
     int64_t n;
     int64_t n_chunks;
     int32_t sh_degree;
-    int32_t reserved_;
+    int32_t sh_decode;     /* how an 8-bit SH coefficient v becomes a float (the field was `reserved_`, 0, before version 111):
+                            *   SGS_SH_DECODE_BIN_CENTRE (0)  v / 32 - 4 + 1 / 64: the centre of the truncation bin trunc((x / 8 + 0.5) * 256) the writer
+                            *                                 used — this repo's reading of the format since round 2, and the default;
+                            *   SGS_SH_DECODE_LINEAR255  (1)  v * 8 / 255 - 4: 0 -> -4, 255 -> +4, linear in between;
+                            *   SGS_SH_DECODE_BIN_CENTRE_ENDS (2)  as 0, but v = 0 -> -4 and v = 255 -> +4 exactly.
+                            * The three differ by at most 1 / 64 per coefficient.  The reference never decodes these bytes itself (README.md:197-231 hands
+                            * the file to @playcanvas/splat-transform, un-vendored, unpinned and not installable here), so which of them that tool
+                            * applies cannot be pinned from this container: choose the one your converter uses.  Anything else: SGS_ERR_INVALID. */
     const float* chunks;
     const uint32_t* packed;
     const uint8_t* sh;

@@ -37,6 +37,7 @@ struct sgs_scene {
     int64_t n = 0, n_chunks = 0;
     int sh_degree = 0, sh_rows = 0;     // sh_rows: 16-byte rows of SH per Gaussian (12 at degree 3; 4 when sh_packed)
     bool sh_packed = false;             // uploaded from the compressed payload: the 8-bit coefficients stay bytes in HBM (k_scene_layout<true>)
+    int sh_decode = 0;                  // ... and are read as sage_gs.h SGS_SH_DECODE_* says
     float4* geom = nullptr;
     float4* shq = nullptr;
     float4* cbound = nullptr;           // per chunk: bounding sphere of the means + largest scale (k_chunk_bounds)
@@ -303,7 +304,7 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.limx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx); P.limy = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
     P.rec_capacity = L.rec_cap;
     P.job_capacity = (int32_t)std::min<int64_t>(L.job_cap, 0x7fffffff);
-    P.flags = (cfg.flags & ~SGS_PFLAG_SH_PACKED) | (scene->sh_packed ? SGS_PFLAG_SH_PACKED : 0u);
+    P.flags = (cfg.flags & ~SGS_PFLAG_INTERNAL) | (scene->sh_packed ? SGS_PFLAG_SH_PACKED | ((uint32_t)scene->sh_decode << SGS_PFLAG_SH_MODE_SHIFT) : 0u);
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
         const double lx = P.limx, ly = P.limy;
         P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
@@ -794,6 +795,7 @@ int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int
     const int64_t n = z->n;
     if (n < 0 || n > 0x7fffffffll) SGS_FAIL(ctx, SGS_ERR_INVALID, "n = %lld out of range", (long long)n);
     if (z->sh_degree < 0 || z->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d not in 0..3", z->sh_degree);
+    if (z->sh_decode < SGS_SH_DECODE_BIN_CENTRE || z->sh_decode > SGS_SH_DECODE_BIN_CENTRE_ENDS) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_decode %d is not one of SGS_SH_DECODE_*", z->sh_decode);
     const int k_rest = (z->sh_degree + 1) * (z->sh_degree + 1) - 1;
     if (n > 0 && (!z->chunks || !z->packed || (k_rest > 0 && !z->sh))) SGS_FAIL(ctx, SGS_ERR_INVALID, "null input array");
     if (z->n_chunks != (n + 255) / 256) SGS_FAIL(ctx, SGS_ERR_INVALID, "n_chunks %lld is not ceil(n / 256)", (long long)z->n_chunks);
@@ -801,6 +803,7 @@ int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int
     sgs_scene* sc = nullptr;
     int rc;
     if ((rc = new_scene(ctx, n, z->sh_degree, true, &sc)) != SGS_OK) return rc;
+    sc->sh_decode = z->sh_decode;
     if (n > 0) {
         const void* src[3] = {z->chunks, z->packed, z->sh};
         const size_t bytes[3] = {(size_t)z->n_chunks * 18 * 4, (size_t)n * 16, (size_t)n * 3 * k_rest};
@@ -1117,7 +1120,13 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
             if (!sc->sh_packed) memcpy(o, w.data(), (size_t)nf * 4);
             else {      // 12 B of fp32 DC, then a byte per coefficient: v / 32 - 4 + 1 / 64, exact in fp32 (sgs_kernels.h sgs_sh_byte)
                 memcpy(o, w.data(), 12);
-                for (int j = 0; j < nf - 3; ++j) o[3 + j] = (float)((w[(size_t)3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu) * (1.0f / 32.0f) + (-4.0f + 1.0f / 64.0f);
+                for (int j = 0; j < nf - 3; ++j) {      // sgs_kernels.h sgs_sh_byte / sgs_sh_byte_mode, restated: one correctly rounded fma (exact in double, rounded once)
+                    const unsigned v = (w[(size_t)3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
+                    volatile double prod = (double)v * (8.0 / 255.0);         // (two roundings, as the kernel's __dmul_rn / __dsub_rn)
+                    float x = sc->sh_decode == SGS_SH_DECODE_LINEAR255 ? (float)(prod - 4.0) : (float)((double)v * (1.0 / 32.0) + (-4.0 + 1.0 / 64.0));
+                    if (sc->sh_decode == SGS_SH_DECODE_BIN_CENTRE_ENDS) x = v == 0u ? -4.0f : v == 255u ? 4.0f : x;
+                    o[3 + j] = x;
+                }
             }
         }
     }

@@ -20,7 +20,7 @@
 #define SGS_DYNAMIC_LDS(T, name) extern __shared__ T name[]
 #endif
 // a wave-uniform value the hot loop multiplies with: pinned to a vector register (an SGPR or literal operand makes a VALU
-// instruction cost 1.6 issue slots on gfx950, scripts/ubench.hip).  Value-preserving; a CPU test harness defines it away.
+// instruction cost 1.75 issue slots on gfx950: 4.2 against 2.4 cycles, scripts/ubench2.hip).  Value-preserving; a CPU test harness defines it away.
 #ifndef SGS_PIN_VGPR
 #define SGS_PIN_VGPR(x) asm volatile("" : "+v"(x))
 #endif
@@ -48,7 +48,9 @@
 #define SGS_PROF_WORDS 24            // profiling build: words per tile in the tile_prof buffer
 #define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
 
-#define SGS_PFLAG_SH_PACKED 0x80000000u   // FrameParams.flags, set by the library (never by a caller's sgs_config): the scene's SH rows are packed bytes
+#define SGS_PFLAG_SH_PACKED 0x80000000u   // FrameParams.flags, set by the library (never by a caller's sgs_config): the scene's SH rows are packed bytes,
+#define SGS_PFLAG_SH_MODE_SHIFT 29        // ... decoded with mode (flags >> 29) & 3 (sage_gs.h SGS_SH_DECODE_*)
+#define SGS_PFLAG_INTERNAL 0xE0000000u
 // Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).
 struct FrameParams {
     float view[12];                 // rows 0..2 of the model->camera matrix (row-major 3x4)
@@ -110,7 +112,7 @@ struct Splat;
 // frame, and everything that differs between the frames of a group — parameters, intermediates, output — is one FrameSlot
 // of the FrameGroup passed BY VALUE (kernarg segment, scalar-loaded; no device copy to keep alive).  Why: a light frame
 // (a rank's band of tile rows) is five launches of ~25 us each, and an MI355X retires small kernels from several streams
-// barely faster than from one (scripts/launch_floor.hip: 1.6-2x at best) — so a sweep's frames ride the same five
+// barely faster than from one (round 2's launch-floor probe: 1.6-2x at best) — so a sweep's frames ride the same five
 // launches instead of five launches each.
 #define SGS_MAX_GROUP 8
 struct FrameSlot {

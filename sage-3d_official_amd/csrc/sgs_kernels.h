@@ -19,6 +19,7 @@
 namespace sgs {
 
 #define SGS_LOG2E 1.44269504088896341f
+#define SGS_SAT0(x) __builtin_amdgcn_fmed3f((x), 0.0f, 1.0f)
 
 // ------------------------------------------------------------------------------------------------
 // wave64 helpers
@@ -120,6 +121,19 @@ __device__ __forceinline__ void unpack_gaussian(const PackedScene& Z, long long 
 // bit for bit, to the four-step form: the layout kernel (scenes inflated to fp32 rows) and k_preprocess (scenes that keep the bytes in
 // HBM, below) decode to the same floats.
 __device__ __forceinline__ float sgs_sh_byte(unsigned v) { return __builtin_fmaf((float)v, 1.0f / 32.0f, -4.0f + 1.0f / 64.0f); }
+// The three readings of such a byte (sage_gs.h SGS_SH_DECODE_*), selected per scene (wave-uniform `mode`).  LINEAR255 is evaluated as a
+// converter written in JavaScript evaluates it — in DOUBLE, v * (8 / 255) - 4, product and difference rounded separately — and then
+// rounded to fp32 (255 -> exactly 4); BIN_CENTRE_ENDS moves the two end codes out to -4 / +4 with saturated fmas (no compare, no select).
+__device__ __forceinline__ float sgs_sh_byte_mode(unsigned v, unsigned mode) {
+    if (mode == 1u) return (float)__dsub_rn(__dmul_rn((double)v, 8.0 / 255.0), 4.0);
+    const float fv = (float)v;
+    float x = __builtin_fmaf(fv, 1.0f / 32.0f, -4.0f + 1.0f / 64.0f);
+    if (mode == 2u) {
+        const float lo = SGS_SAT0(1.0f - fv), hi = SGS_SAT0(fv - 254.0f);          // 1 for v = 0 / v = 255, else 0
+        x += (hi - lo) * (1.0f / 64.0f);
+    }
+    return x;
+}
 // SH coefficient k (0 .. 3 (k_rest + 1) - 1, Gaussian-major [coefficient][channel] as the renderer takes them) of Gaussian i
 __device__ __forceinline__ float unpack_sh(const PackedScene& Z, long long i, const UnpackedG& g, int k) {
     const int coef = k / 3, ch = k - 3 * coef;
@@ -444,7 +458,7 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
 // PACKED: the rows hold a compressed scene's byte string (k_scene_layout<true>): 12 B of fp32 DC, then one byte per coefficient.
 template <int DEG, bool PACKED>
 __device__ __forceinline__ void eval_sh(const float4* __restrict__ row0, float x, float y, float z,
-                                        float& out_r, float& out_g, float& out_b) {
+                                        float& out_r, float& out_g, float& out_b, unsigned mode = 0u) {
     constexpr int NF = 3 * (DEG + 1) * (DEG + 1);
     constexpr int ROWS = PACKED ? (12 + (NF - 3) + 15) / 16 : (NF + 3) / 4;
     float c[PACKED ? NF + 4 : ROWS * 4];
@@ -456,8 +470,13 @@ __device__ __forceinline__ void eval_sh(const float4* __restrict__ row0, float x
             w[4 * r] = __float_as_uint(v.x); w[4 * r + 1] = __float_as_uint(v.y); w[4 * r + 2] = __float_as_uint(v.z); w[4 * r + 3] = __float_as_uint(v.w);
         }
         c[0] = __uint_as_float(w[0]); c[1] = __uint_as_float(w[1]); c[2] = __uint_as_float(w[2]);
+        if (mode == 0u) {
 #pragma unroll
-        for (int j = 0; j < NF - 3; ++j) c[3 + j] = sgs_sh_byte((w[3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);     // (v_cvt_f32_ubyteN + one fma)
+            for (int j = 0; j < NF - 3; ++j) c[3 + j] = sgs_sh_byte((w[3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu);     // (v_cvt_f32_ubyteN + one fma)
+        } else {
+#pragma unroll
+            for (int j = 0; j < NF - 3; ++j) c[3 + j] = sgs_sh_byte_mode((w[3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu, mode);
+        }
     } else {
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
@@ -718,11 +737,12 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float4* row0 = shq + (chunk * P.sh_rows) * SGS_WAVE + lane;
         float r, g, b;
         if (P.flags & SGS_PFLAG_SH_PACKED) {         // a compressed scene: 8-bit coefficients, dequantised here (wave-uniform branch)
+            const unsigned shm = (P.flags >> SGS_PFLAG_SH_MODE_SHIFT) & 3u;
             switch (P.sh_degree) {
-                case 0: eval_sh<0, true>(row0, ux, uy, uz, r, g, b); break;
-                case 1: eval_sh<1, true>(row0, ux, uy, uz, r, g, b); break;
-                case 2: eval_sh<2, true>(row0, ux, uy, uz, r, g, b); break;
-                default: eval_sh<3, true>(row0, ux, uy, uz, r, g, b); break;
+                case 0: eval_sh<0, true>(row0, ux, uy, uz, r, g, b, shm); break;
+                case 1: eval_sh<1, true>(row0, ux, uy, uz, r, g, b, shm); break;
+                case 2: eval_sh<2, true>(row0, ux, uy, uz, r, g, b, shm); break;
+                default: eval_sh<3, true>(row0, ux, uy, uz, r, g, b, shm); break;
             }
         } else switch (P.sh_degree) {
             case 0: eval_sh<0, false>(row0, ux, uy, uz, r, g, b); break;
@@ -1591,10 +1611,11 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
 }
 
 // ---- the blend loop of k_tile_render -----------------------------------------------------------------
-// Issue costs measured on gfx950 (scripts/ubench.hip, 6 waves per SIMD, plain v_fma_f32 = 1): packed fp32
-// (v_pk_*) 1.8 — no gain over two plain ops —, v_cmp / v_min / v_max / v_cndmask and any SGPR operand 1.6,
-// v_exp_f32 3, an LDS read 3.5-6 on the CU's shared LDS pipe; source modifiers (neg, abs) and the VOP3 `clamp` output
-// modifier (result saturated to [0, 1], NaN -> 0) are free.  The composite is issue-bound, so the per-pixel work is
+// Issue costs measured on gfx950 (scripts/ubench2.hip, in-kernel clocks; shader cycles per wave64 instruction and SIMD at 8 waves per SIMD,
+// profiles/r05b_ubench2_table.txt): v_fma_f32 2.40 (v_mul 2.29), packed fp32 (v_pk_*) 4.34 — barely ahead of two plain ops —, v_cmp / v_max /
+// v_med3 and any SGPR operand 4.2-4.4, v_cndmask on vcc 19 (!), v_exp_f32 8.2, a broadcast ds_read_b32/b64 2.1 on the CU's shared LDS pipe
+// (= 8.4 of each of the four SIMDs' time when all four stream reads), ds_read_b128 twice that; source modifiers (neg, abs) and the VOP3 `clamp`
+// output modifier (result saturated to [0, 1], NaN -> 0) are free.  One wave ALONE on its SIMD issues a VALU instruction every 7.3 cycles.  The composite is issue-bound, so the per-pixel work is
 // written for the smallest issue COST: no compare, select or min is left in the common trip — every predicate is a
 // saturated fma, i.e. a factor 0 / 1, and every constant is folded into the splat once (k_preprocess), not per pixel:
 //   * q2 = A dx^2 + B dx dy + C dy^2 = -power log2(e) is evaluated as the completed square A (dx + k dy)^2 + C' dy^2

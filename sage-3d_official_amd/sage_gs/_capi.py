@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+SH_DECODE = {"bin_centre": 0, "linear255": 1, "bin_centre_ends": 2}      # include/sage_gs.h SGS_SH_DECODE_*
 ABI_VERSION = 111        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
@@ -48,7 +49,7 @@ class SgsConfig(C.Structure):
 
 
 class SgsCompressedScene(C.Structure):
-    _fields_ = [("n", C.c_int64), ("n_chunks", C.c_int64), ("sh_degree", C.c_int32), ("reserved_", C.c_int32),
+    _fields_ = [("n", C.c_int64), ("n_chunks", C.c_int64), ("sh_degree", C.c_int32), ("sh_decode", C.c_int32),
                 ("chunks", C.c_void_p), ("packed", C.c_void_p), ("sh", C.c_void_p)]
 
 

@@ -147,7 +147,7 @@ def _pack_111011(u):
     return (q[:, 0] << 21) | (q[:, 1] << 11) | q[:, 2]
 
 
-def load_compressed_ply(path):
+def load_compressed_ply(path, sh_decode: str = "bin_centre"):
     el = read_elements(path)
     ch, v = el["chunk"], el["vertex"]
     n = v.shape[0]
@@ -183,7 +183,7 @@ def load_compressed_ply(path):
         s = el["sh"]
         rest = sorted(s.dtype.names, key=lambda k: int(k.split("_")[-1]))
         k_rest = len(rest) // 3
-        r = (np.stack([s[k] for k in rest], 1).astype(np.float32) / 256.0 - 0.5) * 8.0 + (4.0 / 256.0)
+        r = decode_sh_bytes(np.stack([s[k] for k in rest], 1), sh_decode)
         sh = np.empty((n, k_rest + 1, 3), np.float32)
         sh[:, 0] = dc
         sh[:, 1:] = np.transpose(r.reshape(n, 3, k_rest), (0, 2, 1))
@@ -197,6 +197,25 @@ CHUNK_PROPS = ["min_x", "min_y", "min_z", "max_x", "max_y", "max_z",
                "min_scale_x", "min_scale_y", "min_scale_z", "max_scale_x", "max_scale_y", "max_scale_z"]
 CHUNK_COLOR_PROPS = ["min_r", "min_g", "min_b", "max_r", "max_g", "max_b"]
 PACKED_PROPS = ["packed_position", "packed_rotation", "packed_scale", "packed_color"]
+
+
+def decode_sh_bytes(v, mode: str = "bin_centre"):
+    """8-bit SH coefficient(s) -> float32, three readings (include/sage_gs.h SGS_SH_DECODE_*; the device applies the same arithmetic):
+      "bin_centre"       (v / 256 - 0.5) * 8 + 4 / 256 = v / 32 - 4 + 1 / 64 — the centre of the bin trunc((x / 8 + 0.5) * 256) that
+                         encode_compressed (and, as far as this repo can tell, the PlayCanvas writer) puts x into.  Exact in fp32.  DEFAULT.
+      "linear255"        v * 8 / 255 - 4: the end codes are -4 and +4.
+      "bin_centre_ends"  bin centres, but 0 -> -4 and 255 -> +4 exactly.
+    They differ by at most 1/64 per coefficient.  The reference delegates this decode to @playcanvas/splat-transform (README.md:197-231),
+    which is neither vendored nor installable offline, so the tool's choice could not be pinned here — hence the option."""
+    v = np.asarray(v)
+    if mode == "linear255":
+        return (v.astype(np.float64) * (8.0 / 255.0) - 4.0).astype(np.float32)      # in double, as a JavaScript converter computes it; the device does the same
+    r = (v.astype(np.float32) / 256.0 - 0.5) * 8.0 + (4.0 / 256.0)
+    if mode == "bin_centre_ends":
+        r = np.where(v == 0, np.float32(-4.0), np.where(v == 255, np.float32(4.0), r)).astype(np.float32)
+    elif mode != "bin_centre":
+        raise ValueError('mode must be "bin_centre", "linear255" or "bin_centre_ends"')
+    return r
 
 
 def read_compressed_payload(path):

@@ -82,7 +82,7 @@ class Scene:
 
     def __init__(self, renderer: "Renderer", handle, n, sh_degree, model_to_world):
         self._r, self.handle, self.n, self.sh_degree = renderer, handle, n, sh_degree
-        self.model_to_world = None if model_to_world is None else np.asarray(model_to_world, np.float64)
+        self.model_to_world = None if model_to_world is None else _check_model_to_world(model_to_world)
 
     def free(self):
         if self.handle:
@@ -97,11 +97,13 @@ class Scene:
 
 
 def _rigid(views: np.ndarray) -> np.ndarray:
-    """[...,4,4] float64 views -> the same, with every 3x3 that is measurably off orthonormal AFTER the cast to fp32 (a view
-    composed or inverted in fp32: torch.linalg.inv of a c2w matrix, poses parsed from 6-digit text) replaced by the nearest
+    """[...,4,4] float64 CAMERA poses (world -> camera) -> the same, with every 3x3 that is measurably off orthonormal AFTER the cast to
+    fp32 (a view composed or inverted in fp32: torch.linalg.inv of a c2w matrix, poses parsed from 6-digit text) replaced by the nearest
     rotation (polar decomposition).  The C ABI wants the rows orthonormal to 1e-5 (include/sage_gs.h) and says so with an error at
     enqueue time; a Python caller gets the projection instead.  Views already orthonormal to 2e-6 pass through bit for bit, and
-    one that is off by more than 1e-3 is not a pose with rounding noise: it is left alone and the library reports it."""
+    one that is off by more than 1e-3 is not a pose with rounding noise: it is left alone and the library reports it.
+    Applied to the camera's pose ONLY, before it is composed with a scene's model_to_world — an asset transform is validated on its own
+    (_check_model_to_world): a USD xformOp:scale of 1.0003 is a real scale, not rounding noise, and must not be projected away."""
     v = np.array(views, np.float64, copy=True)
     flat = v.reshape(-1, 4, 4)
     for m in flat:
@@ -111,6 +113,20 @@ def _rigid(views: np.ndarray) -> np.ndarray:
             u, _, vt = np.linalg.svd(m[:3, :3])
             m[:3, :3] = u @ vt
     return v
+
+
+def _check_model_to_world(m) -> np.ndarray:
+    """A scene's model -> world transform must be RIGID (rotation + translation): the renderer applies it by moving the camera into model
+    space, which is exact only then.  Off by up to 2e-6 (a rotation written in fp32): accepted as it is.  Anything more — a scale, a
+    shear, a mirror — raises here, with the fix, instead of being silently re-orthonormalised (round 4) or rejected later by the
+    library's per-frame rigidity check with a message about the camera."""
+    m = np.asarray(m, np.float64).reshape(4, 4)
+    r = m[:3, :3]
+    dev = float(np.abs(r @ r.T - np.eye(3)).max())
+    if not (dev <= 2.0e-6) or not np.allclose(m[3], [0.0, 0.0, 0.0, 1.0], atol=1e-12) or np.linalg.det(r) < 0:
+        raise ValueError(f"model_to_world is not a rigid transform (its 3x3 is off orthonormal by {dev:.3g}): bake the asset's scale / shear into the "
+                         "Gaussians' means and scales (a USD xformOp:scale s multiplies both) and pass the rotation + translation only")
+    return m
 
 
 def _as_f32(t: torch.Tensor, device, shape_tail):
@@ -159,10 +175,13 @@ class Renderer:
                                                        sh.data_ptr(), 1, C.byref(h)), self._ctx)
         return Scene(self, h, n, int(g.sh_degree), g.model_to_world)
 
-    def upload_compressed(self, chunks, packed, sh, sh_degree: int, model_to_world=None) -> Scene:
+    def upload_compressed(self, chunks, packed, sh, sh_degree: int, model_to_world=None, sh_decode: str = "bin_centre") -> Scene:
         """A scene from the PlayCanvas compressed.ply payload (ply.read_compressed_payload: chunks float32 [nch,18], packed uint32 [n,4],
         sh uint8 [n, 3 k_rest] or None): copied to the device as it is — 16 B + SH bytes per Gaussian — and dequantised there by the
-        layout kernel (sgs_scene_upload_compressed).  NumPy arrays or tensors; tensors already on this device are used in place."""
+        layout kernel (sgs_scene_upload_compressed); the 8-bit SH coefficients stay bytes in HBM and are dequantised by the projection
+        kernel every frame.  NumPy arrays or tensors; tensors already on this device are used in place.
+        sh_decode: how a coefficient byte becomes a float — "bin_centre" (default), "linear255" or "bin_centre_ends" (ply.decode_sh_bytes,
+        include/sage_gs.h SGS_SH_DECODE_*): pick what the tool that wrote / would decompress your file uses."""
         def dev(a, dt):
             if a is None:
                 return None
@@ -180,7 +199,9 @@ class Renderer:
             k_rest = (int(sh_degree) + 1) ** 2 - 1
             if (k_rest > 0) != (b is not None) or (b is not None and tuple(b.shape) != (n, 3 * k_rest)):
                 raise ValueError(f"sh must be uint8 [n, {3 * k_rest}] at degree {sh_degree} (None at degree 0)")
-            z = _capi.SgsCompressedScene(n, nch, int(sh_degree), 0, c.data_ptr(), p.data_ptr(), b.data_ptr() if b is not None else None)
+            if sh_decode not in _capi.SH_DECODE:
+                raise ValueError(f"sh_decode must be one of {sorted(_capi.SH_DECODE)}")
+            z = _capi.SgsCompressedScene(n, nch, int(sh_degree), _capi.SH_DECODE[sh_decode], c.data_ptr(), p.data_ptr(), b.data_ptr() if b is not None else None)
             torch.cuda.synchronize(self.device)
             h = C.c_void_p()
             self._lib.check(self._lib.sgs_scene_upload_compressed(self._ctx, C.byref(z), 1, C.byref(h)), self._ctx)
@@ -205,9 +226,9 @@ class Renderer:
     def _c_camera(cam: Camera, scene: Scene) -> _capi.SgsCamera:
         view = np.asarray(cam.view.detach().cpu().numpy() if isinstance(cam.view, torch.Tensor) else cam.view,
                           np.float64).reshape(4, 4)
+        view = _rigid(view)                       # (the camera's pose alone: see _rigid)
         if scene.model_to_world is not None:
             view = view @ scene.model_to_world.reshape(4, 4)
-        view = _rigid(view)
         return _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                                  view.astype(np.float32).tolist())
 
@@ -222,9 +243,9 @@ class Renderer:
         b = len(cameras)
         views = np.stack([np.asarray(c.view.detach().cpu().numpy() if isinstance(c.view, torch.Tensor) else c.view,
                                      np.float64).reshape(4, 4) for c in cameras])
+        views = _rigid(views)                     # (the cameras' poses alone: see _rigid)
         if scene.model_to_world is not None:
             views = views @ scene.model_to_world.reshape(4, 4)
-        views = _rigid(views)
         arr = np.zeros(b, cls._CAM_DTYPE)
         arr["width"] = [c.width for c in cameras]; arr["height"] = [c.height for c in cameras]
         arr["fx"] = [c.fx for c in cameras]; arr["fy"] = [c.fy for c in cameras]

@@ -241,6 +241,9 @@ static inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CS
 template <class T> static inline T __hip_atomic_fetch_add(T* p, T v, int, int) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return fmaxf(fminf(a, b), fminf(fmaxf(a, b), c)); }
 static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }   // callers pass wave-uniform values
+// IEEE double multiply / subtract, each rounded on its own (never contracted into an fma)
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
 // v_exp_f32 / v_rcp_f32 / v_sqrt_f32 (1 ulp on the hardware; correctly rounded here — the kernels pad every use)
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

@@ -167,3 +167,25 @@ def test_isaac_pose_from_view_inverts_view_from_isaac_pose():
         V = scenes.view_from_yaw((1.0, 2.0, 1.2), yaw)
         p2, q2 = camera.isaac_pose_from_view(V)
         assert np.allclose(camera.view_from_isaac_pose(p2, q2), V, atol=1e-12)
+
+
+def test_pose_projection_and_asset_transform_validation():
+    """Python surface (renderer._rigid / _check_model_to_world): a camera pose with fp32-composition noise is projected onto the nearest
+    rotation, an orthonormal one passes bit for bit, and a scene's model_to_world is NOT projected: rigid to 2e-6 or refused — a USD
+    xformOp:scale of 1.0003 is a real scale (it used to be silently re-orthonormalised away)."""
+    from sage_gs import renderer, scenes
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    q *= np.sign(np.linalg.det(q))
+    V = np.eye(4); V[:3, :3] = q; V[:3, 3] = [0.3, -1.2, 2.0]
+    assert np.array_equal(renderer._rigid(V), V)
+    noisy = V.copy(); noisy[:3, :3] += 3e-5 * rng.normal(size=(3, 3))
+    fixed = renderer._rigid(noisy)
+    assert np.abs(fixed[:3, :3] @ fixed[:3, :3].T - np.eye(3)).max() < 1e-12 and np.abs(fixed - noisy).max() < 2e-4
+    assert np.array_equal(fixed[:3, 3], noisy[:3, 3])
+    far = V.copy(); far[:3, :3] *= 1.01
+    assert np.array_equal(renderer._rigid(far), far)                  # not rounding noise: left for the library to refuse
+    assert np.array_equal(renderer._check_model_to_world(scenes.MODEL_TO_WORLD), np.asarray(scenes.MODEL_TO_WORLD, np.float64))
+    for bad in (np.diag([1.0003, 1.0003, 1.0003, 1.0]), np.diag([1.0, -1.0, 1.0, 1.0]), np.array([[1, 1e-3, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])):
+        with pytest.raises(ValueError, match="not a rigid transform"):
+            renderer._check_model_to_world(bad)

@@ -312,6 +312,28 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
             img32, st32 = d.render(cam)
             assert np.array_equal(img32, img) and st32["d_total"] == st["d_total"] and st32["n_visible"] == st["n_visible"]
             assert st["bytes"]["preprocess"] < st32["bytes"]["preprocess"] or deg == 0     # (algorithmic bytes: 4 rows of SH per visible Gaussian instead of 12)
+            if deg == 3:
+                # the other two readings of a coefficient byte (sage_gs.h SGS_SH_DECODE_*): what the kernel evaluates is ply.decode_sh_bytes' arithmetic
+                # bit for bit (SGS_BUF_SCENE_SH restates it on the host; the frame is checked against the fp32 upload of those floats)
+                payload = ply.read_compressed_payload(path)
+                shb = payload[2]
+                shb[:7, :] = 0; shb[7:13, :] = 255                                     # (the end codes, where the readings differ most)
+                for mode in ("linear255", "bin_centre_ends"):
+                    d.upload_compressed(payload[0], payload[1], shb, deg, sh_decode=mode)
+                    img_m, _ = d.render(cam)
+                    shm = d.scene_sh()
+                    want = np.transpose(ply.decode_sh_bytes(shb, mode).reshape(n, 3, -1), (0, 2, 1))
+                    assert np.array_equal(shm[:, 1:], want), mode
+                    assert (shm[:7, 1:] == -4.0).all() and (shm[7:13, 1:] == 4.0).all()          # the end codes: -4 and +4 exactly
+                    gm = d.scene_geom()
+                    d.upload(gm[:, 0:3].copy(), gm[:, 4:7].copy(), gm[:, 7:11].copy(), gm[:, 3].copy(), shm, deg)
+                    img_f, _ = d.render(cam)
+                    assert np.array_equal(img_f, img_m), mode
+                import ctypes as C
+                from sage_gs import _capi
+                bad = _capi.SgsCompressedScene(n, payload[0].shape[0], deg, 7, payload[0].ctypes.data, np.ascontiguousarray(payload[1], np.uint32).ctypes.data, shb.ctypes.data)
+                h = C.c_void_p()
+                assert d.lib.sgs_scene_upload_compressed(d.ctx, C.byref(bad), 0, C.byref(h)) == -1 and b"sh_decode" in d.lib.sgs_last_error(d.ctx)
     finally:
         d.close()
 

@@ -712,6 +712,17 @@ def test_compressed_scene_keeps_its_sh_bytes_in_hbm_and_renders_the_same_frames(
         assert np.array_equal(shd[:, 1:], want.astype(np.float32))
     scene_c.free()
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    if deg == 3:     # the other readings of a coefficient byte: the kernel's arithmetic (fp64 on the device for linear255) is NumPy's, code for code
+        shb2 = shb.copy(); shb2[:300] = np.arange(300)[:, None] % 256
+        for mode in ("linear255", "bin_centre_ends"):
+            sm = drv.r.upload_compressed(chunks, packed, shb2, deg, model_to_world=sc.model_to_world, sh_decode=mode)
+            fm = drv.r.render(cams[0], sm).clone()
+            got = drv.r.debug_buffer(_capi.BUF_SCENE_SH, np.float32).reshape(len(m), -1, 3)
+            assert np.array_equal(got[:, 1:], ply.decode_sh_bytes(shb2, mode).reshape(len(m), 3, -1).transpose(0, 2, 1)), mode
+            sm.free()
+            sf = drv.r.upload(Gaussians(t(g[:, 0:3]), t(g[:, 4:7]), t(g[:, 7:11]), t(g[:, 3]), t(got), deg, sc.model_to_world))
+            assert bool((drv.r.render(cams[0], sf) == fm).all()), mode          # (what k_preprocess dequantised == those floats)
+            sf.free()
     scene_f = drv.r.upload(Gaussians(t(g[:, 0:3]), t(g[:, 4:7]), t(g[:, 7:11]), t(g[:, 3]), t(shd), deg, sc.model_to_world))
     for cam, f, st in zip(cams, frames, stats):
         f32 = drv.r.render(cam, scene_f, stats=True)

@@ -499,3 +499,19 @@ def test_sweep_writes_the_files_a_recorded_run_of_the_reference_wrote(tmp_path):
     for k in ("scene_id", "trajectory_id", "instruction_index", "frame_filenames", "trajectory_sampled_points"):
         assert so[k] == sr[k], k
     assert so["sampling_info"]["sampled_points_count"] == sr["sampling_info"]["sampled_points_count"] == so["sampling_info"]["generated_images_count"]
+
+
+def test_sh_byte_decode_modes_over_all_codes():
+    """ply.decode_sh_bytes over the 256 codes: the three readings (include/sage_gs.h SGS_SH_DECODE_*) are increasing, agree to 1/64, invert
+    the encoder's truncation bin (bin_centre re-encodes to the same byte), and the end codes of the other two are exactly -4 / +4."""
+    v = np.arange(256, dtype=np.uint8)
+    c, l, e = (ply.decode_sh_bytes(v, m) for m in ("bin_centre", "linear255", "bin_centre_ends"))
+    assert c.dtype == l.dtype == e.dtype == np.float32
+    for a in (c, l, e):
+        assert (np.diff(a) > 0).all() and a.min() >= -4.0 and a.max() <= 4.0
+    assert np.array_equal(c, (v.astype(np.float64) / 32.0 - 4.0 + 1.0 / 64.0).astype(np.float32))
+    assert np.array_equal(np.clip(np.trunc((c.astype(np.float64) / 8.0 + 0.5) * 256.0), 0, 255).astype(np.uint8), v)      # encode(decode(v)) == v
+    assert np.abs(l - c).max() <= 1.0 / 64.0 + 1e-7 and np.abs(e - c).max() == 1.0 / 64.0
+    assert l[0] == -4.0 and l[255] == 4.0 and e[0] == -4.0 and e[255] == 4.0 and np.array_equal(e[1:255], c[1:255])
+    with pytest.raises(ValueError):
+        ply.decode_sh_bytes(v, "nearest")
