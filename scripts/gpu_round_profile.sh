@@ -4,7 +4,7 @@
 #   (frames in flight, and one frame at a time), PMC passes (counters in their own runs, --kernel-trace only) over the SAME
 #   pose sets, traffic.json keyed by pose set (bench.py quotes PMC figures only for the pose set they were taken on),
 #   the 4K sweep of BASELINE config 5.
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profile_$TAG
@@ -12,6 +12,8 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json
 timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err; tail -c 300 $OUT/bench_k20.json
+echo "== N = 2 on this one GPU under gloo (the N > 1 code path incl. verify; not a scaling number)"; SGS_BENCH_SHARE_GPU=1 timeout 400 python $ROOT/bench.py --gpus 2 --steps 20 --warmup 5 --no-secondary > $OUT/bench_n2_shared_gpu.json 2> $OUT/bench_n2_shared_gpu.err; grep verify $OUT/bench_n2_shared_gpu.err
+echo "== fp32 / compressed scene, the reference's resolutions (stage times alone)"; (cd $ROOT && timeout 400 python scripts/r05_probe.py fp32 packed lowres n=20 2>&1 | grep -v amdgpu.ids > $OUT/probe_fp32_packed_lowres.txt; cat $OUT/probe_fp32_packed_lowres.txt)
 echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres --no-upload-probe > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
 trace() { # name args...
   local name=$1; shift
