@@ -47,6 +47,19 @@ def rate(r, gs, cams, ring, n=100):
     return best
 
 
+def rate_batch(r, gs, cams, n=20):
+    """ms per frame of ONE render_batch call of n frames (the bench's headline path: frame groups of four on two streams)"""
+    cl = [cams[poses[i % len(poses)]] for i in range(n)]
+    out = torch.zeros((n, cams[0].height, cams[0].width, 3), dtype=torch.float32, device=dev)
+    best = 1e9
+    for rep in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r.render_batch(cl, gs, out=out)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / n * 1e3)
+    return best
+
+
 def latency(r, gs, cams, buf, n=32):
     lat = []
     for p in poses[:4]:
@@ -77,7 +90,7 @@ for libname in LIBS:
             a = alone(r, gs, cams, ring[0], N)
             line = f"[{tag}] {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
             if (w, h) == (1920, 1080):
-                line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame"
+                line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame | render_batch x20 {rate_batch(r, gs, cams, 20):.4f} x100 {rate_batch(r, gs, cams, 100):.4f}"
             else:
                 p50, p90 = latency(r, gs, cams, ring[0])
                 line += f" | latency p50 {p50:.3f} p90 {p90:.3f} ms"
