@@ -27,7 +27,8 @@ extern "C" {
 #endif
 
 #define SGS_VERSION 111            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
-                                    * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points): a caller compiled against
+                                    * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points; 111: sgs_stats grew n_deep_windows, sgs_compressed_scene.reserved_ became sh_decode,
+                                    * SGS_BUF_SCENE_SH): a caller compiled against
                                     * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
                                     * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
                                     * that takes a struct.  The library writes whole structs (sgs_stats arrays with ITS stride). */
