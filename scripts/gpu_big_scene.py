@@ -14,11 +14,12 @@ t0 = time.time(); gs = r.upload(scenes.to_gaussians(sc, "cuda:0")); torch.cuda.s
 bad = 0
 for i, c in enumerate(cams):
     img = r.render(c, gs, timing=True, stats=True).clone(); st = r.last_stats
+    plain = r.render(c, gs).clone(); deep = r.last_stats["n_deep_windows"]            # the instantiation a sweep runs (no D_f): deep-tile path included
     ref = r.render(c, gs, full_sort=True, loose_cull=True).clone(); st_ref = r.last_stats
     union = torch.zeros_like(img); d = 0
     for a, b in ((0, 20), (20, 31), (31, 33), (33, 50), (50, 68)):
         r.render(c, gs, out=union, tile_rows=(a, b)); d += r.last_stats["d_total"]
-    ok = bool((img == ref).all()) and bool((union == img).all()) and d == st["d_total"] and st["d_total"] <= st_ref["d_total"] and st["n_visible"] == st_ref["n_visible"]
-    print(f"cam {i}: N_v={st['n_visible']} D={st['d_total']} (reference binning {st_ref['d_total']}) D_f={st['d_fetched']} ms={ {k: round(v, 3) for k, v in st['ms'].items()} } -> {'ok' if ok else 'MISMATCH'}", flush=True)
+    ok = bool((img == ref).all()) and bool((plain == img).all()) and bool((union == img).all()) and d == st["d_total"] and st["d_total"] <= st_ref["d_total"] and st["n_visible"] == st_ref["n_visible"]
+    print(f"cam {i}: N_v={st['n_visible']} D={st['d_total']} (reference binning {st_ref['d_total']}) D_f={st['d_fetched']} deep windows {deep} ms={ {k: round(v, 3) for k, v in st['ms'].items()} } -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
 print(f"{bad} mismatches"); sys.exit(1 if bad else 0)
