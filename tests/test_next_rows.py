@@ -515,3 +515,66 @@ def test_sh_byte_decode_modes_over_all_codes():
     assert l[0] == -4.0 and l[255] == 4.0 and e[0] == -4.0 and e[255] == 4.0 and np.array_equal(e[1:255], c[1:255])
     with pytest.raises(ValueError):
         ply.decode_sh_bytes(v, "nearest")
+
+
+def test_sweep_bounds_the_frames_waiting_for_the_encoder_and_always_shuts_its_pool_down(tmp_path, monkeypatch):
+    """sweep.run's host side: at most 4 x encode_workers frames wait for (or are in) the JPEG encoder however fast the renderer produces them
+    (every queued frame holds its own copy: unbounded, a scene of a few thousand waypoints held gigabytes), and the thread pool is shut down
+    on every exit path — also when a callback raises half-way."""
+    import concurrent.futures as cf
+    import time
+    import torch
+    seen = {"max_pending": 0, "shutdowns": 0, "submitted": 0}
+
+    class Pool(cf.ThreadPoolExecutor):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k); self._futs = []
+
+        def submit(self, fn, *a, **k):
+            self._futs = [f for f in self._futs if not f.done()]
+            f = super().submit(fn, *a, **k)
+            self._futs.append(f); seen["submitted"] += 1
+            seen["max_pending"] = max(seen["max_pending"], len(self._futs))
+            return f
+
+        def shutdown(self, *a, **k):
+            seen["shutdowns"] += 1
+            return super().shutdown(*a, **k)
+    monkeypatch.setattr(cf, "ThreadPoolExecutor", Pool)
+    from PIL import Image
+    real_save = Image.Image.save
+
+    def slow_save(self, *a, **k):
+        time.sleep(0.004)                       # an encoder far slower than the (fake) renderer
+        return real_save(self, *a, **k)
+    monkeypatch.setattr(Image.Image, "save", slow_save)
+
+    class Handle:
+        def __init__(self, host):
+            self.host = host
+
+        def wait(self):
+            return self.host
+
+    class Fake:
+        def host_frames(self, shape, depth=2):
+            class Ring:
+                def submit(self, buf, n):
+                    return Handle(np.zeros(shape, np.uint8))
+            return Ring()
+
+        def render_batch(self, cams, scene, out=None):
+            return torch.zeros((len(cams), cams[0].height, cams[0].width, 3))
+    traj = [{"trajectory_id": "t", "instruction_index": 0,
+             "points": [{"point": i, "position": [0.1 * i, 0.0, 1.2], "rotation": [1.0, 0.0, 0.0, 0.0]} for i in range(96)]}]
+    n = sweep.run(Fake(), None, traj, "0042", str(tmp_path / "a"), resolution=(32, 24), chunk=32, encode_workers=2)
+    assert n == 96 and seen["submitted"] == 96 and seen["shutdowns"] == 1
+    assert seen["max_pending"] <= 4 * 2 + 1, seen                       # (+1: the frame being submitted)
+    assert len(os.listdir(tmp_path / "a" / "images" / "trajectory_t")) == 96
+
+    def boom(tid, i, rgb):
+        if i == 40:
+            raise RuntimeError("callback failed")
+    with pytest.raises(RuntimeError, match="callback failed"):
+        sweep.run(Fake(), None, traj, "0042", str(tmp_path / "b"), resolution=(32, 24), chunk=32, encode_workers=2, on_frame=boom)
+    assert seen["shutdowns"] == 2
