@@ -201,3 +201,25 @@ def test_rccl_world_size_one_smoke():
     assert p.exitcode == 0, f"the RCCL process exited with {p.exitcode}"
     ok, notes = q.get(timeout=10)
     assert ok, notes
+
+
+def test_bench_multi_rank_line_verifies_itself_on_one_gpu():
+    """`python bench.py --gpus 2` end to end — the command the driver launches on a multi-GPU node — with both ranks on this box's one GPU under gloo
+    (SGS_BENCH_SHARE_GPU=1: the only difference to the node is the backend string): the self-launch, the N > 1 code path, the self-check that
+    runs before anything is timed (gathered frames == rank 0's un-sharded renders, bit for bit, through all three exchanges) and the JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SGS_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--gaussians", "300000",
+                        "--no-secondary", "--no-cpu-baseline", "--no-lowres", "--preheat-ms", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["metric_version"] >= 4
+    v = d["verify"]
+    assert v["ok"] and v["frames_checked"] == 7 and v["mismatching_pixels"] == 0 and v["ranks"] == 2
+    assert "fp32 bands" in d["config"]["parallelism"] and d["collective"]["ranks"] == 2
+    assert "[verify]" in p.stderr and "bit-identical" in p.stderr
