@@ -116,18 +116,21 @@ def test_sharded_renderer_on_one_gpu(world, mode):
     assert ok, notes
 
 
-@pytest.mark.parametrize("mode", ["even", "balance", "rgba8-balance"])
-def test_sharded_renderer_on_rccl_when_the_box_has_gpus(mode):
-    """The same check on the backend the 8-GPU node uses: "nccl" = RCCL, one GPU per rank, as many ranks (2..8) as the box has
-    GPUs — the gathered frame bit-identical to the un-sharded one.  RCCL refuses two ranks on one device, so on a 1-GPU box
-    this SKIPS, loudly: the N > 1 RCCL exchange is then only covered by bench.py's own `verify` step on the multi-GPU node."""
+@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "balance"), (2, "rgba8-balance"), (8, "even")])
+def test_sharded_renderer_on_rccl_when_the_box_has_gpus(world, mode):
+    """The same check on the backend the 8-GPU node uses: "nccl" = RCCL, one GPU per rank — two ranks (and, where the box has them, up to eight) —
+    the gathered frame bit-identical to the un-sharded one.  RCCL refuses two ranks on one device, so on a 1-GPU box this SKIPS, loudly: the
+    N > 1 RCCL exchange is then only covered by bench.py's own `verify` step on the multi-GPU node."""
     import torch
     n_dev = torch.cuda.device_count()
     if n_dev < 2:
         pytest.skip(f"RCCL with N > 1 ranks needs N GPUs; this box has {n_dev} — the exchange itself runs here under gloo "
-                    f"(test_sharded_renderer_on_one_gpu) and on RCCL at world size 1 (test_rccl_world_size_one_smoke)")
+                    f"(test_sharded_renderer_on_one_gpu, test_bench_multi_rank_line_verifies_itself_on_one_gpu) and on RCCL at world size 1 "
+                    f"(test_rccl_world_size_one_smoke)")
+    if world > 2 and n_dev < 3:
+        pytest.skip(f"the {world}-rank case needs more than the {n_dev} GPUs of this box")
     import torch.multiprocessing as mp
-    world = min(n_dev, 8)
+    world = min(world, n_dev)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
