@@ -23,15 +23,16 @@ struct WaveRec { unsigned long long c0, c1, w0, w1; unsigned hwid, xcc; };
 
 enum Kind { K_FMA, K_FMA_DEP, K_PK_FMA, K_MUL, K_EXP, K_MED3, K_CMP, K_CNDMASK, K_MAX, K_FMA_SGPR, K_EXP_FMA31, K_RCP,
             K_DS64_BCAST, K_DS64_LANE, K_DS128_BCAST, K_DS32_BCAST, K_DS64_BCAST_FMA4, K_DS64_BCAST_FMA8,
-            K_TRIP, K_TRIP_NOLDS, K_TRIP_LDSONLY, K_TRIP_P, K_TRIP_PF, K_TRIP_PPF, K_TRIP_PK, K_COUNT };
+            K_TRIP, K_TRIP_NOLDS, K_TRIP_LDSONLY, K_TRIP_P, K_TRIP_PF, K_TRIP_PPF, K_TRIP_PK, K_TRIP_MFMA, K_TRIP_MFMA_NOLDS, K_MFMA16, K_COUNT };
 static const char* kind_name[] = {"v_fma_f32", "v_fma_f32 dependent chain", "v_pk_fma_f32", "v_mul_f32", "v_exp_f32", "v_med3_f32", "v_cmp_lt_f32 vcc",
                                   "v_cndmask_b32 vcc", "v_max_f32", "v_fma_f32 sgpr operand", "3 v_fma + 1 v_exp", "v_rcp_f32",
                                   "ds_read_b64 broadcast", "ds_read_b64 per lane", "ds_read_b128 broadcast", "ds_read_b32 broadcast",
                                   "ds_read_b64 bcast + 4 v_fma", "ds_read_b64 bcast + 8 v_fma",
                                   "blend trip (4 splats: 66 VALU + 21 LDS)", "blend trip, splats in VGPRs", "blend trip, LDS reads only",
-                                  "blend trip, prefix-product apply", "blend trip, list entry read a trip ahead", "blend trip, prefix-product + read ahead", "blend trip, (t0,V) and (C0,C1) as v_pk_fma_f32"};
+                                  "blend trip, prefix-product apply", "blend trip, list entry read a trip ahead", "blend trip, prefix-product + read ahead", "blend trip, (t0,V) and (C0,C1) as v_pk_fma_f32",
+                                  "blend trip, U and V on the matrix pipe", "... its arithmetic alone (no LDS)", "v_mfma_f32_16x16x1_4b_f32"};
 // instructions (of the kind the row is about) per trip
-static const int kind_ni[] = {NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, 1, 1, 1, 1, 1, 1, 1};
+static const int kind_ni[] = {NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, NI, 1, 1, 1, 1, 1, 1, 1, 1, 1, NI};
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float* out, const float* in, WaveRec* rec, int iters) {
@@ -45,6 +46,16 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, WaveRec* r
         const float rx = (float)((j * 7) & 15), ry = (float)((j * 11) & 15), a = 0.25f + 0.001f * j, ak = 0.05f, c = 0.3f;
         s_p0[j] = make_float2(a * rx + ak * ry, a); s_p1[j] = make_float2(ak, c * ry); s_p2[j] = make_float2(c, j == SGS_BATCH ? 1.0e30f : 6.0f);
         s_p3[j] = make_float2(0.5f, 0.25f); s_p4[j] = make_float2(0.125f, 3.0f);
+    }
+    if (KIND == K_TRIP_MFMA) {       // the candidate's staged layout over the same arena: uv[j] = (m, -a, -a k | c ry, 0, -c), cn[j] = (r, g, b, nlo)
+        __syncthreads();
+        float* const uv = reinterpret_cast<float*>(s_arena);
+        float4* const cn = reinterpret_cast<float4*>(uv + 6 * (SGS_BATCH + 2));
+        for (int j = tid; j <= SGS_BATCH; j += 256) {
+            const float rx = (float)((j * 7) & 15), ry = (float)((j * 11) & 15), a = 0.25f + 0.001f * j, ak = 0.05f, c = 0.3f;
+            uv[6 * j] = a * rx + ak * ry; uv[6 * j + 1] = -a; uv[6 * j + 2] = -ak; uv[6 * j + 3] = c * ry; uv[6 * j + 4] = 0.f; uv[6 * j + 5] = -c;
+            cn[j] = make_float4(0.5f, 0.25f, 0.125f, j == SGS_BATCH ? 1.0e30f : 6.0f);
+        }
     }
     unsigned* const lst = s_sorted + (unsigned)wave * (SGS_BATCH + 4);
     for (int j = lane; j < SGS_BATCH + 4; j += 64) lst[j] = (unsigned)(j < 64 ? ((j * 4 + wave) & 255) : SGS_BATCH) << 3;
@@ -211,6 +222,63 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, WaveRec* r
                 if (__ballot(Tm > 0.0f) == 0ull) break;
             }
             C0 = C01.x; C1 = C01.y;
+        } else if (KIND == K_TRIP_MFMA || KIND == K_TRIP_MFMA_NOLDS) {
+            // candidate (round 6): the two LINEAR forms of a splat — U = m - a lx - a k ly and V = c ry - c ly — on the matrix pipe.  One
+            // v_mfma_f32_16x16x1_4b_f32 is four 16 x 16 outer products; lane l holds D[block b][row 4 (l / 16) + r][column l % 16] in VGPR 4 b + r,
+            // i.e. 16 items (b, r) for ONE pixel when pixel = (group g = l / 16, column j = l % 16) = lane l of the 8 x 8 quadrant (rows 2 g, 2 g + 1).
+            // Items = 8 splats x {U, V}; three k-steps (B = 1, column, row-in-group) accumulate  const_g + coef_x col + coef_y h  with the group's
+            // row offset folded into the constant by the lane that supplies A (lane 16 b + 4 g' + r: item (b, r) for group g').  Same three
+            // products per form as the fma chain of SGS_ALPHA_F, so the same error class; q = U^2 + (V^2 + nlo) stays on the VALU.
+            // Staged layout of the candidate: uv[j] = (m, -a, -a k | c ry, 0, -c), cn[j] = (r, g, b, nlo).
+            float* const uv = reinterpret_cast<float*>(s_arena);                       // 257 x 6 floats
+            float4* const cn = reinterpret_cast<float4*>(uv + 6 * (SGS_BATCH + 2));    // 257 x 4 floats (16-byte aligned: 6 * 258 * 4 = 6192)
+            Tm = amax;
+            const unsigned bq = (unsigned)lane >> 4, rq = (unsigned)lane & 3u, gq = ((unsigned)lane >> 2) & 3u;
+            const unsigned s_mine = 2u * bq + (rq >> 1), kind = rq & 1u;
+            const float QX = (float)((wave & 1) * 8), gy = (float)((wave >> 1) * 8) + 2.0f * (float)gq;
+            float one = 1.0f, colf = (float)(lane & 7), hf = (float)((lane >> 3) & 1);
+            SGS_PIN_VGPR(one); SGS_PIN_VGPR(colf); SGS_PIN_VGPR(hf);
+            typedef float v16f __attribute__((ext_vector_type(16)));
+            for (unsigned kq = 0; kq < cntq; kq += 8) {
+                float r0, r1, r2;
+                if (KIND == K_TRIP_MFMA) {
+                    const unsigned myo = lst[kq + s_mine] >> 3;                        // my item's splat (per-lane read: 8 distinct addresses)
+                    const float* rec = uv + myo * 6u + kind * 3u;
+                    r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+                } else { r0 = a[0] + (float)kq; r1 = a[1]; r2 = a[2]; }
+                const float c0 = __builtin_fmaf(r2, gy, __builtin_fmaf(r1, QX, r0));
+                v16f acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(c0, one, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(r1, colf, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x1f32(r2, hf, acc, 0, 0, 0);
+                uint4 pa, pb4;
+                if (KIND == K_TRIP_MFMA) { pa = *reinterpret_cast<const uint4*>(lst + kq); pb4 = *reinterpret_cast<const uint4*>(lst + kq + 4); }
+                else { pa = uint4{0u, 0u, 0u, 0u}; pb4 = pa; }
+#define UB_SPLAT_M(OFF, IU)                                                                             \
+                {                                                                                       \
+                    float4 c4;                                                                          \
+                    if (KIND == K_TRIP_MFMA) c4 = SGS_AT(cn, float4, (OFF) << 1);                       \
+                    else c4 = make_float4(a[6], a[7], a[8], a[5] + 6.0f);                               \
+                    const float U = acc[IU], V = acc[(IU) + 1];                                         \
+                    const float q = __builtin_fmaf(U, U, __builtin_fmaf(V, V, c4.w));                   \
+                    const float al = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));  \
+                    float wgt = al * Tm;                                                                \
+                    const float tt = __builtin_fmaf(-wgt, amax, Tm);                                    \
+                    const float lv = SGS_SAT(__builtin_fmaf(tt, big, nt_big));                          \
+                    wgt *= lv; Tm = tt * lv;                                                            \
+                    C0 = __builtin_fmaf(wgt, c4.x, C0); C1 = __builtin_fmaf(wgt, c4.y, C1); C2 = __builtin_fmaf(wgt, c4.z, C2); \
+                }
+                UB_SPLAT_M(pa.x, 0) UB_SPLAT_M(pa.y, 2) UB_SPLAT_M(pa.z, 4) UB_SPLAT_M(pa.w, 6)
+                if (__ballot(Tm > 0.0f) == 0ull) break;
+                UB_SPLAT_M(pb4.x, 8) UB_SPLAT_M(pb4.y, 10) UB_SPLAT_M(pb4.z, 12) UB_SPLAT_M(pb4.w, 14)
+                if (__ballot(Tm > 0.0f) == 0ull) break;
+            }
+        } else if (KIND == K_MFMA16) {
+            typedef float v16f __attribute__((ext_vector_type(16)));
+            v16f acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[i], b, acc, 0, 0, 0);
+            a[0] += acc[0] + acc[5] + acc[10] + acc[15];
         } else if (KIND == K_TRIP_NOLDS) {
             Tm = amax;
             for (unsigned kq = 0; kq < cntq; kq += 4) {
@@ -251,7 +319,7 @@ template <int KIND>
 Result run(int wps, int wgs_per_launch_cu, float* out, const float* in, WaveRec* rec_d, double wall_hz) {
     const int blocks = 256 * wps;
     int iters = ITER;
-    if (KIND >= K_TRIP) iters = ITER / 8;
+    if (KIND >= K_TRIP && KIND != K_MFMA16) iters = ITER / 8;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, in, rec_d, iters);       // warm (clock ramp, code fetch)
     hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, in, rec_d, iters);
@@ -274,7 +342,7 @@ Result run(int wps, int wgs_per_launch_cu, float* out, const float* in, WaveRec*
     std::sort(cyc.begin(), cyc.end());
     Result R; R.cyc_med = (double)cyc[cyc.size() / 2]; R.ghz = sc / sw * wall_hz * 1e-9; R.ms = ms;
     R.wmin = 1 << 30; R.wmax = 0; R.simds = (int)per_simd.size();
-    const double per_wave = (double)iters * (KIND >= K_TRIP ? 16.0 : (double)kind_ni[KIND]);
+    const double per_wave = (double)iters * (KIND >= K_TRIP && KIND != K_MFMA16 ? 16.0 : (double)kind_ni[KIND]);
     std::vector<double> cpi;           // per SIMD: cycles from its first wave's start to its last wave's end / instructions it retired in between
     for (auto& kv : per_simd) {
         R.wmin = std::min(R.wmin, kv.second.n); R.wmax = std::max(R.wmax, kv.second.n);
@@ -304,7 +372,7 @@ int main(int argc, char** argv) {
     printf("# blend-trip rows: cycles per TRIP (4 splats) per SIMD\n");
     const double wall_hz = (double)wall_khz * 1e3;
     runfn fns[] = {run<0>, run<1>, run<2>, run<3>, run<4>, run<5>, run<6>, run<7>, run<8>, run<9>, run<10>, run<11>, run<12>, run<13>, run<14>, run<15>,
-                   run<16>, run<17>, run<18>, run<19>, run<20>, run<21>, run<22>, run<23>, run<24>};
+                   run<16>, run<17>, run<18>, run<19>, run<20>, run<21>, run<22>, run<23>, run<24>, run<25>, run<26>, run<27>};
     static_assert(sizeof(fns) / sizeof(fns[0]) == K_COUNT, "kinds");
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     for (int kind = 0; kind < K_COUNT; ++kind) {

@@ -39,10 +39,12 @@ def look_at_view(eye, target, down=(0, 1, 0)):
     return V.astype(np.float32)
 
 
-def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True):
+def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True, upload=True):
     """Full comparison of one frame: counts and queues bit-exact, splat attributes to fp32 rounding,
-    image within the parity tolerance."""
-    drv.upload(*scene)
+    image within the parity tolerance.  upload=False: `scene` is already the driver's uploaded scene (several poses
+    of a multi-million-Gaussian scene are checked against one upload)."""
+    if upload:
+        drv.upload(*scene)
     # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them
     img, st = drv.render(cam, cfg, rows)
     # ... which counts D_f only on request (the drivers ask for it): the instantiation without the bookkeeping — the one
