@@ -45,7 +45,7 @@
 #define SGS_RADIX_BITS 8
 #define SGS_RADIX (1 << SGS_RADIX_BITS)
 #define SGS_SORT_CLASSES 4
-#define SGS_PROF_WORDS 24            // profiling build: words per tile in the tile_prof buffer
+#define SGS_PROF_WORDS 32            // profiling build: words per tile in the tile_prof buffer
 #define SGS_TIE_RUN_MAX 32          // equal-depth runs longer than this take the (index,depth) resort
 
 #define SGS_PFLAG_SH_PACKED 0x80000000u   // FrameParams.flags, set by the library (never by a caller's sgs_config): the scene's SH rows are packed bytes,
@@ -102,7 +102,8 @@ struct alignas(128) FrameStatus {
     uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
     uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
     uint32_t n_deep;                // windows culled against the tile's live pixels before ranking (k_tile_render, deep tiles)
-    uint32_t pad1_[6];
+    uint32_t n_tail;                // tiles in which a wave blended a list with (pixel, splat) pairs in its lanes (k_tile_render, tail blend)
+    uint32_t pad1_[5];
 };
 static_assert(sizeof(FrameStatus) == 128, "two cache lines");
 

@@ -145,14 +145,14 @@ def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
     for k in range(5):
         V = np.eye(4, dtype=np.float32); V[0, 3] = 0.15 * k - 0.3
         cams.append(onp.Camera(96, 80, 70.0, 70.0, 48.0, 40.0, V))
-    seq = [drv.render(c)[0].copy() for c in cams]
+    seq = [drv.render(c, stats=False)[0].copy() for c in cams]          # (the production instantiation, as the batch runs it)
     outs = [np.full((80, 96, 3), -1.0, np.float32) for _ in cams]
     cfg = lib.default_config()
     cfg.flags = _capi.FLAG_ASYNC | _capi.FLAG_PIPELINED
     for c, o in zip(cams, outs):
         cc = _capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy, np.asarray(c.view, np.float32).reshape(4, 4).tolist())
         lib.check(lib.sgs_render(ctx, drv.scene, C.byref(cc), C.byref(cfg), 0, -1, o.ctypes.data, None, None), ctx)
-    plain = drv.render(cams[2])[0]                       # an ordinary frame while pipelined ones are pending
+    plain = drv.render(cams[2], stats=False)[0]           # an ordinary frame while pipelined ones are pending
     st = _capi.SgsStats()
     lib.check(lib.sgs_frame_sync(ctx, C.byref(st)), ctx)
     assert (plain == seq[2]).all()
@@ -200,7 +200,7 @@ def test_batch_on_a_fresh_context_survives_overflowing_frames():
         cfg = d.lib.default_config()
         d.lib.check(d.lib.sgs_render_batch(d.ctx, d.scene, arr, len(cams), C.byref(cfg), 0, -1, batch.ctypes.data, stats, None), d.ctx)
         for i, c in enumerate(cams):
-            single, st = d.render(c)
+            single, st = d.render(c, stats=False)
             assert st["d_total"] > 1024
             assert (batch[i] == single).all(), f"frame {i} of the batch differs from the frame rendered alone"
             assert stats[i].d_total == st["d_total"] and stats[i].n_visible == st["n_visible"]
