@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define SGS_VERSION 112            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
-                                    * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points; 111: sgs_stats grew n_deep_windows, sgs_compressed_scene.reserved_ became sh_decode; 112: sgs_stats grew n_tail_tiles, SGS_FLAG_NO_TAIL / _NO_DEEP, SGS_BUF_TILE_FLAGS,
+                                    * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points; 111: sgs_stats grew n_deep_windows, sgs_compressed_scene.reserved_ became sh_decode; 112: SGS_FLAG_NO_DEEP; sgs_set_tuning,
                                     * SGS_BUF_SCENE_SH): a caller compiled against
                                     * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
                                     * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
@@ -61,12 +61,6 @@ enum {
     SGS_FLAG_NO_CHUNK_CULL = 1u << 6, /* tests: project every chunk of the scene (the production path first tests each
                                     * 64-Gaussian chunk's bounding sphere against the frame / the band of tile rows and skips
                                     * the chunks that cannot reach it).  N_v, D, queues and frames must not change */
-    SGS_FLAG_NO_TAIL = 1u << 7,    /* tests, A/B: never TAIL-BLEND.  A wave of the composite whose 8x8 quadrant has at most 8 live pixels left puts
-                                    * (pixel, splat) pairs in its lanes and forms the transmittance in front of 16 splats at a time as a prefix
-                                    * product — ~4x fewer instructions on the serial tail of a frame, and products
-                                    * associated differently from S6's sequential chain: such tiles (sgs_stats.n_tail_tiles, SGS_BUF_TILE_FLAGS)
-                                    * equal the frame rendered with this flag to rounding (~1e-7 relative), every other tile bit for bit.
-                                    * SGS_FLAG_STATS, _FULL_SORT and _LOOSE_CULL imply it */
     SGS_FLAG_NO_DEEP = 1u << 8,    /* tests, A/B: never cull a resident window of a long-lived tile against its live pixels before ranking it
                                     * (DESIGN.md §4.2 item 8).  Frames must not change, bit for bit */
     SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
@@ -140,8 +134,6 @@ typedef struct sgs_stats {
     int64_t d_super;       /* D_s: records in the super-tile queues (level 1 of the binning) */
     int64_t n_deep_windows; /* windows of tile queues that the composite culled against the tile's live pixels BEFORE ranking / staging (tiles that
                             * kept consuming batches; never with SGS_FLAG_STATS) — version 111 */
-    int64_t n_tail_tiles;  /* tiles in which at least one wave tail-blended a list (SGS_FLAG_NO_TAIL): the tiles of this frame that may differ
-                            * from the sequential chain in the last bits — version 112 */
 } sgs_stats;
 
 int sgs_version(void);
@@ -258,8 +250,6 @@ enum {
     SGS_BUF_SPLATS       = 3,      /* S x 12 words: x,y,conic a,b | c,opacity,r,g | b,depth bits,rect01,rect23 (dead = 0) */
     SGS_BUF_SCENE_GEOM   = 5,      /* float[N][11] of the LAST RENDERED scene as the device holds it, by original index: mean xyz, opacity, scale xyz,
                                     * quaternion wxyz (as uploaded / as dequantised from a compressed payload) */
-    SGS_BUF_TILE_FLAGS   = 7,      /* uint8[T]  per tile of the frame (row-major; tiles outside the rendered band: 0): bit 0 = a wave of the tile's
-                                    * workgroup tail-blended at least one list (see SGS_FLAG_NO_TAIL) — version 112 */
     SGS_BUF_SCENE_SH     = 6       /* float[N][3 (d+1)^2] of the LAST RENDERED scene, by original index, [coefficient][channel]: the SH coefficients the
                                     * projection kernel evaluates — the fp32 rows as uploaded, or (a scene uploaded from the compressed payload, which
                                     * keeps its 8-bit coefficients as bytes in HBM) those bytes dequantised exactly as the kernel does */

@@ -516,7 +516,6 @@ void collect(sgs_ctx* ctx, int slot, sgs_stats* stats, int64_t n, int ntiles, in
     stats->max_tile_len = (int32_t)s.max_tile_len;
     stats->n_spill_tiles = (int32_t)s.class_count[3];
     stats->n_deep_windows = (int64_t)s.n_deep;
-    stats->n_tail_tiles = (int64_t)s.n_tail;
     stats->retries = ctx->last_retries;
     // Algorithmic bytes per stage — DESIGN.md §4 (what the stage must move, not what it happens to).
     const int64_t nv = s.n_visible, D = s.d_total, Df = (int64_t)s.d_fetched;
@@ -1068,7 +1067,6 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         case SGS_BUF_CHUNK_SKIPPED: have = n_chunks; break;
         case SGS_BUF_SCENE_GEOM: have = ctx->last_scene ? ctx->last_n * 11 * 4 : 0; break;
         case SGS_BUF_SCENE_SH: have = ctx->last_scene ? ctx->last_n * 3 * (ctx->last_scene->sh_degree + 1) * (ctx->last_scene->sh_degree + 1) * 4 : 0; break;
-        case SGS_BUF_TILE_FLAGS: have = (int64_t)ctx->last_T; break;
         case 100: src = L.tile_prof; have = (int64_t)ctx->last_T * 8 * SGS_PROF_WORDS; break;    // profiling build only
         case 101: src = L.bin_prof; have = (int64_t)SGS_BIN_BLOCKS * 64; break;  // profiling build only
         default: SGS_FAIL(ctx, SGS_ERR_INVALID, "unknown buffer id %d", what);
@@ -1087,15 +1085,6 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
         for (int64_t i = 0; (i + 1) * 4 <= n; ++i)
             ((unsigned*)host_dst)[i] = i < ctx->last_t_lo ? 0u : i >= ctx->last_t_hi ? total : tmp[(size_t)i];
         free(tmp);
-    }
-    if (what == SGS_BUF_TILE_FLAGS) {
-        // the flags ride in word 3 of the render-order entries (tile, first record, length, flags) of the band the frame rendered
-        const size_t cnt = (size_t)(ctx->last_t_hi - ctx->last_t_lo);
-        std::vector<uint4> order(cnt);
-        if (cnt) SGS_HIP(ctx, hipMemcpy(order.data(), L.tile_order, cnt * sizeof(uint4), hipMemcpyDeviceToHost));
-        memset(host_dst, 0, (size_t)n);
-        if (!s.overflow)
-            for (const uint4& e : order) if ((int64_t)e.x < n) ((uint8_t*)host_dst)[e.x] = (uint8_t)(e.w & 0xffu);
     }
     if (what == SGS_BUF_SCENE_GEOM) {
         std::vector<float4> rows((size_t)n_slots * SGS_GEOM_ROWS);

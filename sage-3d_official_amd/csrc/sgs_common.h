@@ -102,8 +102,7 @@ struct alignas(128) FrameStatus {
     uint32_t class_count[SGS_SORT_CLASSES];   // [3]: oversized depth buckets sorted through HBM; others unused
     uint32_t n_resort_tiles;        // tiles that needed the (index, depth) resort for long tie runs
     uint32_t n_deep;                // windows culled against the tile's live pixels before ranking (k_tile_render, deep tiles)
-    uint32_t n_tail;                // tiles in which a wave blended a list with (pixel, splat) pairs in its lanes (k_tile_render, tail blend)
-    uint32_t pad1_[5];
+    uint32_t pad1_[6];
 };
 static_assert(sizeof(FrameStatus) == 128, "two cache lines");
 

@@ -1670,15 +1670,16 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
     }
 #define SGS_PROF_STAGED_ALL() atomicAdd(&s_pe[4], 1u);
 #define SGS_PROF_STAGED(qb) if ((qb) != 0u) atomicAdd(&s_pe[5], 1u);
-// a wave's list of a batch, by the number of its live pixels: splats listed, per class 1-4 / 5-8 / 9-16 / 17-32 / 33-64; cycles of the two kinds of blend
+// a wave's list of a batch, by the number of its live pixels: splats listed, per class 1-4 / 5-8 / 9-16 / 17-32 / 33-64 (r06c: 89-97 % of them are listed
+// by waves with more than 8 live pixels — why the tail blend of round 6 bought nothing); cycles of the trip loops
 #define SGS_PROF_LIST(NL, CQ) { const unsigned nl_ = (NL); pw_hist[nl_ <= 4u ? 0 : nl_ <= 8u ? 1 : nl_ <= 16u ? 2 : nl_ <= 32u ? 3 : 4] += (CQ); pw_t0 = clock64(); }
-#define SGS_PROF_LIST_END(TAIL) { const unsigned long long d_ = clock64() - pw_t0; if (TAIL) { pw_tail_cyc += d_; ++pw_tail_n; } else pw_list_cyc += d_; }
+#define SGS_PROF_LIST_END() { pw_list_cyc += clock64() - pw_t0; }
 #else
 #define SGS_PROF_EVAL(valid, J)
 #define SGS_PROF_STAGED_ALL()
 #define SGS_PROF_STAGED(qb)
 #define SGS_PROF_LIST(NL, CQ)
-#define SGS_PROF_LIST_END(TAIL)
+#define SGS_PROF_LIST_END()
 #endif
 #define SGS_AT(arr, T_, off) (*reinterpret_cast<const T_*>(reinterpret_cast<const char*>(arr) + (off)))
 #define SGS_NEXT(OV)                                                                                   \
@@ -1785,15 +1786,9 @@ __device__ __forceinline__ void rank_sort(const unsigned long long* kk, unsigned
         if (lane < 4) lst[cntq + (unsigned)lane] = (unsigned)(SGS_BATCH << 3);         /* inert tail */ \
         wave_lds_sync();                                                                               \
         bool wave_done = false;                                                                        \
-        const unsigned long long lm_ = __ballot(Tm > 0.0f);                                            \
-        SGS_PROF_LIST((unsigned)__popcll(lm_), cntq)                                                   \
-        if (tail_ok && !hyper && cntq >= SGS_TAIL_MIN && (unsigned)__popcll(lm_) <= SGS_TAIL_LIVE) {   \
-            /* a handful of live pixels: (pixel, splat) pairs in the lanes (tail_blend above) */       \
-            tail_blend<AUX, TF>(s_p0, s_p1, s_p2, s_p3, s_p4, lst, cntq, reinterpret_cast<float*>(s_skey) + wave * SGS_TAIL_SCRATCH, \
-                                lm_, lane, lx, ly, amax, big, cq_big, nt_big, Tm, C0, C1, C2, Dz, Wsum); \
-            tail_used = true;                                                                          \
-            SGS_PROF_LIST_END(true)                                                                    \
-        } else { if (!hyper) { SGS_LIST_LOOP(SGS_ALPHA_F) } else { SGS_LIST_LOOP(SGS_ALPHA_X) } SGS_PROF_LIST_END(false) } \
+        SGS_PROF_LIST((unsigned)__popcll(__ballot(Tm > 0.0f)), cntq)                                   \
+        if (!hyper) { SGS_LIST_LOOP(SGS_ALPHA_F) } else { SGS_LIST_LOOP(SGS_ALPHA_X) }                 \
+        SGS_PROF_LIST_END()                                                                            \
         (void)wave_done;                                                                               \
         if (STATS) used = Tm > 0.0f ? base + m : used;                                                 \
     }
@@ -1880,110 +1875,7 @@ __device__ __forceinline__ float4 sgs_live_rect(unsigned long long m, float x0, 
     return make_float4(x0 + (float)ca, x0 + (float)cb, y0 + (float)ra, y0 + (float)rb);
 }
 
-// ---- the TAIL blend: (pixel, splat) pairs in the lanes --------------------------------------------------------------------
-// A wave whose quadrant has a handful of live pixels left still evaluates every splat of its list on all 64 lanes, four
-// splats per trip — and at the end of a frame (or all through a 320x240 frame, where one such tile IS the kernel's duration:
-// 7 448 evaluations of one wave alone on its SIMD at 7.3 cycles per instruction, r05f) nothing else runs beside it.  With at
-// most 8 live pixels the wave instead puts a pixel in every 16-lane ROW and 16 splats of the list across the row's lanes:
-//   * every lane evaluates ITS splat's alpha at its row's pixel (the same five fmas, exponential and cut-off as SGS_ALPHA_F);
-//   * the transmittance in front of each splat is the row's running product of (1 - alpha): an inclusive DPP scan (row_shr
-//     1, 2, 4, 8 with the identity as `old`), shifted by one for the exclusive form;  T (1 - alpha_1) .. (1 - alpha_i) < t_min
-//     ends the pixel at splat i as S6 says — the flags are made prefix-closed (a scan's lanes associate their products
-//     differently, so two neighbours may disagree by an ulp about which of them is smaller);
-//   * every lane keeps partial colour sums w c over the passes; they are added up across the row once, at the end;
-//   * the row's last lane hands T to the next pass (ds_bpermute).
-// 16 splats cost ~35 instructions (twice that with 5-8 live pixels: rows 0-3 take pixels 0-3, then 4-7) instead of 4 trips
-// of 66.  The products are associated differently from the sequential chain, so T and the colours differ from it in the
-// last bits (1e-7 relative): frames with tail-blended tiles equal the frames of the test hooks (STATS, FULL_SORT, LOOSE_CULL
-// and SGS_FLAG_NO_TAIL never take this path) to rounding, not bit for bit — sgs_stats.n_tail_tiles counts them and
-// SGS_BUF_TILE_FLAGS names them; every other tile is bit-identical.  The result is still a function of the tile's queue
-// alone (the depth range every partition is cut from is that of the whole queue), so frames are reproducible and a band of
-// tile rows renders its tiles exactly as the full frame does.
 #define SGS_BATCH 256                 // splats staged per batch (k_tile_render)
-#ifndef SGS_TAIL_LIVE
-#define SGS_TAIL_LIVE 8u              // live pixels of a wave's quadrant at or below which its list is tail-blended
-#endif
-#ifndef SGS_TAIL_MIN
-#define SGS_TAIL_MIN 12u              // ... if the list holds at least this many splats (shorter: the set-up costs more than three trips)
-#endif
-#define SGS_TAIL_SCRATCH 80           // floats of per-wave LDS scratch: [8][4] pixel in (lx, ly, Tm, -), [8][6] pixel out
-#define SGS_ROW_SHR(OLD, X, CTRL) __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(OLD), (int)__float_as_uint(X), CTRL, 0xf, 0xf, false))
-// inclusive scans over the 16 lanes of a DPP row (lanes without a source keep the identity)
-#define SGS_ROW_SCAN_MUL(X) { X *= SGS_ROW_SHR(1.0f, X, 0x111); X *= SGS_ROW_SHR(1.0f, X, 0x112); X *= SGS_ROW_SHR(1.0f, X, 0x114); X *= SGS_ROW_SHR(1.0f, X, 0x118); }
-#define SGS_ROW_SCAN_ADD(X) { X += SGS_ROW_SHR(0.0f, X, 0x111); X += SGS_ROW_SHR(0.0f, X, 0x112); X += SGS_ROW_SHR(0.0f, X, 0x114); X += SGS_ROW_SHR(0.0f, X, 0x118); }
-// one pixel (PX, PY, its alpha_max T in TT) against the 16 splats of the pass; ACC* = this lane's partial sums for that pixel
-#define SGS_TAIL_EVAL(PX, PY, TT, ACC0, ACC1, ACC2, ACCD, ACCW)                                        \
-    {                                                                                                  \
-        const float U = __builtin_fmaf(-n1.x, PY, __builtin_fmaf(-n0.y, PX, n0.x));                    \
-        const float V = __builtin_fmaf(-n2.x, PY, n1.y);                                               \
-        const float q = __builtin_fmaf(U, U, __builtin_fmaf(V, V, n2.y));                              \
-        const float al = SGS_SAT(SGS_EXP2(-q)) * SGS_SAT(__builtin_fmaf(-q, big, cq_big));   /* alpha / alpha_max, 0 outside the cut-off */ \
-        float x = __builtin_fmaf(-al, amax, 1.0f);                                           /* 1 - alpha */ \
-        SGS_ROW_SCAN_MUL(x)                                                                  /* (1 - alpha_first) .. (1 - alpha_mine) */ \
-        const float xe = SGS_ROW_SHR(1.0f, x, 0x111);                                        /* ... up to the splat in front of mine */ \
-        const float Tbef = TT * xe, Taft = TT * x;                                                     \
-        float lv = SGS_SAT(__builtin_fmaf(Taft, big, nt_big));                               /* 0: the pixel ends at my splat (or ended before) */ \
-        if (__ballot(lv > SGS_ROW_SHR(1.0f, lv, 0x111)) != 0ull) {                           /* (an ulp-sized inversion between neighbours) */ \
-            lv *= SGS_ROW_SHR(1.0f, lv, 0x111); lv *= SGS_ROW_SHR(1.0f, lv, 0x112); lv *= SGS_ROW_SHR(1.0f, lv, 0x114); lv *= SGS_ROW_SHR(1.0f, lv, 0x118); \
-        }                                                                                              \
-        const float w = al * Tbef * lv;                                                                \
-        ACC0 = __builtin_fmaf(w, n3.x, ACC0); ACC1 = __builtin_fmaf(w, n3.y, ACC1); ACC2 = __builtin_fmaf(w, n4.x, ACC2); \
-        if (AUX) ACCD = __builtin_fmaf(w, n4.y, ACCD);                                                 \
-        if (TF) ACCW += w;                                                                             \
-        TT = __shfl(Taft * lv, lane | 15);                                                   /* the row's last lane: T behind the pass, 0 if it ended */ \
-    }
-#ifndef SGS_TAIL_FN
-#define SGS_TAIL_FN __attribute__((noinline))     // (its own register allocation: inlined, its live values cost the composite's common path 4 spilled VGPRs)
-#endif
-template <bool AUX, bool TF>
-__device__ SGS_TAIL_FN void tail_blend(const float2* s_p0, const float2* s_p1, const float2* s_p2, const float2* s_p3, const float2* s_p4,
-                                           const unsigned* lst, const unsigned cntq, float* scr, const unsigned long long live_m, const int lane,
-                                           const float lx, const float ly, const float amax, const float big, const float cq_big, const float nt_big,
-                                           float& Tm, float& C0, float& C1, float& C2, float& Dz, float& Wsum) {
-    float* const pin = scr; float* const pout = scr + 32;
-    const bool two = __popcll(live_m) > 4;                  // (uniform) rows 0-3 take pixels 0-3, and in a second evaluation pixels 4-7
-    if (lane < 8) *reinterpret_cast<float4*>(pin + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);        // slots without a pixel: T = 0, inert
-    wave_lds_sync();
-    const bool live = (live_m >> lane) & 1ull;
-    const unsigned slot = lanes_below(live_m);
-    if (live) *reinterpret_cast<float4*>(pin + 4 * slot) = make_float4(lx, ly, Tm, 0.f);
-    wave_lds_sync();
-    const unsigned row = (unsigned)lane >> 4, sl = (unsigned)lane & 15u;
-    const float4 pa = *reinterpret_cast<const float4*>(pin + 4 * row), pb = *reinterpret_cast<const float4*>(pin + 4 * (row + 4u));
-    float Ta = pa.z, Tb = pb.z;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f, b4 = 0.f;
-    for (unsigned k = 0; k < cntq; k += 16u) {
-        const unsigned idx = k + sl;
-        const unsigned off = idx < cntq ? lst[idx] : (unsigned)(SGS_BATCH << 3);        // (past the list: the inert dummy splat)
-        const float2 n0 = SGS_AT(s_p0, float2, off), n1 = SGS_AT(s_p1, float2, off), n2 = SGS_AT(s_p2, float2, off),
-                     n3 = SGS_AT(s_p3, float2, off), n4 = SGS_AT(s_p4, float2, off);
-        SGS_TAIL_EVAL(pa.x, pa.y, Ta, a0, a1, a2, a3, a4)
-        if (two) SGS_TAIL_EVAL(pb.x, pb.y, Tb, b0, b1, b2, b3, b4)
-        if (__ballot(Ta > 0.0f || Tb > 0.0f) == 0ull) break;
-    }
-    // the rows' sums (lane 15 of a row ends up with the row's total) -> the pixels that own them
-    SGS_ROW_SCAN_ADD(a0) SGS_ROW_SCAN_ADD(a1) SGS_ROW_SCAN_ADD(a2)
-    if (AUX) SGS_ROW_SCAN_ADD(a3)
-    if (TF) SGS_ROW_SCAN_ADD(a4)
-    if (two) {
-        SGS_ROW_SCAN_ADD(b0) SGS_ROW_SCAN_ADD(b1) SGS_ROW_SCAN_ADD(b2)
-        if (AUX) SGS_ROW_SCAN_ADD(b3)
-        if (TF) SGS_ROW_SCAN_ADD(b4)
-    }
-    if (sl == 15u) {
-        float* o = pout + 6 * row;
-        o[0] = Ta; o[1] = a0; o[2] = a1; o[3] = a2; o[4] = a3; o[5] = a4;
-        if (two) { o += 24; o[0] = Tb; o[1] = b0; o[2] = b1; o[3] = b2; o[4] = b3; o[5] = b4; }
-    }
-    wave_lds_sync();
-    if (live) {
-        const float* o = pout + 6 * slot;
-        Tm = o[0]; C0 += o[1]; C1 += o[2]; C2 += o[3];
-        if (AUX) Dz += o[4];
-        if (TF) Wsum += o[5];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // S5 + S6 fused: per-tile LAZY depth sort feeding the front-to-back composite.  One workgroup per 16x16 tile,
 // one lane per pixel, each of the four waves owns an 8x8 quadrant.
@@ -2098,7 +1990,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     const unsigned long long prt0 = wall_clock64();      // 100 MHz, common to all XCDs
     __shared__ unsigned s_pe[8];
     __shared__ unsigned long long s_pw[8];
-    unsigned pw_hist[5] = {0u, 0u, 0u, 0u, 0u}, pw_tail_n = 0; unsigned long long pw_t0 = 0, pw_tail_cyc = 0, pw_list_cyc = 0;
+    unsigned pw_hist[5] = {0u, 0u, 0u, 0u, 0u}; unsigned long long pw_t0 = 0, pw_list_cyc = 0;
     if (threadIdx.x < 8) { s_pe[threadIdx.x] = 0; s_pw[threadIdx.x] = 0ull; }
 #define SGS_PROF_MARK(acc) do { unsigned long long now_ = clock64(); acc += now_ - ptm; ptm = now_; } while (0)
 #else
@@ -2132,12 +2024,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     SGS_PIN_VGPR(cq_big); SGS_PIN_VGPR(nt_big);
     const bool full_sort = (P.flags & 8u) != 0u;       // SGS_FLAG_FULL_SORT (tests): order the whole queue
     const bool loose_cull = (P.flags & 32u) != 0u;     // SGS_FLAG_LOOSE_CULL (tests): extent-only quadrant test
-    // the tail blend (above) re-associates a pixel's products: never in the instantiation that counts D_f, under the test hooks, or with
-    // SGS_FLAG_NO_TAIL — the frames of all of those are one sequential fma chain per pixel and equal each other bit for bit
-    const bool tail_ok = !STATS && !full_sort && !loose_cull && (P.flags & 128u) == 0u;
     const bool deep_ok = (P.flags & 256u) == 0u;      // SGS_FLAG_NO_DEEP (tests, A/B): never cull a window against the live pixels
-    bool tail_used = false;                           // (uniform per wave)
-    static_assert(4 * SGS_TAIL_SCRATCH * sizeof(float) <= (SGS_BATCH + 8) * sizeof(unsigned long long), "the tail blend's scratch lives in s_skey");
 
     const unsigned beg = job.y, n = job.z;            // the tile's 8 per-XCD sub-queues are adjacent: one queue
     float Tm = inside ? amax : 0.0f;     // alpha_max x transmittance; 0 = finished (or outside the image): takes nothing more
@@ -2260,11 +2147,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
             if (tid < 8) s_q[SGS_GROUP + tid] = ~0ull;
         } else {
             s_bcnt[tid] = 0;
-            {   // the depth range of the queue — of ALL its records, also when it is longer than the LDS holds (one more coalesced pass over
-                // it): the buckets, hence the groups, the batches and every list a wave blends are then a function of the queue's CONTENT,
-                // not of the order the binning happened to write it in.  (Rounds 3-5 cut a long queue's buckets from its first 1024 records,
-                // widened by half: any grouping gives the same frame while every pixel is one sequential fma chain; the tail blend below
-                // re-associates products inside a list, and a frame must not depend on which records came first.)
+            {   // the depth range of the records held (all of them, or the sample of a long queue: widened by half on both sides)
                 unsigned kmn = 0xffffffffu, kmx = 0u;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -2272,20 +2155,6 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                         const unsigned key = (unsigned)(rq[r] >> 32);
                         kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
                     }
-                for (unsigned i0 = 1024u; i0 < n; i0 += 256u * SGS_PASS_R) {             // (long queues only)
-                    unsigned long long x[SGS_PASS_R];
-#pragma unroll
-                    for (int r = 0; r < SGS_PASS_R; ++r) {
-                        const unsigned i = i0 + (unsigned)tid + 256u * (unsigned)r;
-                        x[r] = i < n ? rec[beg + i] : ~0ull;
-                    }
-#pragma unroll
-                    for (int r = 0; r < SGS_PASS_R; ++r)
-                        if (i0 + (unsigned)tid + 256u * (unsigned)r < n) {
-                            const unsigned key = (unsigned)(x[r] >> 32);
-                            kmn = key < kmn ? key : kmn; kmx = key > kmx ? key : kmx;
-                        }
-                }
                 kmn = wave_min(kmn); kmx = wave_max(kmx);
                 if (lane == 0) { s_kmn[wave] = kmn; s_kmx[wave] = kmx; }
             }
@@ -2294,6 +2163,10 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
                 unsigned kmn = s_kmn[0], kmx = s_kmx[0];
 #pragma unroll
                 for (int w = 1; w < 4; ++w) { kmn = s_kmn[w] < kmn ? s_kmn[w] : kmn; kmx = s_kmx[w] > kmx ? s_kmx[w] : kmx; }
+                if (!in_lds) {
+                    const unsigned half = (kmx - kmn) >> 1;
+                    kmn = kmn > half ? kmn - half : 0u; kmx = kmx < 0xffffffffu - half ? kmx + half : 0xffffffffu;
+                }
                 const unsigned span = kmx - kmn;                                  // (span >> ksh) < SGS_NB
                 klo = kmn; ksh = span < (unsigned)SGS_NB ? 0u : 24u - (unsigned)__clz((int)span);
             }
@@ -2760,7 +2633,7 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
 #ifdef SGS_TILE_PROF
     if (lane == 0) {
         for (int k_ = 0; k_ < 5; ++k_) atomicAdd(&s_pw[k_], (unsigned long long)pw_hist[k_]);
-        atomicAdd(&s_pw[5], (unsigned long long)pw_tail_n); atomicAdd(&s_pw[6], pw_tail_cyc); atomicAdd(&s_pw[7], pw_list_cyc);
+        atomicAdd(&s_pw[7], pw_list_cyc);
     }
     if (lane == 0) { atomicAdd(&s_pe[0], pe_eval); atomicAdd(&s_pe[1], pe_empty); atomicAdd(&s_pe[2], pe_valid); atomicAdd(&s_pe[3], pe_useful); atomicAdd(&s_pe[6], pe_dead); atomicAdd(&s_pe[7], pe_few); }
     __syncthreads();
@@ -2773,9 +2646,6 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
         o[20] = pt_rec; o[21] = n_refine | (pn_deep_try << 16) | (pn_deep_ok << 32); o[22] = n_fill | (pn_deep_surv << 16); o[23] = (unsigned long long)s_pe[6] | ((unsigned long long)s_pe[7] << 32);
     }
 #endif
-    if (tail_used && lane == 0) {        // the tile's render-order entry carries the flag (SGS_BUF_TILE_FLAGS); the first wave to set it counts the tile
-        if (atomicOr(&S.tile_order[bx].w, 1u) == 0u) atomicAdd(&st->n_tail, 1u);
-    }
     {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)
         int tid_out = tid_entry; SGS_PIN_VGPR(tid_out);
         const unsigned lane_o = (unsigned)tid_out & 63u, wave_o = (unsigned)tid_out >> 6;

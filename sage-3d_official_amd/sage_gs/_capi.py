@@ -15,9 +15,9 @@ NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
 FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL, FLAG_NO_CHUNK_CULL = 1, 2, 4, 8, 16, 32, 64
-FLAG_NO_TAIL, FLAG_NO_DEEP = 128, 256
+FLAG_NO_DEEP = 256
 BACKEND_CPU, BACKEND_HIP = 0, 1
-BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM, BUF_SCENE_SH, BUF_TILE_FLAGS = 0, 1, 2, 3, 4, 5, 6, 7
+BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM, BUF_SCENE_SH = 0, 1, 2, 3, 4, 5, 6
 
 ERR_NAMES = {-1: "SGS_ERR_INVALID", -2: "SGS_ERR_HIP", -3: "SGS_ERR_OOM", -4: "SGS_ERR_OVERFLOW",
              -5: "SGS_ERR_BACKEND"}
@@ -59,7 +59,7 @@ class SgsStats(C.Structure):
                 ("d_fetched", C.c_int64), ("n_pixels", C.c_int64), ("n_tiles", C.c_int32),
                 ("max_tile_len", C.c_int32), ("n_spill_tiles", C.c_int32), ("retries", C.c_int32),
                 ("ms", C.c_float * NUM_STAGES), ("ms_total", C.c_float),
-                ("bytes", C.c_int64 * NUM_STAGES), ("d_super", C.c_int64), ("n_deep_windows", C.c_int64), ("n_tail_tiles", C.c_int64)]
+                ("bytes", C.c_int64 * NUM_STAGES), ("d_super", C.c_int64), ("n_deep_windows", C.c_int64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("ms", "bytes")}

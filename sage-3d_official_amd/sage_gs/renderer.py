@@ -272,7 +272,7 @@ class Renderer:
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
                return_aux=False, pipelined=False, loose_cull=False, interleave=None, chunk_cull=True, stats=False,
-               tail_blend=True, deep_cull=True):
+               deep_cull=True):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
 
         stats=True also counts D_f (records consumed by the composite; SGS_FLAG_STATS) — bookkeeping that costs a sweep ~4 %,
@@ -289,8 +289,8 @@ class Renderer:
         shard one frame over `stride` GPUs) into `out_band`, a COMPACT [>= 16 * owned rows, W, 3] image: owned row k
         (frame tile row k*stride + phase) is stored at pixel rows [16k, 16k+16).  tile_rows then indexes owned rows.
 
-        tail_blend=False / deep_cull=False (tests, A/B): SGS_FLAG_NO_TAIL / SGS_FLAG_NO_DEEP — every pixel one sequential fma
-        chain; last_stats["n_tail_tiles"] and tile_flags() say which tiles of a production frame were tail-blended."""
+        deep_cull=False (tests, A/B): SGS_FLAG_NO_DEEP — no window of a long-lived tile is culled against its live pixels before it is
+        ranked; the frame must not change."""
         scene = self._scene_of(gaussians)
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
         stride, phase = (1, 0) if interleave is None else (int(interleave[0]), int(interleave[1]))
@@ -330,7 +330,7 @@ class Renderer:
                 (_capi.FLAG_FULL_SORT if full_sort else 0) | \
                 (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
                 (0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL) | (_capi.FLAG_STATS if stats else 0) | \
-                (0 if tail_blend else _capi.FLAG_NO_TAIL) | (0 if deep_cull else _capi.FLAG_NO_DEEP) | \
+                (0 if deep_cull else _capi.FLAG_NO_DEEP) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
@@ -493,11 +493,6 @@ class Renderer:
         splats = self.debug_buffer(_capi.BUF_SPLATS, np.uint32).reshape(-1, 12)
         live = ids != 0xFFFFFFFF
         return off, ids[slots].astype(np.int64), ids[live].astype(np.int64), splats[live]
-
-    def tile_flags(self) -> np.ndarray:
-        """uint8 per tile of the LAST completed frame (row-major): bit 0 = a wave of the tile tail-blended a list (SGS_BUF_TILE_FLAGS):
-        the tiles whose pixels may differ in the last bits from the frame rendered with tail_blend=False."""
-        return self.debug_buffer(_capi.BUF_TILE_FLAGS, np.uint8)
 
     def set_record_capacity(self, n: int):
         self._lib.check(self._lib.sgs_set_record_capacity(self._ctx, int(n)), self._ctx)

@@ -16,7 +16,7 @@ TOT = {'ev': 0.0, 'val': 0.0, 'use': 0.0, 'stg': 0.0, 'hit': 0.0}
 for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')]:
     r.render(cams[ci], gs, stats=True); d_f = r.last_stats["d_fetched"]      # (D_f is counted on request only)
     for _ in range(3):
-        r.render(cams[ci], gs, timing=True, tail_blend=os.environ.get('TAIL', '1') != '0', deep_cull=os.environ.get('DEEP', '1') != '0')      # the kernels a sweep runs
+        r.render(cams[ci], gs, timing=True, deep_cull=os.environ.get('DEEP', '1') != '0')      # the kernels a sweep runs
     st = dict(r.last_stats); st["d_fetched"] = d_f
     p = r.debug_buffer(100, np.uint64).reshape(-1, 32).astype(np.float64)
     n, part, sort, blend, ng, nb, tot, t0, ev, emp, val, use, stg, hit, rt0, rt1, prank, pbar1, pstage, pjob, prec = p.T[:21]
@@ -46,12 +46,12 @@ for ci in [int(v) for v in os.environ.get('POSES', '5,20,70,140,200').split(',')
     print(f"     single-batch path, cycle sums: rank (records resident -> ranked) {prank.sum()/1e6:.0f}M, barrier 1 {pbar1.sum()/1e6:.0f}M, stage (gather wait + extents + quadrant test) {pstage.sum()/1e6:.0f}M, barrier 2 {sort.sum()/1e6:.0f}M; partition {part.sum()/1e6:.0f}M; blend {blend.sum()/1e6:.0f}M; total {tot.sum()/1e6:.0f}M")
     print(f"     start of a tile, mean cycles: entry -> job arrived {pjob.mean():.0f}, -> records arrived {prec.mean():.0f}, -> partitioned {part.mean():.0f}  (p90: {np.quantile(pjob,0.9):.0f}, {np.quantile(prec,0.9):.0f}, {np.quantile(part,0.9):.0f})")
     print(f"     deep-tile culls: attempted {int(dtry.sum())} (tiles {int((dtry > 0).sum())}), taken {int(dok.sum())}, survivors per taken window {dsurv.sum() / max(1.0, dok.sum()):.0f}; cull cycles {pbar1.sum()/1e6:.1f}M")
-    h = praw[:, 24:29].astype(np.float64); tn, tcyc, lcyc = praw[:, 29].astype(np.float64), praw[:, 30].astype(np.float64), praw[:, 31].astype(np.float64)
+    h = praw[:, 24:29].astype(np.float64); lcyc = praw[:, 31].astype(np.float64)
     print(f"     listed splats (wave x batch lists) by live pixels of the wave: 1-4 {h[:,0].sum()/1e3:.0f}k  5-8 {h[:,1].sum()/1e3:.0f}k  9-16 {h[:,2].sum()/1e3:.0f}k  17-32 {h[:,3].sum()/1e3:.0f}k  33-64 {h[:,4].sum()/1e3:.0f}k | "
-          f"tail blends {int(tn.sum())}, wave-cycles in them {tcyc.sum()/1e6:.1f}M, in the trip loops {lcyc.sum()/1e6:.1f}M")
+          f"wave-cycles in the trip loops {lcyc.sum()/1e6:.1f}M")
     order = np.argsort(-tot)[:8]
     for o in order:
-        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} (no live pixel {int(dead[o])}, 1-2 {int(few[o])}) refinements {int(nref[o])} window fills {int(nfill[o])} deep {int(dok[o])}/{int(dtry[o])} surv {int(dsurv[o])} cull {pbar1[o]/1e3:.0f}k | listed by live px {[int(v) for v in h[o]]} tail {int(tn[o])} ({tcyc[o]/1e3:.0f}k cyc) trips {lcyc[o]/1e3:.0f}k cyc")
+        print(f"     tile {o}: n={int(n[o])} part {part[o]/1e3:.0f}k sort {sort[o]/1e3:.0f}k blend {blend[o]/1e3:.0f}k groups {int(ng[o])} batches {int(nb[o])} | rank {prank[o]/1e3:.0f}k stage {pstage[o]/1e3:.0f}k total {tot[o]/1e3:.0f}k evals {int(ev[o])} (no live pixel {int(dead[o])}, 1-2 {int(few[o])}) refinements {int(nref[o])} window fills {int(nfill[o])} deep {int(dok[o])}/{int(dtry[o])} surv {int(dsurv[o])} cull {pbar1[o]/1e3:.0f}k | listed by live px {[int(v) for v in h[o]]} trips {lcyc[o]/1e3:.0f}k cyc")
     # by size class
     for lo, hi in ((0, 256), (256, 1024), (1024, 4096), (4096, 10**9)):
         m = (n > lo) & (n <= hi)

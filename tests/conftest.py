@@ -76,38 +76,8 @@ def assert_frame_close(img, ref, margin, recheck, tol=TOL, what="frame", y0=0):
     return max(worst, worst2)
 
 
-TAIL_LOG = []           # one entry per production frame held against its sequential twin: (what, tiles, tail tiles, worst |d| in them)
-TAIL_TOL = 1.0e-5       # a tail-blended tile against the sequential chain: products associated differently, ~1e-7 relative per pixel
-
-
-def tail_pixel_mask(tile_flags, width, height):
-    """bool [H,W]: pixels of the tiles whose flag says "tail-blended" (Renderer.tile_flags / SGS_BUF_TILE_FLAGS)."""
-    gx, gy = (width + 15) // 16, (height + 15) // 16
-    f = (np.asarray(tile_flags).reshape(gy, gx) & 1).astype(bool)
-    return np.repeat(np.repeat(f, 16, axis=0), 16, axis=1)[:height, :width]
-
-
-def assert_equal_off_tail_tiles(prod, seq, tile_flags, what="frame", n_tail=None, tol=TAIL_TOL):
-    """`prod`: a frame of the production path; `seq`: the same frame with every pixel one sequential fma chain (a test hook, SGS_FLAG_STATS
-    or SGS_FLAG_NO_TAIL); `tile_flags`: the production frame's per-tile flags.  Bit-identical in every tile that was not tail-blended; to
-    rounding (`tol`) in those that were.  (Full frames; a band: rows outside it are equal in both.)"""
-    prod = np.asarray(prod); seq = np.asarray(seq)
-    m = tail_pixel_mask(tile_flags, prod.shape[1], prod.shape[0])
-    nt = int((np.asarray(tile_flags) & 1).sum())
-    if n_tail is not None:
-        assert nt == n_tail, f"{what}: {nt} flagged tiles, sgs_stats.n_tail_tiles = {n_tail}"
-    assert (prod[~m] == seq[~m]).all(), f"{what}: a pixel outside the tail-blended tiles differs from the sequential chain"
-    worst = float(np.abs(prod[m].astype(np.float64) - seq[m]).max(initial=0.0))
-    assert worst < tol, f"{what}: a tail-blended tile is {worst:.3e} off the sequential chain (tol {tol})"
-    TAIL_LOG.append((what, int(np.asarray(tile_flags).size), nt, worst))
-    return nt, worst
-
-
 def pytest_terminal_summary(terminalreporter):
     """The parity ledger: how many pixels of each oracle-checked frame sat near a threshold and how far off the worst was."""
-    if TAIL_LOG:
-        terminalreporter.write_line(f"[tail] {len(TAIL_LOG)} production frames held against their sequential twins: {sum(r[2] for r in TAIL_LOG)} of "
-                                    f"{sum(r[1] for r in TAIL_LOG)} tiles tail-blended, worst |d| in them {max(r[3] for r in TAIL_LOG):.2e} (bit-identical elsewhere)")
     if not PARITY_LOG:
         return
     px = sum(r[1] for r in PARITY_LOG); fl = sum(r[2] for r in PARITY_LOG)

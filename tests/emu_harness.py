@@ -87,9 +87,9 @@ class EmuRenderer:
         return self.debug(_capi.BUF_SCENE_SH, np.float32).reshape(self.n, -1, 3)
 
     def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
-               chunk_cull=True, stats=True, tail=True, deep=True):
+               chunk_cull=True, stats=True, deep=True):
         flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL
-        flags |= (0 if tail else _capi.FLAG_NO_TAIL) | (0 if deep else _capi.FLAG_NO_DEEP)
+        flags |= 0 if deep else _capi.FLAG_NO_DEEP
         flags |= _capi.FLAG_STATS if stats else 0
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
         flags |= _capi.FLAG_LOOSE_CULL if loose_cull else 0
@@ -130,10 +130,6 @@ class EmuRenderer:
 
     def chunk_skipped(self):
         return self.debug(_capi.BUF_CHUNK_SKIPPED, np.uint8)
-
-    def tile_flags(self):
-        """uint8 per tile of the LAST frame: bit 0 = tail-blended (SGS_BUF_TILE_FLAGS)."""
-        return self.debug(_capi.BUF_TILE_FLAGS, np.uint8)
 
     def row_records(self, n_rows, reset=True):
         out = np.zeros(int(n_rows), np.int64)

@@ -11,7 +11,7 @@ import numpy as np
 
 import oracle_c
 import oracle_np as onp
-from conftest import assert_frame_close, assert_equal_off_tail_tiles
+from conftest import assert_frame_close
 
 
 def random_scene(n, seed, deg=0, box=((-2, 2), (-2, 2), (2, 8)), scale=(0.02, 0.2), opac_mu=0.0):
@@ -50,21 +50,15 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     # ... which counts D_f only on request (the drivers ask for it): the instantiation without the bookkeeping — the one
     # a sweep runs — must produce the same frame from the same queues
     img_plain, st_plain = drv.render(cam, cfg, rows, stats=False)
-    tail_flags = drv.tile_flags()
-    assert st_plain["d_total"] == st["d_total"] and st_plain["n_visible"] == st["n_visible"] and st_plain["d_fetched"] == 0
-    # ... bit for bit with the tail blend switched off (SGS_FLAG_NO_TAIL: every pixel one sequential fma chain, as in all the hooks below) —
+    assert (img_plain == img).all() and st_plain["d_total"] == st["d_total"] and st_plain["n_visible"] == st["n_visible"] \
+        and st_plain["d_fetched"] == 0, f"{what}: the frame depends on whether D_f is counted"
     # (the instantiation without D_f is also the only one that takes the deep-tile path: windows of a long-lived tile culled against its
-    #  live pixels before anything is ranked — this comparison holds the two paths against each other) —
-    img_seq, st_seq = drv.render(cam, cfg, rows, stats=False, tail=False)
-    assert (img_seq == img).all() and st_seq["n_tail_tiles"] == 0, f"{what}: the frame depends on whether D_f is counted"
-    assert st_seq["n_deep_windows"] == st_plain["n_deep_windows"]
-    # ... and with it, bit for bit outside the tiles that were tail-blended and to rounding inside them (further down those pixels are
-    # held against the oracle like every other)
-    n_tail, _ = assert_equal_off_tail_tiles(img_plain, img, tail_flags, what, n_tail=st_plain["n_tail_tiles"])
-    img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, tail=False, deep=False)
+    #  live pixels before anything is ranked — the comparison above holds the two paths against each other, bit for bit; and so does the
+    #  runtime switch, SGS_FLAG_NO_DEEP, inside the one instantiation)
+    img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, deep=False)
     assert (img_nodeep == img).all() and st_nodeep["n_deep_windows"] == 0, f"{what}: the deep-tile cull changed a pixel"
-    assert st["n_deep_windows"] == 0 and st["n_tail_tiles"] == 0
-    st["n_deep_windows_plain"] = st_plain["n_deep_windows"]; st["n_tail_tiles_plain"] = n_tail
+    assert st["n_deep_windows"] == 0
+    st["n_deep_windows_plain"] = st_plain["n_deep_windows"]
     # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
     # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
     drv.row_records(0, reset=True)
@@ -112,8 +106,6 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     gy = (cam.height + 15) // 16
     ya, yb = 16 * rows[0], min(cam.height, 16 * (gy if rows[1] < 0 else rows[1]))
     worst = assert_frame_close(img[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what, y0=ya)
-    if n_tail:      # the production frame differs from `img` in its tail-blended tiles: those pixels against the oracle as well
-        worst = max(worst, assert_frame_close(img_plain[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " (tail blend)", y0=ya))
     if "d_fetched" in st_loose and st_loose["d_fetched"]:
         # D_f (reference binning) only differs from the oracle's where a pixel sat on the termination threshold
         assert abs(st_loose["d_fetched"] - aux["D_f"]) <= max(8, 2e-3 * aux["D_f"]), (what, st_loose["d_fetched"], aux["D_f"])
@@ -196,7 +188,7 @@ def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
                 d_sum += st_p["d_total"]
             assert d_sum == st_full["d_total"], f"fuzz seed {seed}: interleaved shards queue {d_sum} records, the frame {st_full['d_total']}"
         if seed % 4 == 0:
-            rgb0, _ = drv.render(cam, stats=False)          # (the production instantiation: the same lists, tail-blended or not, as the aux one)
+            rgb0, _ = drv.render(cam, stats=False)          # (the production instantiation)
             rgb, aux = drv.render_aux(cam)
             assert (rgb == rgb0).all(), f"fuzz seed {seed}: the aux instantiation changed the colours"
             ref, o = oracle_c.render(*scene, cam)
@@ -498,6 +490,6 @@ def case_determinism(drv, n=4000):
     ids_b = drv.intermediates()[1]
     c, _ = drv.render(cam)
     assert (c == a).all()
-    p1, _ = drv.render(cam, stats=False); p2, _ = drv.render(cam, stats=False)      # the production path (tail blend on) twice
-    assert (p1 == p2).all(), "two production renders of the same frame differ"
+    p1, _ = drv.render(cam, stats=False); p2, _ = drv.render(cam, stats=False)      # the production instantiation twice
+    assert (p1 == p2).all() and (p1 == a).all(), "two production renders of the same frame differ"
     assert (a == b).all() and (ids_a == ids_b).all(), "two renders of the same frame differ"

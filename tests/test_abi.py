@@ -41,7 +41,7 @@ def test_struct_layouts_match_the_header(lib):
     from sage_gs import _capi
     assert C.sizeof(_capi.SgsCamera) == 2 * 4 + 4 * 4 + 16 * 4
     assert C.sizeof(_capi.SgsConfig) == 7 * 4 + 3 * 4 + 4 + 4 + 2 * 4      # + tile_row_stride, tile_row_phase
-    assert C.sizeof(_capi.SgsStats) == 136      # 5 i64, 4 i32, float[4], float, (pad), i64[4], i64 (d_super), i64 (n_deep_windows, version 111), i64 (n_tail_tiles, 112)
+    assert C.sizeof(_capi.SgsStats) == 128      # 5 i64, 4 i32, float[4], float, (pad), i64[4], i64 (d_super), i64 (n_deep_windows, version 111)
     sz = (C.c_int32 * 3)()
     p = lambda k: C.cast(C.byref(sz, 4 * k), C.POINTER(C.c_int32))
     lib.sgs_struct_sizes(p(0), p(1), p(2))          # the sizes the LIBRARY was compiled with (Lib() has already refused a mismatch)
