@@ -711,7 +711,7 @@ def main():
                 "stages": stages,
                 "frame_ms_alone": pct(frame_ms),
                 "gpu_ms_per_frame_in_flight": avg["ms_total"] if avg is not None else None,
-                "frames_in_flight": (int(os.environ.get("SGS_LANES", "3")) if pipelined else 1),
+                "frames_in_flight": (r.tuning()["lanes"] if pipelined else 1),
                 "events_on_every_nth_frame": max(1, args.event_stride),
                 "note": "the composite is bound by instruction issue (VALU + the CU's LDS pipe: roofline.valu, DESIGN.md §4.1), not by HBM; ms_alone = a "
                         "launch with nothing else running; ms_in_flight = HIP-event span inside the timed region, where frames "

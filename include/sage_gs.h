@@ -151,6 +151,23 @@ const char* sgs_last_error(const sgs_ctx* ctx);    /* ctx may be NULL: last crea
  * by synchronous renders; asynchronous renders fail with SGS_ERR_OVERFLOW instead. */
 int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
 
+/* The library's tuning surface — ALL of it: the library reads nothing from the environment (rounds 2-5 read eight SGS_* variables at
+ * sgs_create; four of them — the grids of the binning and projection launches — were settled by A/B runs and are constants now).
+ * sgs_tuning_default() fills what the bench runs; sgs_set_tuning() takes effect for the scenes uploaded and the frames issued AFTER it
+ * (it completes the frames in flight first).  Frames do not depend on any of these, bit for bit (tests/test_gpu_parity.py).  No
+ * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112. */
+typedef struct sgs_tuning {
+    int32_t lanes;            /* 3  frames in flight for SGS_FLAG_PIPELINED single frames: each lane has its own stream and intermediates (1..8) */
+    int32_t group;            /* 4  frames per set of launches in sgs_render_batch* (blockIdx.y selects the frame; 1..8) */
+    int32_t group_lanes;      /* 2  streams the groups of a batch alternate over (group x group_lanes <= 8) */
+    int32_t morton;           /* 1  lay the scene out in Z-order at upload (device radix sort); 0 keeps the caller's order */
+    int64_t record_capacity;  /* 16 Mi  (Gaussian, tile) records the queues of a lane hold; an overflowing frame grows them and is rendered again
+                               *        (= sgs_set_record_capacity) */
+} sgs_tuning;
+void sgs_tuning_default(sgs_tuning* out);
+int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* tuning);
+int sgs_get_tuning(const sgs_ctx* ctx, sgs_tuning* out);
+
 /* Scene load — replaces open_stage(usd_path) resolving /World/gauss (simple_env.py:219;
  * generate_images.py:320-327).  Inputs are fp32, activations already applied:
  *   means[N,3], scales[N,3] (linear), quats[N,4] (w,x,y,z; normalised by the library),

@@ -89,14 +89,14 @@ struct sgs_ctx {
     int device = 0;
     std::string err;
     Lane lanes[kMaxLanes];
-    int n_lanes = 3, next_lane = 0;          // SGS_LANES: lanes that SGS_FLAG_PIPELINED single frames rotate over
-    int group = 4, group_lanes = 2;          // SGS_GROUP x SGS_GROUP_LANES <= kMaxLanes: sgs_render_batch* issues `group` frames per
+    int n_lanes = 3, next_lane = 0;          // sgs_tuning.lanes: lanes that SGS_FLAG_PIPELINED single frames rotate over
+    int group = 4, group_lanes = 2;          // sgs_tuning.group x .group_lanes <= kMaxLanes: sgs_render_batch* issues `group` frames per
                                              // set of launches (blockIdx.y = frame), groups rotating over `group_lanes` streams
     int last_lane = 0;
-    int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (SGS_EXP_GRID_ENV)
-    int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (SGS_BIN_GRID, <= SGS_BIN_BLOCKS)
-    int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP (SGS_PRE_GRID): its waves loop over the live list
-    bool morton = true;                      // Z-order the scene at upload (SGS_MORTON=0 keeps the caller's order): a chunk of 64
+    int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (settled by A/B: r03, r04)
+    int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (<= SGS_BIN_BLOCKS)
+    int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP: its waves loop over the live list (r03y)
+    bool morton = true;                      // Z-order the scene at upload (sgs_tuning.morton = 0 keeps the caller's order): a chunk of 64
                                              // Gaussians is then a compact patch, which is what makes the per-chunk bounds
                                              // (k_chunk_bounds / chunk_outside) worth testing — trained scenes come in no spatial order
     unsigned long long* row_acc = nullptr;   // records queued per frame tile row, summed over the frames since the last
@@ -331,7 +331,7 @@ void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t
     if (P.n_chunks <= 0) return;
     launch_cull(G, nf, stream);
     // a wave per chunk of the scene (most end at once) — except for a group of narrow bands, whose frames share
-    // SGS_PRE_GRID workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
+    // pre_grid workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
     const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
     if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all)
         hipLaunchKernelGGL((sgs::k_preprocess<true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
@@ -589,19 +589,7 @@ int sgs_create(int device_id, int backend, sgs_ctx** out) {
     if ((e = hipMalloc(reinterpret_cast<void**>(&ctx->row_acc), sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMalloc", e);
     if ((e = hipMemset(ctx->row_acc, 0, sizeof(unsigned long long) * SGS_MAX_ROWS)) != hipSuccess) return fail("hipMemset", e);
     if ((e = hipStreamSynchronize(nullptr)) != hipSuccess) return fail("hipStreamSynchronize", e);
-    // the tuning variables INTEGRATION.md §5 documents — nothing else is read from the environment
-    if (const char* env = getenv("SGS_MORTON")) ctx->morton = atoi(env) != 0;
-    if (const char* env = getenv("SGS_EXP_GRID")) ctx->exp_grid = std::min(65535, std::max(8, atoi(env)));
-    if (const char* env = getenv("SGS_PRE_GRID")) ctx->pre_grid = std::max(256, atoi(env));
-    if (const char* env = getenv("SGS_BIN_GRID")) ctx->bin_grid = std::min(SGS_BIN_BLOCKS, std::max(8, atoi(env)));
-    if (const char* env = getenv("SGS_LANES")) ctx->n_lanes = std::min(kMaxLanes, std::max(1, atoi(env)));
-    if (const char* env = getenv("SGS_GROUP")) ctx->group = std::min(std::min(kMaxLanes, SGS_MAX_GROUP), std::max(1, atoi(env)));
-    if (const char* env = getenv("SGS_GROUP_LANES")) ctx->group_lanes = std::max(1, atoi(env));
-    ctx->group_lanes = std::max(1, std::min(ctx->group_lanes, kMaxLanes / ctx->group));
-    if (const char* env = getenv("SGS_RECORD_CAPACITY")) {
-        const long long v = atoll(env);
-        if (v > 0) ctx->rec_cap_wanted = v;
-    }
+    // (nothing is read from the environment: sgs_set_tuning is the library's whole tuning surface)
     *out = ctx;
     return SGS_OK;
 }
@@ -628,6 +616,33 @@ int sgs_destroy(sgs_ctx* ctx) {
         delete[] ctx->ev;
     }
     delete ctx;
+    return SGS_OK;
+}
+
+void sgs_tuning_default(sgs_tuning* out) {
+    if (!out) return;
+    out->lanes = 3; out->group = 4; out->group_lanes = 2; out->morton = 1; out->record_capacity = 16ll << 20;
+}
+
+int sgs_get_tuning(const sgs_ctx* ctx, sgs_tuning* out) {
+    if (!ctx || !out) return SGS_ERR_INVALID;
+    out->lanes = ctx->n_lanes; out->group = ctx->group; out->group_lanes = ctx->group_lanes; out->morton = ctx->morton ? 1 : 0;
+    out->record_capacity = ctx->rec_cap_wanted;
+    return SGS_OK;
+}
+
+int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* t) {
+    if (!ctx) return SGS_ERR_INVALID;
+    if (!t) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_set_tuning: tuning is NULL");
+    if (t->lanes < 1 || t->lanes > kMaxLanes) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.lanes %d outside [1, %d]", t->lanes, kMaxLanes);
+    if (t->group < 1 || t->group > std::min(kMaxLanes, SGS_MAX_GROUP)) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.group %d outside [1, %d]", t->group, std::min(kMaxLanes, SGS_MAX_GROUP));
+    if (t->group_lanes < 1 || t->group * t->group_lanes > kMaxLanes)
+        SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.group x group_lanes = %d x %d exceeds the %d lanes of a context", t->group, t->group_lanes, kMaxLanes);
+    if (t->record_capacity <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.record_capacity must be positive");
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();                          // frames in flight were issued under the old values (their verdicts stay for sgs_frame_sync)
+    ctx->n_lanes = t->lanes; ctx->next_lane = 0; ctx->group = t->group; ctx->group_lanes = t->group_lanes; ctx->morton = t->morton != 0;
+    if (t->record_capacity != ctx->rec_cap_wanted) return sgs_set_record_capacity(ctx, t->record_capacity);
     return SGS_OK;
 }
 

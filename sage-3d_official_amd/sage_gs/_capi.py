@@ -28,7 +28,8 @@ DEFAULT_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__fil
 # every symbol include/sage_gs.h declares (tests/test_abi.py checks the built library exports them)
 EXPORTS = ("sgs_version", "sgs_struct_sizes", "sgs_config_default", "sgs_create", "sgs_destroy", "sgs_last_error",
            "sgs_set_record_capacity", "sgs_scene_upload", "sgs_scene_upload_compressed", "sgs_scene_free", "sgs_render",
-           "sgs_render_rgbd", "sgs_render_batch", "sgs_render_batch_strided", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read")
+           "sgs_render_rgbd", "sgs_render_batch", "sgs_render_batch_strided", "sgs_frame_sync", "sgs_row_records", "sgs_pack_rgba8", "sgs_debug_read",
+           "sgs_tuning_default", "sgs_set_tuning", "sgs_get_tuning")
 
 
 class SgsError(RuntimeError):
@@ -52,6 +53,12 @@ class SgsConfig(C.Structure):
 class SgsCompressedScene(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_chunks", C.c_int64), ("sh_degree", C.c_int32), ("sh_decode", C.c_int32),
                 ("chunks", C.c_void_p), ("packed", C.c_void_p), ("sh", C.c_void_p)]
+
+
+class SgsTuning(C.Structure):
+    """include/sage_gs.h sgs_tuning: the library's whole tuning surface (it reads nothing from the environment)."""
+    _fields_ = [("lanes", C.c_int32), ("group", C.c_int32), ("group_lanes", C.c_int32), ("morton", C.c_int32),
+                ("record_capacity", C.c_int64)]
 
 
 class SgsStats(C.Structure):
@@ -118,6 +125,9 @@ class Lib:
         lib.sgs_row_records.argtypes = [vp, vp, i32, i32]
         lib.sgs_pack_rgba8.argtypes = [vp, vp, vp, i32, i32, vp]
         lib.sgs_debug_read.argtypes = [vp, i32, vp, i64]; lib.sgs_debug_read.restype = i64
+        lib.sgs_tuning_default.argtypes = [C.POINTER(SgsTuning)]; lib.sgs_tuning_default.restype = None
+        lib.sgs_set_tuning.argtypes = [vp, C.POINTER(SgsTuning)]
+        lib.sgs_get_tuning.argtypes = [vp, C.POINTER(SgsTuning)]
 
     def __getattr__(self, name):
         return getattr(self._lib, name)

@@ -141,7 +141,11 @@ def _as_f32(t: torch.Tensor, device, shape_tail):
 class Renderer:
     """One rendering context bound to one GPU (one process per GPU is the intended deployment)."""
 
-    def __init__(self, device=None, record_capacity: Optional[int] = None, lib: Optional[_capi.Lib] = None):
+    def __init__(self, device=None, record_capacity: Optional[int] = None, lib: Optional[_capi.Lib] = None, *,
+                 lanes: Optional[int] = None, group: Optional[int] = None, group_lanes: Optional[int] = None,
+                 morton: Optional[bool] = None):
+        """lanes / group / group_lanes / morton / record_capacity: include/sage_gs.h `sgs_tuning` (None = the library's default, what the
+        bench runs).  The library reads nothing from the environment; frames do not depend on any of these, bit for bit."""
         self._lib = lib or _capi.Lib()
         if not torch.cuda.is_available():
             raise RuntimeError("sage_gs.Renderer needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -154,9 +158,26 @@ class Renderer:
         ctx = C.c_void_p()
         self._lib.check(self._lib.sgs_create(index, _capi.BACKEND_HIP, C.byref(ctx)))
         self._ctx = ctx
-        if record_capacity:
-            self._lib.check(self._lib.sgs_set_record_capacity(ctx, int(record_capacity)), ctx)
+        if any(v is not None for v in (record_capacity, lanes, group, group_lanes, morton)):
+            self.set_tuning(lanes=lanes, group=group, group_lanes=group_lanes, morton=morton, record_capacity=record_capacity)
         self.last_stats = None
+
+    def tuning(self) -> dict:
+        t = _capi.SgsTuning()
+        self._lib.check(self._lib.sgs_get_tuning(self._ctx, C.byref(t)), self._ctx)
+        return {k: int(getattr(t, k)) for k, _ in t._fields_}
+
+    def set_tuning(self, **kw):
+        """sgs_set_tuning: any of lanes, group, group_lanes, morton, record_capacity (the others keep their values); applies to the scenes
+        uploaded and the frames issued afterwards."""
+        t = _capi.SgsTuning()
+        self._lib.check(self._lib.sgs_get_tuning(self._ctx, C.byref(t)), self._ctx)
+        for k, v in kw.items():
+            if k not in dict(t._fields_):
+                raise TypeError(f"unknown tuning field {k!r}")
+            if v is not None:
+                setattr(t, k, int(v))
+        self._lib.check(self._lib.sgs_set_tuning(self._ctx, C.byref(t)), self._ctx)
 
     # -- scene ------------------------------------------------------------------------------------
     def upload(self, g: Gaussians) -> Scene:

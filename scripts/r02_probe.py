@@ -21,8 +21,9 @@ ring = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(4
 
 
 def make(morton):
-    os.environ["SGS_MORTON"] = "1" if morton else "0"
-    r = Renderer(dev, record_capacity=(192 << 20) if W > 1920 else (96 << 20))
+    ev = lambda k: int(os.environ[k]) if k in os.environ else None       # (the probe's own knobs; the library reads no environment)
+    r = Renderer(dev, record_capacity=(192 << 20) if W > 1920 else (96 << 20), morton=morton, lanes=ev("SGS_LANES"), group=ev("SGS_GROUP"),
+                 group_lanes=ev("SGS_GROUP_LANES"))
     return r, r.upload(scenes.to_gaussians(sc, dev))
 
 

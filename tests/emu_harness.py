@@ -52,7 +52,6 @@ class EmuRenderer:
     def __init__(self, record_capacity=1 << 20):
         self.lib = lib()
         self.ctx = C.c_void_p()
-        os.environ.setdefault("SGS_RECORD_CAPACITY", str(record_capacity))
         self.lib.check(self.lib.sgs_create(0, _capi.BACKEND_HIP, C.byref(self.ctx)))
         self.lib.check(self.lib.sgs_set_record_capacity(self.ctx, record_capacity), self.ctx)
         self.scene = None

@@ -360,3 +360,37 @@ def test_z_order_sort_of_a_scene_that_spans_several_scan_workgroups():
         assert st["n_gaussians"] == n and np.isfinite(img).all() and img.max() > 0.05
     finally:
         d.close()
+
+
+def test_tuning_surface(drv):
+    """sgs_tuning_default / sgs_set_tuning / sgs_get_tuning (include/sage_gs.h): values are validated (an error and a message, never a
+    clamp), readable back, and a frame rendered under non-default values equals the default one (the emulator's streams are synchronous:
+    the GPU suite holds pipelined frames and batches against each other)."""
+    import ctypes as C
+    from sage_gs import _capi
+    lib, ctx = drv.lib, drv.ctx
+    t = _capi.SgsTuning()
+    lib.sgs_tuning_default(C.byref(t))
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == (3, 4, 2, 1, 16 << 20)
+    scene = pc.random_scene(900, 41, 1, scale=(0.05, 0.3))
+    cam = onp.Camera(96, 64, 70.0, 70.0, 48.0, 32.0, np.eye(4, dtype=np.float32))
+    drv.upload(*scene)
+    want, st0 = drv.render(cam, stats=False)
+    lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
+    keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity)
+    for bad in ((0, 4, 2), (9, 4, 2), (3, 9, 1), (3, 4, 3), (3, 0, 1)):
+        u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20)
+        assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"sgs_tuning" in lib.sgs_last_error(ctx)
+    u = _capi.SgsTuning(3, 4, 2, 1, 0)
+    assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1
+    lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == keep, "a refused tuning changed the context"
+    u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20)
+    lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)
+    lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == (5, 2, 3, 0, 1 << 20)
+    drv.upload(*scene)                                   # (morton = 0: the caller's order is kept)
+    got, st1 = drv.render(cam, stats=False)
+    assert (got == want).all() and st1["n_visible"] == st0["n_visible"] and st1["d_total"] == st0["d_total"]
+    u = _capi.SgsTuning(*keep)
+    lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)

@@ -901,3 +901,44 @@ def test_sweep_driver_against_the_oracle(drv, tmp_path):
         im = np.asarray(Image.open(out / "images" / "trajectory_3" / files[i]))
         assert im.shape == (192, 256, 3) and np.abs(im.astype(int) - seen[("3", i)].astype(int)).mean() < 3.0      # JPEG q95
     scene.free()
+
+
+def test_frames_do_not_depend_on_the_tuning(drv):
+    """include/sage_gs.h sgs_tuning (the library's whole tuning surface: it reads nothing from the environment): lanes in flight, frames per
+    launch group, streams per batch, Z-order at upload.  Pipelined single frames and a batch under non-default values must equal, bit for
+    bit, the frames of the default context; N_v and D too (the scene's layout order only decides which chunk a Gaussian shares)."""
+    import torch
+    from sage_gs import Renderer, scenes
+    sc = scenes.make_room(150_000, seed=6)
+    cams = scenes.room_cameras(sc, 800, 600, n_positions=2, n_yaw=5, seed=6)
+    g = scenes.to_gaussians(sc, "cuda:0")
+    scene = drv.r.upload(g)
+    assert drv.r.tuning() == {"lanes": 3, "group": 4, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"]}
+    want, stats = [], []
+    for c in cams:
+        want.append(drv.r.render(c, scene).clone()); stats.append((drv.r.last_stats["n_visible"], drv.r.last_stats["d_total"]))
+    scene.free()
+    for kw in (dict(lanes=1, group=1, group_lanes=1), dict(lanes=8, group=8, group_lanes=1), dict(lanes=2, group=2, group_lanes=4),
+               dict(lanes=5, group=3, group_lanes=2, morton=False)):
+        r = Renderer("cuda:0", **kw)
+        t = r.tuning()
+        assert all(t[k] == int(v) for k, v in kw.items()), (t, kw)
+        s2 = r.upload(g)
+        outs = [torch.zeros_like(want[0]) for _ in cams]
+        for c, o in zip(cams, outs):
+            r.render(c, s2, out=o, sync=False, pipelined=True)
+        r.sync()
+        batch, bst = r.render_batch(cams, s2, want_stats=True)
+        for i in range(len(cams)):
+            assert (outs[i] == want[i]).all() and (batch[i] == want[i]).all(), f"{kw}: frame {i} differs"
+            assert (bst[i]["n_visible"], bst[i]["d_total"]) == stats[i]
+        # changing it on a live context: the next frames run under the new values
+        r.set_tuning(lanes=3, group=4, group_lanes=2)
+        assert (r.render_batch(cams, s2)[0] == want[0]).all()
+        s2.free(); r.close()
+    # refused, with a message, not clamped
+    r = Renderer("cuda:0")
+    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5)):
+        with pytest.raises(Exception, match="sgs_tuning"):
+            r.set_tuning(**bad)
+    r.close()
