@@ -49,6 +49,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29
 #   cycles per trip and SIMD at 1 / 2 / 3 / 4 / 5 / 8 waves per SIMD (its LDS reads alone: 180; its arithmetic alone: 250-260)
 VALU_CYC_PER_INST = {"v_fma_f32_w8": 2.40, "v_fma_f32_w5": 2.62, "datasheet": 2.0}
 TRIP_CYCLES_W5 = 240.0
+VALU_DATASHEET_LANE_OPS = 1024 * 64 / 2.0 * 2.4e9      # SIMD-32: a wave64 instruction per 2.0 cycles (the figure `roofline.valu.frac` is quoted against)
 VALU_PEAK_LANE_OPS = 256 * 4 * 64 * 2.4e9 / VALU_CYC_PER_INST["v_fma_f32_w8"]      # 65.5e12: the measured v_fma_f32 issue rate at 2.4 GHz
 POSE_STRIDE = 77
 
@@ -74,6 +75,13 @@ def parse():
     ap.add_argument("--rows-rgba8", action="store_true",
                     help="N>1: make the uint8-RGBA gather (bands packed on every rank, 4-byte pixels travel) the tile-row headline; "
                          "default: the fp32 gather north_star names at EVERY N (one metric along the 1/2/4/8 curve), uint8 under also_measured")
+    ap.add_argument("--exchange", choices=("slab", "frames"), default="slab",
+                    help="N>1, tile rows: shape of the framebuffer gatherv — 'slab': every peer sends the bands of a batch as ONE contiguous "
+                         "[B, rows, W, C] message, rank 0 scatters it into the frames (world - 1 operations per exchange + one strided copy per "
+                         "peer); 'frames': one receive per (peer, frame) straight into the frame rows ((world - 1) x B operations, no copy). "
+                         "Both are timed (collective.gather_us_per_frame); this picks the one the timed sweep uses")
+    ap.add_argument("--init-timeout", type=float, default=300.0,
+                    help="N>1: seconds the communicator's creation and every collective may take before the rank says so (with its id) and exits")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1: skip the check made before anything is timed — rank 0 renders pose 0 un-sharded and compares it BIT FOR BIT with "
                          "the frame gathered from the N ranks' bands (single-frame and batched exchange); reported as `verify`")
@@ -96,6 +104,8 @@ def parse():
     ap.add_argument("--scene-kind", choices=("room", "trained"), default="room",
                     help="synthetic scene: make_room (BASELINE.md, default) or make_trained_like (trained-3DGS statistics: heavy-tailed "
                          "anisotropic scales, 40 %% nearly transparent splats, floaters, no spatial order)")
+    ap.add_argument("--no-trained", action="store_true",
+                    help="N=1: skip the side measurement on a scene with trained-3DGS statistics (also_measured.trained_scene: ~30 s of scene generation)")
     ap.add_argument("--no-lowres", action="store_true",
                     help="N=1: skip the measurements at the reference's own resolutions (320x240, 640x480, 1024x768)")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
@@ -231,11 +241,37 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     if world > 1:
+        import datetime
+        import threading
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+        def stuck(what):
+            # a rank that never gets its communicator (or never leaves its first collective) must SAY so, with its id — the first N > 1 run
+            # on a real node is a driver run nobody can attach a debugger to
+            print(f"[bench rank {rank}/{world} local_rank {local_rank} device {dev_index}] {what} did not finish within {args.init_timeout:.0f} s "
+                  f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} backend={'gloo' if share else 'nccl'} "
+                  f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}); exiting", file=sys.stderr, flush=True)
+            os._exit(3)
+        wd = threading.Timer(args.init_timeout, stuck, args=("creating the process group + its first all-reduce",))
+        wd.daemon = True
+        wd.start()
+        try:
+            to = datetime.timedelta(seconds=args.init_timeout)
+            if share:
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=to)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=to)
+            t_ = torch.ones(1, dtype=torch.float32, device="cpu" if share else device)
+            dist.all_reduce(t_)                                    # forces the communicator into existence on every rank, now
+            if not share:
+                torch.cuda.synchronize(device)
+            assert int(t_.item()) == world, f"the first all-reduce summed to {t_.item()} over {world} ranks"
+        except Exception as e:             # noqa: BLE001
+            print(f"[bench rank {rank}/{world} local_rank {local_rank} device {dev_index}] process group creation failed: {type(e).__name__}: {e}",
+                  file=sys.stderr, flush=True)
+            raise
+        finally:
+            wd.cancel()
 
     config = args.config or (3 if world == 1 else 4)
     width = args.width or (3840 if config == 5 else 1920)
@@ -310,8 +346,9 @@ def main():
     # (also_measured.rows_rgba8).  Rounds 3-4 switched the headline's payload to uint8 from N = 4 on: a curve of two metrics.
     head_rgba8 = world > 1 and args.rows_rgba8 and args.bands != "interleave"
     if world > 1:
-        sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"))
-        sharded_head = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8") if head_rgba8 else sharded_f32
+        sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"),
+                                                exchange=args.exchange)
+        sharded_head = ShardedRenderer(r, height, width, balance=(args.bands == "balanced"), output="rgba8", exchange=args.exchange) if head_rgba8 else sharded_f32
 
     warming = [False]
 
@@ -456,11 +493,13 @@ def main():
         exchanges; rank 0 compares and prints one line on stderr.  A mismatch does not stop the run: it is in the JSON line
         (`verify.ok` false) and the judge / the driver can see that the number belongs to wrong frames."""
         sel = [cams[pose(i)] for i in range(3)]
+        backend = dist.get_backend() if world > 1 else "none"
         res = {"ok": True, "frames_checked": 0, "mismatching_pixels": 0, "max_abs_diff": 0.0,
-               "backend": dist.get_backend(), "ranks": dist.get_world_size(),
-               "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
+               "backend": backend, "ranks": world, "rccl_ranks": world if backend == "nccl" else 0, "exchange": args.exchange,
                "what": "gathered frame == rank 0's un-sharded render of the same pose, bit for bit (torch.equal); single-frame exchange, "
-                       "batched exchange of 3 frames, and the uint8-RGBA gather against pack_rgba8 of the un-sharded frame"}
+                       "batched exchange of 3 frames in BOTH shapes (one slab per peer / one operation per (peer, frame)), and the uint8-RGBA "
+                       "gather against pack_rgba8 of the un-sharded frame.  (N = 1: the same code with nothing to gather — the line has the "
+                       "same shape along the 1/2/4/8 curve)"}
         refs = []
         if rank == 0:
             for c in sel:
@@ -475,24 +514,29 @@ def main():
                 res["ok"] = False
                 res["mismatching_pixels"] += int((d.reshape(d.shape[0], d.shape[1], -1).amax(-1) > 0).sum().item())
                 res["max_abs_diff"] = max(res["max_abs_diff"], float(d.max().item()))
-        vs = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=False, batch=4)
-        fr = vs.render(sel[0], gs)                                  # single-frame exchange (even bands)
-        if rank == 0:
-            check(fr, refs[0])
-        g = vs.render_batch(sel, gs)                                # the batched exchange of the timed sweep
-        vs.finish()
-        if rank == 0:
-            for b in range(len(sel)):
-                check(g.frame(b), refs[b])
+        ops = {}
+        for ex in ("slab", "frames"):
+            vs = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=False, batch=4, exchange=ex)
+            if ex == "slab":
+                fr = vs.render(sel[0], gs)                              # single-frame exchange (even bands)
+                if rank == 0:
+                    check(fr, refs[0])
+            g = vs.render_batch(sel, gs)                                # the batched exchange of the timed sweep, in this shape
+            vs.finish()
+            ops[g.mode] = g.last_ops
+            if rank == 0:
+                for b in range(len(sel)):
+                    check(g.frame(b), refs[b])
+            del vs
+        res["p2p_ops_rank0_per_exchange_of_3_frames"] = ops
         if args.bands != "interleave":
-            v8 = ShardedRenderer(r, height, width, balance=False, batch=4, output="rgba8")
+            v8 = ShardedRenderer(r, height, width, balance=False, batch=4, output="rgba8", exchange=args.exchange)
             g8 = v8.render_batch(sel, gs)
             v8.finish()
             if rank == 0:
                 for b in range(len(sel)):
                     check(g8.frame(b), r.pack_rgba8(refs[b]))
             del v8
-        del vs
         fence()
         if rank == 0:
             print(f"[verify] backend={res['backend']} rccl_ranks={res['rccl_ranks']} of {world}: {res['frames_checked']} gathered frames "
@@ -502,7 +546,7 @@ def main():
 
     verify = None
     try:
-        if world > 1 and not args.no_verify:
+        if not args.no_verify and (world > 1 or not (args.scene or args.scene_kind == "trained")):
             verify = verify_rows()
         elapsed, avg = measure(run_rows if rows_primary else run_cameras, W, K, timing)
     except Exception as e:             # noqa: BLE001
@@ -511,20 +555,33 @@ def main():
         bail_rows(f"the tile-row-sharded sweep failed: {type(e).__name__}: {e}"[:300])
     frames_total = K if (rows_primary or world == 1) else K * world       # camera shards: one frame per rank per step
     # N > 1, tile rows: the exchange alone — the gatherv of already rendered bands, no rendering — per frame (all ranks take part)
-    gather_us = None
+    gather_us, gather_ops = None, None
     if rows_primary and pipelined and getattr(sharded_head, "_ring", None):
-        try:
-            gq = sharded_head._ring[0]
-            ng = max(1, min(8, sharded_head.batch))
-            gq.exchange(ng)
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                gq.exchange(ng)
-            fence()
-            gather_us = 1e6 * (time.perf_counter() - t0) / (3 * ng)
-        except Exception as e:             # noqa: BLE001 - a diagnostic, never fatal for the headline
-            gather_us = f"{type(e).__name__}: {e}"[:200]
+        from sage_gs.dist import FrameGather
+        gather_us, gather_ops = {}, {}
+        gq = sharded_head._ring[0]
+        ng = max(1, min(8, sharded_head.batch))
+        for ex in ("slab", "frames"):
+            try:
+                if ex == gq.mode or gq.interleave:
+                    gx = gq
+                else:                            # the other shape of the same gatherv: same bands, same payload, its own buffers
+                    gx = FrameGather(height, width, device, batch=sharded_head.batch, exchange=ex, **sharded_head._gk)
+                    gx.set_bands(gq.bands)
+                if gx.mode in gather_us:
+                    continue
+                gx.exchange(ng)
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    gx.exchange(ng)
+                fence()
+                gather_us[gx.mode] = 1e6 * (time.perf_counter() - t0) / (3 * ng)
+                gather_ops[gx.mode] = gx.last_ops
+                if gx is not gq:
+                    del gx
+            except Exception as e:             # noqa: BLE001 - a diagnostic, never fatal for the headline
+                gather_us[ex] = f"{type(e).__name__}: {e}"[:200]
     # a short timed region (the driver's --steps 20 is 5 ms) gets a neighbour measured over 100 steps in the same process:
     # same poses, same path as a --steps 100 run (frames pipelined on the lanes), W warm-up steps already done
     value_100 = None
@@ -542,11 +599,12 @@ def main():
     # visible Gaussian instead of 192 B.  Not the headline: quantisation makes it a (slightly) different scene than the fp32 arrays.
     compressed_scene = None
     if world == 1 and pipelined and not args.scene and not args.no_upload_probe:
+        gs_fp32, gs_packed = gs, None
         try:
             dvq = quantise_on_gpu(scenes.to_gaussians(scene, device))
-            gs_fp32 = gs
-            gs = r.upload_compressed(dvq[0], dvq[1], dvq[2], scene.sh_degree, model_to_world=scene.model_to_world)
+            gs_packed = r.upload_compressed(dvq[0], dvq[1], dvq[2], scene.sh_degree, model_to_world=scene.model_to_world)
             del dvq
+            gs = gs_packed                       # (run_cameras renders `gs`; restored in `finally` whatever happens in between)
             measure(run_cameras, max(W, 8), max(W, 8), False)
             dtc, _ = measure(run_cameras, W, K, False)
             pre = []
@@ -557,10 +615,18 @@ def main():
                                 "preprocess_ms_alone": float(np.mean(pre)), "sh_bytes_per_gaussian_in_hbm": 64,
                                 "what": "the same sweep, same path, on the scene uploaded from the PlayCanvas compressed payload (16 B + 45 SH bytes per "
                                         "Gaussian; SH dequantised by k_preprocess every frame)"}
-            gs.free()
-            gs = gs_fp32
         except Exception as e:             # noqa: BLE001 - a neighbour of the headline, never fatal for it
             compressed_scene = {"error": f"{type(e).__name__}: {e}"[:300]}
+        finally:
+            # everything below (ms_alone, algorithmic bytes, latency, the low resolutions) is the fp32 headline scene's again — also when
+            # the side measurement raised half-way — and the compressed handle does not leak
+            gs = gs_fp32
+            if gs_packed is not None:
+                try:
+                    r.sync()
+                except Exception:          # noqa: BLE001
+                    pass
+                gs_packed.free()
 
     # ---- the same frames one at a time on rank 0 (outside the timed region): kernel durations ALONE, algorithmic bytes,
     #      and the host-timed latency of a synchronous frame -------------------------------------------------------------
@@ -614,8 +680,11 @@ def main():
             "verify": verify,
             "upload_ms": upload_ms,
             "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
-                            "gather_us_per_frame": gather_us, "what": "ranks = the size the communicator reports; gather_us_per_frame = the "
-                            "framebuffer gatherv alone (bands already rendered), 8 frames per exchange, host-timed between fences"}
+                            "exchange": args.exchange, "gather_us_per_frame": gather_us, "p2p_ops_rank0_per_exchange_of_8_frames": gather_ops,
+                            "what": "ranks = the size the communicator reports; exchange = the shape of the gatherv the timed sweep used (slab: one "
+                            "contiguous [B, rows, W, C] message per peer + one strided copy per peer on rank 0; frames: one operation per (peer, frame), "
+                            "no copy); gather_us_per_frame = the framebuffer gatherv ALONE in both shapes (bands already rendered), 8 frames per exchange, "
+                            "host-timed between fences, with the operations rank 0 posted per exchange"}
                            if world > 1 else None),
             "config": {"workload": workload,
                        "pose_set": pose_set,
@@ -665,9 +734,13 @@ def main():
                         vi = tj.get("_valu_insts", {}).get(dom)
                         if vi and ms_dom > 0:
                             valu = {"inst_per_launch": vi, "lane_ops_per_s": vi * 64.0 / (ms_dom * 1e-3),
-                                    "peak_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac": vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS,
-                                    "peak_basis": "measured: one v_fma_f32 per 2.40 shader cycles and SIMD at 8 waves per SIMD (2.62 at the kernel's 5; datasheet 2.0), "
-                                                  "1024 SIMDs x 64 lanes at 2.4 GHz — scripts/ubench2.hip, profiles/r05b_ubench2_table.txt",
+                                    # `frac` is against the DATASHEET rate (SIMD-32: a wave64 instruction per 2.0 cycles, 1024 SIMDs x 64 lanes at 2.4 GHz =
+                                    # 78.6 T lane-ops/s) — no home-field advantage; the rate this repo MEASURED (2.40 cycles: 65.5 T) is beside it
+                                    "peak_lane_ops_per_s": VALU_DATASHEET_LANE_OPS, "frac": vi * 64.0 / (ms_dom * 1e-3) / VALU_DATASHEET_LANE_OPS,
+                                    "peak_basis": "datasheet: one wave64 VALU instruction per 2.0 shader cycles and SIMD, 1024 SIMDs x 64 lanes at 2.4 GHz",
+                                    "measured_ceiling_lane_ops_per_s": VALU_PEAK_LANE_OPS, "frac_of_measured_ceiling": vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS,
+                                    "measured_ceiling_basis": "one v_fma_f32 per 2.40 shader cycles and SIMD at 8 waves per SIMD (2.62 at the kernel's 5) — scripts/ubench2.hip, "
+                                                              "profiles/r05b_ubench2_table.txt",
                                     "cycles_per_inst": VALU_CYC_PER_INST,
                                     # valu_busy (SQ_ACTIVE_INST_VALU) books every VALU instruction as ONE quad-cycle = 4 cycles of its SIMD whatever it
                                     # costs; frac books it at the measured v_fma rate: the two describe the same instruction count,
@@ -675,6 +748,7 @@ def main():
                                     "reconciliation": {"valu_busy_books_cycles_per_inst": 4.0, "frac_books_cycles_per_inst": VALU_CYC_PER_INST["v_fma_f32_w8"],
                                                        "valu_busy_over_frac_expected": 4.0 / VALU_CYC_PER_INST["v_fma_f32_w8"],
                                                        "valu_busy_over_frac": (valu_busy / (vi * 64.0 / (ms_dom * 1e-3) / VALU_PEAK_LANE_OPS)) if valu_busy else None,
+                                                       "frac_here": "frac_of_measured_ceiling",
                                                        "what": "neither is 'time the VALU could not have been used': the kernel's instruction MIX costs more than v_fma "
                                                                "(v_exp 8.2, clamp / compare forms 4.2-4.6 cycles) and its blend also drives the CU's LDS pipe to ~75 % "
                                                                "(21 broadcast reads per trip at 2.1 cycles per CU)"},
@@ -691,15 +765,19 @@ def main():
             out["roofline"] = {
                 # the composite is bound by vector issue slots, not by HBM (valu_busy ~0.8, traffic ~1.1x the algorithmic bytes):
                 # `frac` stays the HBM fraction SURVEY.md §8(d) defines (and the judge recomputes), `valu.frac` is the binding one
-                "bound": "valu" if dom == "render" else "hbm", "bound_note": "achieved/peak/frac are the HBM roofline of SURVEY.md §8(d); the kernel's binding resource is VALU issue (roofline.valu)",
+                "bound": "valu" if dom == "render" else "hbm",
+                "bound_note": "achieved/peak/frac are the HBM roofline of the COMPOSITE PASS as SURVEY.md §8(d) prices it (K5: 40 D_f + 12 P — the pass "
+                              "BASELINE.json's >= 60 % target is stated on; the launch also does K4's work, whose bytes are NOT credited here: see "
+                              "accountings); the kernel's binding resource is VALU issue (roofline.valu)",
                 "kernel": "k_tile_render (fused per-tile sort K4 + composite K5)" if dom == "render" else dom,
-                "achieved": gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0),
+                "achieved": gbps(b_k5) if dom == "render" else (stages[dom]["GBps"] or 0.0),
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": (gbps(b_fused) if dom == "render" else (stages[dom]["GBps"] or 0.0)) / HBM_PEAK_GBPS,
+                "frac": (gbps(b_k5) if dom == "render" else (stages[dom]["GBps"] or 0.0)) / HBM_PEAK_GBPS,
                 "basis": "algorithmic bytes per launch / average duration of the launch ALONE (HIP events, one frame at a time)",
-                "avg_launch_ms": ms_dom, "alg_bytes_per_launch": b_fused if dom == "render" else stages[dom]["alg_bytes"],
-                "accountings": ({"survey_k4_k5": {"bytes": b_fused, "formula": "16 D + 40 D_f + 12 P", "frac": gbps(b_fused) / HBM_PEAK_GBPS},
-                                 "survey_k5_only": {"bytes": b_k5, "formula": "40 D_f + 12 P", "frac": gbps(b_k5) / HBM_PEAK_GBPS},
+                "avg_launch_ms": ms_dom, "alg_bytes_per_launch": b_k5 if dom == "render" else stages[dom]["alg_bytes"],
+                "accountings": ({"survey_k5_only": {"bytes": b_k5, "formula": "40 D_f + 12 P", "frac": gbps(b_k5) / HBM_PEAK_GBPS, "headline": True},
+                                 "survey_k4_k5": {"bytes": b_fused, "formula": "16 D + 40 D_f + 12 P (rounds 1-5 quoted this one as `frac`: it credits a "
+                                                  "sort write-back the lazy sort never makes)", "frac": gbps(b_fused) / HBM_PEAK_GBPS},
                                  "builder_tight": {"bytes": b_tight, "formula": "8 D + 36 D_f + 12 P (the sort never writes records back)",
                                                    "frac": gbps(b_tight) / HBM_PEAK_GBPS}} if dom == "render" else None),
                 "traffic": traffic, "valu_busy": valu_busy, "lds_bank_conflict_share": lds_conf, "valu": valu,
@@ -800,6 +878,49 @@ def main():
             out["also_measured"] = dict(out.get("also_measured") or {}, reference_resolutions=dict(
                 low, what="one frame at a time at the resolutions the reference renders (run_benchmark.py:1409-1419 --low-res 320x240, simple_env.py:52 "
                           "640x480, generate_images.py:43 1024x768), same scene and poses; get_rgba = the same through the GsCamera adapter to host uint8"))
+        if world == 1 and not args.no_trained and not args.scene and args.scene_kind == "room" and config != 5:
+            # Real InteriorGS scenes are TRAINED 3DGS, not make_room: log-normal scales with a heavy tail, strong anisotropy, 40 % of the splats
+            # nearly transparent, floaters, no spatial order (scenes.make_trained_like; no checkpoint is available offline).  The same sweep and
+            # the same one-at-a-time pass on such a scene of the same size, with every stage's algorithmic bytes and GB/s: here the binning, not
+            # the composite, is the larger half of a frame.
+            try:
+                t0 = time.perf_counter()
+                sc_t = scenes.make_trained_like(args.gaussians, seed=2)
+                gen_s = time.perf_counter() - t0
+                cams_t = scenes.room_cameras(sc_t, width, height, n_positions=4, n_yaw=64, seed=2)
+                gs_t = r.upload(scenes.to_gaussians(sc_t, device))
+                nt = min(K, 20)
+                sel_t = [cams_t[pose(W + i)] for i in range(nt)]
+                tb = torch.zeros((nt, height, width, 3), dtype=torch.float32, device=device)
+                r.render_batch(sel_t, gs_t, out=tb)                       # (grows the record queues: D is ~6x the room scene's)
+                r.render_batch(sel_t, gs_t, out=tb)
+                torch.cuda.synchronize(device); t0 = time.perf_counter()
+                r.render_batch(sel_t, gs_t, out=tb)
+                torch.cuda.synchronize(device); dtt = time.perf_counter() - t0
+                st_ms = {n: [] for n in STAGE_NAMES}; st_b = {n: 0 for n in STAGE_NAMES}; cnt_t = {"n_visible": 0, "d_total": 0, "d_super": 0, "d_fetched": 0}
+                for c_ in sel_t:
+                    r.render(c_, gs_t, out=frame, timing=True)
+                    for n in STAGE_NAMES:
+                        st_ms[n].append(r.last_stats["ms"][n])
+                    r.render(c_, gs_t, out=frame, stats=True)
+                    for n in STAGE_NAMES:
+                        st_b[n] += r.last_stats["bytes"][n]
+                    for k_ in cnt_t:
+                        cnt_t[k_] += r.last_stats[k_]
+                stages_t = {}
+                for n in STAGE_NAMES:
+                    ms_ = mean(st_ms[n]); b_ = st_b[n] / nt
+                    stages_t[n] = {"ms_alone": ms_, "alg_bytes": b_, "GBps": b_ / (ms_ * 1e-3) / 1e9 if ms_ > 0 else None,
+                                   "frac_of_hbm_peak": b_ / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBPS if ms_ > 0 else None}
+                out["also_measured"] = dict(out.get("also_measured") or {}, trained_scene={
+                    "value": nt / dtt, "unit": "frames/s", "steps": nt, "ms_per_step": 1e3 * dtt / nt, "stages": stages_t,
+                    "per_frame": {k_: v_ / nt for k_, v_ in cnt_t.items()}, "scene_generation_s": gen_s,
+                    "what": f"make_trained_like({args.gaussians}, seed=2) at {width}x{height}, the same poses: one render_batch call of {nt} frames (value), then "
+                            "one frame at a time with HIP events (stages: duration alone, algorithmic bytes as DESIGN.md §4 defines them, GB/s)"})
+                gs_t.free()
+                del tb, sc_t, cams_t
+            except Exception as e:             # noqa: BLE001 - a neighbour of the headline, never fatal for it
+                out["also_measured"] = dict(out.get("also_measured") or {}, trained_scene={"error": f"{type(e).__name__}: {e}"[:300]})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, [cams[pose(W + i)] for i in range(min(K, 32))], args.cpu_seconds)
     else:

@@ -24,11 +24,18 @@ Which rows a rank owns:
     splat covers 2-3 tile rows, so every rank then projects and bins ~1.7x the splats of a contiguous band, and rank 0
     has to re-interleave the rows (one copy).  Opt-in; measured slower than balanced bands.
 
-The one exchange step is a gatherv of exact slabs: rank 0 posts one receive per (peer, frame) straight into the rows of
-its frame buffer, every peer one send per frame, all in ONE group (`torch.distributed.batch_isend_irecv`; on the
-"nccl" backend — RCCL on ROCm — that is a single ncclGroupStart/End of ncclSend/ncclRecv, i.e. a gatherv with
-the seven peers on seven distinct xGMI links of rank 0 concurrently; "gloo" in the CPU tests).  Bands may therefore be
-of any height and there is no padding and no assembly copy.  A 1080p fp32 frame is 24.9 MB (3.1 MB per rank at 8
+The one exchange step is a gatherv of exact slabs, all of it ONE group of point-to-point operations
+(`torch.distributed.batch_isend_irecv`; on the "nccl" backend — RCCL on ROCm — a single ncclGroupStart/End of
+ncclSend/ncclRecv, i.e. a gatherv with the seven peers on seven distinct xGMI links of rank 0 concurrently; "gloo" in the
+CPU tests), in one of two shapes (`exchange=`):
+  * "slab" (default for batches) — every peer keeps the bands of a batch's B frames as ONE contiguous [B, rows, W, C] slab
+    (the library renders a batch at any frame stride) and sends it in ONE operation; rank 0 receives it into a staging slab
+    and scatters it into the rows of its [B, H, W, C] frame buffer with one strided device copy per peer: world - 1
+    operations per exchange (7 at 8 ranks) whatever B is, at the price of one more pass over the gathered bytes on rank 0;
+  * "frames" — rank 0 posts one receive per (peer, frame) straight into the rows of its frame buffer, every peer one send
+    per frame: no staging, no copy, (world - 1) x B operations per exchange (224 at 8 ranks x 32 frames).
+Bands may be of any height either way and there is no padding.  Which shape is faster over xGMI is not known to this
+repo (no multi-GPU node was available to its builder): `bench.py --gpus N` times both and says so in `collective`.  A 1080p fp32 frame is 24.9 MB (3.1 MB per rank at 8
 ranks): latency-, not bandwidth-bound — so a sweep ships the bands of B frames per group, asynchronously, double-
 buffered against the rendering of the next batch (`ShardedRenderer.render_batch`; 32 frames by default: the library
 renders a batch in groups of four frames per launch on two streams, and the pipeline drains at the end of every call —
@@ -179,11 +186,17 @@ class FrameGather:
 
     def __init__(self, height: int, width: int, device, rank: Optional[int] = None, world: Optional[int] = None,
                  group=None, dst: int = 0, channels: int = 3, dtype=torch.float32, batch: Optional[int] = None,
-                 interleave: bool = False, max_band_rows: Optional[int] = None):
+                 interleave: bool = False, max_band_rows: Optional[int] = None, exchange: str = "frames"):
+        if exchange not in ("frames", "slab"):
+            raise ValueError("exchange must be 'frames' or 'slab'")
         self.group = group
+        # "slab": one operation per peer and exchange (contiguous bands of a batch; interleaved rows and single frames keep "frames")
+        self.mode = "slab" if (exchange == "slab" and not interleave and batch is not None) else "frames"
         self.interleave = bool(interleave)
-        self.rank = dist.get_rank(group) if rank is None else rank
-        self.world = dist.get_world_size(group) if world is None else world
+        # (no process group: one rank — `bench.py --gpus 1` runs its verify step through the very same code)
+        have_pg = dist.is_available() and dist.is_initialized()
+        self.rank = (dist.get_rank(group) if have_pg else 0) if rank is None else rank
+        self.world = (dist.get_world_size(group) if have_pg else 1) if world is None else world
         self.dst, self.h, self.w, self.c = dst, height, width, channels
         self.batch = batch
         self.n_tile_rows = (height + TILE - 1) // TILE
@@ -203,13 +216,28 @@ class FrameGather:
         self._frames = None
         self._compact = None
         self._slab = None
+        self._slab_flat = None       # "slab" mode, a peer: the storage its compact [nb, rows, W, C] slab is a view of
+        self._stage = None           # "slab" mode, rank dst: where the peers' slabs land before they are scattered into the frames
+        self.last_ops = 0            # point-to-point operations this rank posted in its last exchange
         if self.rank == dst:
             self._frames = torch.zeros((nb, height, width, channels), dtype=dtype, device=device)
             if self.interleave and self.world > 1:
                 # compact images of every rank's rows land here; frames are assembled on request (one copy)
                 self._compact = torch.zeros((self.world, nb, rows_cap * TILE, width, channels), dtype=dtype, device=device)
+            if self.mode == "slab" and self.world > 1:
+                self._stage = torch.zeros(nb * height * width * channels, dtype=dtype, device=device)
+        elif self.mode == "slab":
+            self._slab_flat = torch.zeros(nb * rows_cap * TILE * width * channels, dtype=dtype, device=device)
+            self._view_slab()
         else:
             self._slab = torch.zeros((nb, rows_cap * TILE, width, channels), dtype=dtype, device=device)
+
+    def _view_slab(self):
+        """"slab" mode, a peer: its slab is COMPACT for the band it currently owns — [nb, rows, W, C] contiguous, so that the first n frames
+        are one contiguous message (the library renders a batch at any frame stride: sgs_render_batch_strided)."""
+        y0, y1 = self._px(self.band)
+        rows = max(0, y1 - y0)
+        self._slab = self._slab_flat[: self._nb * rows * self.w * self.c].view(self._nb, rows, self.w, self.c)
 
     # -- bands ------------------------------------------------------------------------------------------------------
     def set_bands(self, bands: Sequence[Tuple[int, int]]):
@@ -224,6 +252,8 @@ class FrameGather:
                              f"{self.max_band_rows} rows: {bands}")
         self.bands = bands
         self.band = bands[self.rank]
+        if self._slab_flat is not None:
+            self._view_slab()
 
     def _px(self, band) -> Tuple[int, int]:
         return band[0] * TILE, min(band[1] * TILE, self.h)
@@ -295,8 +325,34 @@ class FrameGather:
             return None
         mine = self._frames if self.rank == self.dst else self._slab
         gloo_gpu = mine.is_cuda and dist.get_backend(self.group) == "gloo"
-        ops, staged = [], []
-        if self.rank == self.dst:
+        ops, staged, scatter = [], [], []
+        if self.mode == "slab":
+            # ONE operation per peer: its [n, rows, W, C] slab, contiguous on both sides; rank dst scatters it into the frames afterwards
+            if self.rank == self.dst:
+                off = 0
+                for r in range(self.world):
+                    rows = self._rows_px(r)
+                    if r == self.dst or rows <= 0:
+                        continue
+                    cnt = n * rows * self.w * self.c
+                    view = self._stage[off:off + cnt].view(n, rows, self.w, self.c)
+                    off += cnt
+                    y0 = self.bands[r][0] * TILE
+                    scatter.append((self._frames[:n, y0:y0 + rows], view))
+                    if gloo_gpu:
+                        host = torch.empty(view.shape, dtype=view.dtype)
+                        staged.append((view, host))
+                        view = host
+                    ops.append(dist.P2POp(dist.irecv, view, self._global(r), self.group))
+            else:
+                rows = self._rows_px(self.rank)
+                if rows > 0:
+                    src = self._slab[:n]                 # (compact: the first n frames are one contiguous range)
+                    if gloo_gpu:
+                        src = src.cpu()
+                        staged.append((None, src))
+                    ops.append(dist.P2POp(dist.isend, src, self._global(self.dst), self.group))
+        elif self.rank == self.dst:
             for r in range(self.world):
                 rows = self._rows_px(r)
                 if r == self.dst or rows <= 0:
@@ -321,13 +377,16 @@ class FrameGather:
                         src = src.cpu()
                         staged.append((None, src))       # kept alive until the send has completed
                     ops.append(dist.P2POp(dist.isend, src, self._global(self.dst), self.group))
+        self.last_ops = len(ops)
         works = dist.batch_isend_irecv(ops) if ops else []
 
         def land():
             for view, host in staged:
                 if view is not None:
                     view.copy_(host)
-        h = _Works(works, land if staged else None)
+            for rows_of_frames, slab in scatter:         # "slab" mode: one strided device copy per peer
+                rows_of_frames.copy_(slab)
+        h = _Works(works, land if (staged or scatter) else None)
         if async_op:
             return h
         h.wait()
@@ -376,7 +435,7 @@ class ShardedRenderer:
     MAX_BUFFER_BYTES = 16 << 30
 
     def __init__(self, renderer, height: int, width: int, group=None, dst: int = 0, batch: int = 32,
-                 interleave: bool = False, balance: bool = False, output: str = "float32"):
+                 interleave: bool = False, balance: bool = False, output: str = "float32", exchange: str = "slab"):
         """output="float32": rank dst gets [H,W,3] float32 frames (the renderer's native output).  output="rgba8": every rank
         packs its band to uint8 RGBA (Renderer.pack_rgba8 — what `get_rgba()` hands the reference's callers) and the bands
         travel as bytes: a third of the fp32 payload over xGMI (8.3 instead of 24.9 MB per 1080p frame into rank dst);
@@ -387,6 +446,9 @@ class ShardedRenderer:
             raise ValueError("output must be 'float32' or 'rgba8'")
         if output == "rgba8" and interleave:
             raise ValueError("rgba8 output is for contiguous bands")
+        if exchange not in ("frames", "slab"):
+            raise ValueError("exchange must be 'frames' or 'slab' (see the module docstring)")
+        self.exchange = exchange
         self.r = renderer
         self.h, self.w, self.group, self.dst = height, width, group, dst
         self.interleave, self.balance = bool(interleave), bool(balance)
@@ -409,7 +471,8 @@ class ShardedRenderer:
         ch = 4 if output == "rgba8" else 3
         band_rows = min(height, self.g.max_band_rows * TILE)
         scratch = self.batch * band_rows * width * 12 if output == "rgba8" else 0
-        size = lambda rows: 2 * self.batch * rows * width * ch * esz + scratch
+        stage = self.batch * height * width * ch * esz if (exchange == "slab" and not self.interleave) else 0     # rank dst, per ring buffer
+        size = lambda rows: 2 * self.batch * rows * width * ch * esz + scratch + (2 * stage if rows == height else 0)
         self.buffer_bytes = int(size(height if self.g.rank == dst else band_rows))
         # The limit is checked against the LARGEST rank's need (rank dst holds whole frames) on EVERY rank: a check of the rank's own
         # need would raise on dst alone and leave the others blocked in the collective below until the communicator times out.
@@ -495,7 +558,7 @@ class ShardedRenderer:
             raise ValueError(f"1..{self.batch} cameras per batch")
         if self._ring is None:
             self._ring = [FrameGather(self.h, self.w, self.r.device, group=self.group, dst=self.dst, batch=self.batch,
-                                      interleave=self.interleave, **self._gk) for _ in range(2)]
+                                      interleave=self.interleave, exchange=self.exchange, **self._gk) for _ in range(2)]
         k = self._turn
         self._turn ^= 1
         if self._pending[k] is not None:           # the exchange that last read this buffer

@@ -13,11 +13,14 @@ cd /tmp
 echo "== bench"; timeout 600 python $ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 400 $OUT/bench.json
 timeout 600 python $ROOT/bench.py --steps 20 --warmup 5 > $OUT/bench_k20.json 2> $OUT/bench_k20.err; tail -c 300 $OUT/bench_k20.json
 echo "== N = 2 on this one GPU under gloo (the N > 1 code path incl. verify; not a scaling number)"; SGS_BENCH_SHARE_GPU=1 timeout 400 python $ROOT/bench.py --gpus 2 --steps 20 --warmup 5 --no-secondary > $OUT/bench_n2_shared_gpu.json 2> $OUT/bench_n2_shared_gpu.err; grep verify $OUT/bench_n2_shared_gpu.err
+echo "== N = 8 on this one GPU under gloo: configs[3] and configs[4] (the N > 1 code path at the driver's world size incl. verify and both gatherv shapes; not a scaling number)"
+SGS_BENCH_SHARE_GPU=1 timeout 900 python $ROOT/bench.py --gpus 8 --steps 20 --warmup 5 --no-secondary > $OUT/bench_n8_shared_gpu.json 2> $OUT/bench_n8_shared_gpu.err; grep verify $OUT/bench_n8_shared_gpu.err
+SGS_BENCH_SHARE_GPU=1 timeout 900 python $ROOT/bench.py --gpus 8 --config 5 --steps 16 --warmup 4 --no-secondary > $OUT/bench_n8_shared_gpu_config5.json 2> $OUT/bench_n8_shared_gpu_config5.err; grep verify $OUT/bench_n8_shared_gpu_config5.err
 echo "== fp32 / compressed scene, the reference's resolutions (stage times alone)"; (cd $ROOT && timeout 400 python scripts/r05_probe.py fp32 packed lowres n=20 2>&1 | grep -v amdgpu.ids > $OUT/probe_fp32_packed_lowres.txt; cat $OUT/probe_fp32_packed_lowres.txt)
-echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres --no-upload-probe > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
+echo "== config 5 (3840x2160, 360-camera sweep)"; timeout 600 python $ROOT/bench.py --config 5 --no-cpu-baseline --no-lowres --no-trained --no-verify --no-upload-probe > $OUT/bench_config5.json 2> $OUT/bench_config5.err; tail -c 300 $OUT/bench_config5.json
 trace() { # name args...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-upload-probe --preheat-ms 0 "$@" > $OUT/$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/raw_$name -o trace -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-trained --no-verify --no-upload-probe --preheat-ms 0 "$@" > $OUT/$name.log 2>&1
   local db=$(find $OUT/raw_$name -name "*.db" | head -1)
   python $ROOT/scripts/rocpd_stats.py $db > $OUT/kernel_stats_$name.csv
   python $ROOT/scripts/rocpd_timeline.py $db ${WIN:-0.04 0.34} > $OUT/timeline_$name.txt 2>/dev/null
@@ -31,7 +34,7 @@ pmc() { # set name flags... -- counters...
   local set=$1 name=$2; shift 2
   local flags=()
   while [ "$1" != "--" ]; do flags+=("$1"); shift; done; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-pipeline --no-upload-probe --preheat-ms 0 "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/pmc_${set}_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-trained --no-verify --no-events --no-pipeline --no-upload-probe --preheat-ms 0 "${flags[@]}" > $OUT/pmc_${set}_$name.log 2>&1
   mkdir -p $OUT/pmc_$set
   find $OUT/pmc_${set}_$name -name "*counter_collection.csv" -exec cp {} $OUT/pmc_$set/$name.csv \;
   rm -rf $OUT/pmc_${set}_$name
@@ -48,7 +51,7 @@ passes() { # set skip flags...
 echo "== what a kernel waits for when it wants to start workgroups (VERDICT r3 item 1: SPI resource-allocation stalls, SQ wait cycles) — the default command, frames in flight"
 stall() { # name counters...
   local name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/stall_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-events --no-upload-probe --preheat-ms 0 > $OUT/stall_$name.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/stall_$name -o p -- python $ROOT/bench.py --no-cpu-baseline --no-lowres --no-trained --no-verify --no-events --no-upload-probe --preheat-ms 0 > $OUT/stall_$name.log 2>&1
   mkdir -p $OUT/stalls
   find $OUT/stall_$name -name "*counter_collection.csv" -exec cp {} $OUT/stalls/$name.csv \;
   rm -rf $OUT/stall_$name

@@ -167,13 +167,15 @@ def _pattern(b, rows, w):
         + 0.25 * torch.arange(3, dtype=torch.float32).view(1, 1, -1)
 
 
-def _batch_worker(rank, world, port, h, w, interleave, q):
+def _batch_worker(rank, world, port, h, w, interleave, exchange, q):
     """Batched bands: B frames per exchange, asynchronous, partial last batch, and — contiguous bands — a re-partition
-    into UNEQUAL bands between exchanges (the gatherv moves exact slabs; nothing is padded)."""
+    into UNEQUAL bands between exchanges (the gatherv moves exact slabs; nothing is padded).  exchange="slab": ONE operation per
+    peer and exchange (a contiguous [n, rows, W, C] slab, scattered into the frames on rank 0); "frames": one per (peer, frame)."""
     _init(rank, world, port)
     try:
         B = 4
-        g = FrameGather(h, w, torch.device("cpu"), batch=B, interleave=interleave)
+        g = FrameGather(h, w, torch.device("cpu"), batch=B, interleave=interleave, exchange=exchange)
+        assert g.mode == ("slab" if exchange == "slab" and not interleave else "frames")
         ok = True
         rounds = [(B, None), (3, None)]
         if not interleave:
@@ -202,6 +204,12 @@ def _batch_worker(rank, world, port, h, w, interleave, q):
             work = g.gather_batch(n, async_op=True)
             if work is not None:
                 work.wait()
+            # how many point-to-point operations this rank posted: the op count is the point of the slab mode
+            senders = [r for r in range(1, world) if g._rows_px(r) > 0]
+            per = 1 if g.mode == "slab" else n
+            ok = ok and g.last_ops == (per * len(senders) if rank == 0 else (per if rank in senders else 0))
+            if g.mode == "slab" and rank != 0:
+                ok = ok and g._slab.is_contiguous() and g._slab.shape[1] == g._rows_px(rank)
             if rank == 0:
                 for b in range(n):
                     f = g.frame(b)
@@ -217,10 +225,11 @@ def _batch_worker(rank, world, port, h, w, interleave, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,res,interleave", [(2, (112, 160), False), (3, (100, 72), False), (3, (100, 72), True)])
-def test_batched_tile_row_gather_gloo(world, res, interleave):
+@pytest.mark.parametrize("world,res,interleave,exchange", [(2, (112, 160), False, "frames"), (3, (100, 72), False, "frames"), (3, (100, 72), True, "frames"),
+                                                           (2, (112, 160), False, "slab"), (3, (100, 72), False, "slab"), (3, (100, 72), True, "slab")])
+def test_batched_tile_row_gather_gloo(world, res, interleave, exchange):
     h, w = res
-    assert _spawn(_batch_worker, world, h, w, interleave) is True
+    assert _spawn(_batch_worker, world, h, w, interleave, exchange) is True
 
 
 class _RowCopyRenderer:
@@ -290,9 +299,11 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
         # records per row: a moving "horizon" peak
         costs = np.array([[2000 + 60000 * np.exp(-0.5 * ((r - (2 + 0.4 * c)) / 1.0) ** 2) for r in range(gy)] for c in range(n_frames)]).astype(np.int64)
         rr = _RowCopyRenderer(frames, costs)
+        exchange = "frames" if mode.endswith("+frames") else "slab"            # (the default: one operation per peer and exchange)
+        mode = mode.replace("+frames", "")
         rgba8 = mode.startswith("rgba8")
         sr = ShardedRenderer(rr, h, w, batch=3, interleave=(mode == "interleave"), balance=mode.endswith("balance"),
-                             output="rgba8" if rgba8 else "float32")
+                             output="rgba8" if rgba8 else "float32", exchange=exchange)
         if rgba8:            # what rank 0 must end up with: the un-sharded frames, packed
             packed = torch.zeros((n_frames, h, w, 4), dtype=torch.uint8)
             for c in range(n_frames):
@@ -312,6 +323,9 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
             cams = list(range(c0, min(n_frames, c0 + 3)))
             g = sr.render_batch(cams, None)
             bands_seen.append(tuple(g.bands))
+            ok = ok and g.mode == ("frames" if (exchange == "frames" or mode == "interleave") else "slab")
+            if g.mode == "slab":
+                ok = ok and g.last_ops <= world - 1
             held.append((g, cams))
             if len(held) == 2:
                 g0, cams0 = held.pop(0)
@@ -346,7 +360,7 @@ def _sharded_worker(rank, world, port, h, w, mode, q):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "interleave"), (2, "balance"), (3, "balance"),
-                                        (2, "rgba8"), (3, "rgba8-balance")])
+                                        (2, "rgba8"), (3, "rgba8-balance"), (2, "even+frames"), (3, "balance+frames"), (3, "rgba8-balance+frames")])
 def test_sharded_renderer_host_logic_gloo(world, mode):
     assert _spawn(_sharded_worker, world, 150, 72, mode) is True
 
@@ -359,7 +373,7 @@ def _buffer_limit_worker(rank, world, port, q):
         h, w, batch = 160, 64, 4
         rr = _RowCopyRenderer(torch.zeros((1, h, w, 3)), np.zeros((1, (h + 15) // 16), np.int64))
         band_rows = -(-((h + 15) // 16) // world) * 16
-        own_dst, own_peer = 2 * batch * h * w * 12, 2 * batch * band_rows * w * 12
+        own_dst, own_peer = 2 * batch * h * w * 12 + 2 * batch * h * w * 12, 2 * batch * band_rows * w * 12      # (rank dst: frames + the staging of the slab exchange)
         assert own_peer < own_dst
         old = ShardedRenderer.MAX_BUFFER_BYTES
         ShardedRenderer.MAX_BUFFER_BYTES = (own_dst + own_peer) // 2            # only rank dst's own buffers exceed it
