@@ -101,6 +101,8 @@ def parse():
                          "PlayCanvas compressed .ply) loaded through sage_gs.ply with the reference's model->world transform "
                          "(template.usda:120); poses = the same pose generator over the scene's bounds")
     ap.add_argument("--compressed", action="store_true", help="--scene is a PlayCanvas compressed .ply")
+    ap.add_argument("--sh-decode", choices=("bin_centre", "linear255", "bin_centre_ends"), default=None,
+                    help="--compressed with SH coefficients: how a coefficient byte becomes a float (sage_gs.ply.decode_sh_bytes) — required, there is no default")
     ap.add_argument("--scene-kind", choices=("room", "trained"), default="room",
                     help="synthetic scene: make_room (BASELINE.md, default) or make_trained_like (trained-3DGS statistics: heavy-tailed "
                          "anisotropic scales, 40 %% nearly transparent splats, floaters, no spatial order)")
@@ -280,7 +282,7 @@ def main():
     # ---- workload: deterministic synthetic scene + pose list (identical on every rank) ---------------
     if args.scene:
         from sage_gs import ply
-        arrays = (ply.load_compressed_ply if args.compressed else ply.load_ply)(args.scene)
+        arrays = ply.load_compressed_ply(args.scene, sh_decode=args.sh_decode) if args.compressed else ply.load_ply(args.scene)
         scene = scenes.scene_from_arrays(arrays)                # model->world = template.usda:120; bounds -> where the eye points go
         args.gaussians = int(scene.means.shape[0])
         scene_desc = f"{os.path.basename(args.scene)} ({'PlayCanvas compressed' if args.compressed else '3DGS'} PLY, {args.gaussians} Gaussians, SH deg {scene.sh_degree})"
@@ -318,12 +320,12 @@ def main():
         hv = [t.cpu() for t in dv]
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        s3 = r.upload_compressed(hv[0], hv[1], hv[2], scene.sh_degree, model_to_world=scene.model_to_world); torch.cuda.synchronize(device)
+        s3 = r.upload_compressed(hv[0], hv[1], hv[2], scene.sh_degree, model_to_world=scene.model_to_world, sh_decode="bin_centre"); torch.cuda.synchronize(device)
         upload_ms["compressed_from_host"] = 1e3 * (time.perf_counter() - t0)
         s3.free()
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        s4 = r.upload_compressed(dv[0], dv[1], dv[2], scene.sh_degree, model_to_world=scene.model_to_world); torch.cuda.synchronize(device)
+        s4 = r.upload_compressed(dv[0], dv[1], dv[2], scene.sh_degree, model_to_world=scene.model_to_world, sh_decode="bin_centre"); torch.cuda.synchronize(device)
         upload_ms["compressed_on_device"] = 1e3 * (time.perf_counter() - t0)
         s4.free()
         del dv, hv, g_host
@@ -602,7 +604,7 @@ def main():
         gs_fp32, gs_packed = gs, None
         try:
             dvq = quantise_on_gpu(scenes.to_gaussians(scene, device))
-            gs_packed = r.upload_compressed(dvq[0], dvq[1], dvq[2], scene.sh_degree, model_to_world=scene.model_to_world)
+            gs_packed = r.upload_compressed(dvq[0], dvq[1], dvq[2], scene.sh_degree, model_to_world=scene.model_to_world, sh_decode="bin_centre")
             del dvq
             gs = gs_packed                       # (run_cameras renders `gs`; restored in `finally` whatever happens in between)
             measure(run_cameras, max(W, 8), max(W, 8), False)

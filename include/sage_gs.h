@@ -185,19 +185,22 @@ int sgs_scene_upload(sgs_ctx* ctx, int64_t n, int sh_degree, const float* means,
  *                          (11-10-11), packed_color (8-8-8-8), in THIS order
  *   sh[n][3 * ((d+1)^2-1)] the `sh` element's uint8 properties f_rest_*, in file order (channel-major); NULL at degree 0
  * sage_gs/ply.py (read_compressed_payload) produces exactly these from a file.  n_chunks must be ceil(n / 256). */
-enum { SGS_SH_DECODE_BIN_CENTRE = 0, SGS_SH_DECODE_LINEAR255 = 1, SGS_SH_DECODE_BIN_CENTRE_ENDS = 2 };
+enum { SGS_SH_DECODE_UNSPECIFIED = 0, SGS_SH_DECODE_LINEAR255 = 1, SGS_SH_DECODE_BIN_CENTRE_ENDS = 2, SGS_SH_DECODE_BIN_CENTRE = 3 };
 typedef struct sgs_compressed_scene {
     int64_t n;
     int64_t n_chunks;
     int32_t sh_degree;
-    int32_t sh_decode;     /* how an 8-bit SH coefficient v becomes a float (the field was `reserved_`, 0, before version 111):
-                            *   SGS_SH_DECODE_BIN_CENTRE (0)  v / 32 - 4 + 1 / 64: the centre of the truncation bin trunc((x / 8 + 0.5) * 256) the writer
-                            *                                 used — this repo's reading of the format since round 2, and the default;
-                            *   SGS_SH_DECODE_LINEAR255  (1)  v * 8 / 255 - 4: 0 -> -4, 255 -> +4, linear in between;
-                            *   SGS_SH_DECODE_BIN_CENTRE_ENDS (2)  as 0, but v = 0 -> -4 and v = 255 -> +4 exactly.
+    int32_t sh_decode;     /* how an 8-bit SH coefficient v becomes a float — REQUIRED when sh_degree > 0 (version 112: 0 = UNSPECIFIED is refused with
+                            * SGS_ERR_INVALID instead of silently meaning "bin centre" as in version 111; ignored at degree 0):
+                            *   SGS_SH_DECODE_BIN_CENTRE (3)  v / 32 - 4 + 1 / 64: the centre of the truncation bin trunc((x / 8 + 0.5) * 256) that the
+                            *                                 PlayCanvas WRITER (and sage_gs.ply.encode_compressed) puts x into;
+                            *   SGS_SH_DECODE_LINEAR255  (1)  v * 8 / 255 - 4: 0 -> -4, 255 -> +4, linear in between — to this builder's recollection what
+                            *                                 the PlayCanvas READERS (engine GSplatCompressedData, splat-transform's decompress) apply;
+                            *   SGS_SH_DECODE_BIN_CENTRE_ENDS (2)  bin centres, but v = 0 -> -4 and v = 255 -> +4 exactly.
                             * The three differ by at most 1 / 64 per coefficient.  The reference never decodes these bytes itself (README.md:197-231 hands
                             * the file to @playcanvas/splat-transform, un-vendored, unpinned and not installable here), so which of them that tool
-                            * applies cannot be pinned from this container: choose the one your converter uses.  Anything else: SGS_ERR_INVALID. */
+                            * applies cannot be pinned from this container — which is why there is no default: say which one your converter uses
+                            * (tests/golden/compressed_ply_kat.json lists every byte's value under all three). */
     const float* chunks;
     const uint32_t* packed;
     const uint8_t* sh;

@@ -810,15 +810,19 @@ int sgs_scene_upload_compressed(sgs_ctx* ctx, const sgs_compressed_scene* z, int
     const int64_t n = z->n;
     if (n < 0 || n > 0x7fffffffll) SGS_FAIL(ctx, SGS_ERR_INVALID, "n = %lld out of range", (long long)n);
     if (z->sh_degree < 0 || z->sh_degree > 3) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_degree %d not in 0..3", z->sh_degree);
-    if (z->sh_decode < SGS_SH_DECODE_BIN_CENTRE || z->sh_decode > SGS_SH_DECODE_BIN_CENTRE_ENDS) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_decode %d is not one of SGS_SH_DECODE_*", z->sh_decode);
     const int k_rest = (z->sh_degree + 1) * (z->sh_degree + 1) - 1;
+    if (z->sh_decode < SGS_SH_DECODE_UNSPECIFIED || z->sh_decode > SGS_SH_DECODE_BIN_CENTRE) SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_decode %d is not one of SGS_SH_DECODE_*", z->sh_decode);
+    if (k_rest > 0 && z->sh_decode == SGS_SH_DECODE_UNSPECIFIED)
+        SGS_FAIL(ctx, SGS_ERR_INVALID, "sh_decode is required for a scene with 8-bit SH coefficients (sh_degree %d): SGS_SH_DECODE_BIN_CENTRE, _LINEAR255 or "
+                                       "_BIN_CENTRE_ENDS — there is no default, include/sage_gs.h says why", z->sh_degree);
     if (n > 0 && (!z->chunks || !z->packed || (k_rest > 0 && !z->sh))) SGS_FAIL(ctx, SGS_ERR_INVALID, "null input array");
     if (z->n_chunks != (n + 255) / 256) SGS_FAIL(ctx, SGS_ERR_INVALID, "n_chunks %lld is not ceil(n / 256)", (long long)z->n_chunks);
     SGS_HIP(ctx, hipSetDevice(ctx->device));
     sgs_scene* sc = nullptr;
     int rc;
     if ((rc = new_scene(ctx, n, z->sh_degree, true, &sc)) != SGS_OK) return rc;
-    sc->sh_decode = z->sh_decode;
+    // (the kernels' mode: 0 = bin centre — one exact fma —, 1 = linear255, 2 = bin centre with exact ends)
+    sc->sh_decode = (z->sh_decode == SGS_SH_DECODE_BIN_CENTRE || z->sh_decode == SGS_SH_DECODE_UNSPECIFIED) ? 0 : z->sh_decode;
     if (n > 0) {
         const void* src[3] = {z->chunks, z->packed, z->sh};
         const size_t bytes[3] = {(size_t)z->n_chunks * 18 * 4, (size_t)n * 16, (size_t)n * 3 * k_rest};
@@ -1138,8 +1142,8 @@ int64_t sgs_debug_read(sgs_ctx* ctx, int what, void* host_dst, int64_t bytes) {
                 for (int j = 0; j < nf - 3; ++j) {      // sgs_kernels.h sgs_sh_byte / sgs_sh_byte_mode, restated: one correctly rounded fma (exact in double, rounded once)
                     const unsigned v = (w[(size_t)3 + (j >> 2)] >> (8 * (j & 3))) & 0xffu;
                     volatile double prod = (double)v * (8.0 / 255.0);         // (two roundings, as the kernel's __dmul_rn / __dsub_rn)
-                    float x = sc->sh_decode == SGS_SH_DECODE_LINEAR255 ? (float)(prod - 4.0) : (float)((double)v * (1.0 / 32.0) + (-4.0 + 1.0 / 64.0));
-                    if (sc->sh_decode == SGS_SH_DECODE_BIN_CENTRE_ENDS) x = v == 0u ? -4.0f : v == 255u ? 4.0f : x;
+                    float x = sc->sh_decode == 1 ? (float)(prod - 4.0) : (float)((double)v * (1.0 / 32.0) + (-4.0 + 1.0 / 64.0));
+                    if (sc->sh_decode == 2) x = v == 0u ? -4.0f : v == 255u ? 4.0f : x;
                     o[3 + j] = x;
                 }
             }

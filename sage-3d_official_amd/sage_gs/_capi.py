@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-SH_DECODE = {"bin_centre": 0, "linear255": 1, "bin_centre_ends": 2}      # include/sage_gs.h SGS_SH_DECODE_*
+SH_DECODE = {"bin_centre": 3, "linear255": 1, "bin_centre_ends": 2}      # include/sage_gs.h SGS_SH_DECODE_* (0 = unspecified: refused at degree > 0)
 ABI_VERSION = 112        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")

@@ -21,7 +21,7 @@ from __future__ import annotations
 
 import math
 import re
-from typing import Dict, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 
@@ -147,8 +147,12 @@ def _pack_111011(u):
     return (q[:, 0] << 21) | (q[:, 1] << 11) | q[:, 2]
 
 
-def load_compressed_ply(path, sh_decode: str = "bin_centre"):
+def load_compressed_ply(path, sh_decode: Optional[str] = None):
+    """sh_decode: decode_sh_bytes' mode — REQUIRED when the file has an `sh` element (no default, see decode_sh_bytes)."""
     el = read_elements(path)
+    if "sh" in el and sh_decode is None:
+        raise ValueError('this compressed.ply carries 8-bit SH coefficients: pass sh_decode="bin_centre", "linear255" or "bin_centre_ends" '
+                         "(what the tool that wrote / would decompress the file uses; there is no default)")
     ch, v = el["chunk"], el["vertex"]
     n = v.shape[0]
     ci = np.arange(n) // 256
@@ -202,11 +206,12 @@ PACKED_PROPS = ["packed_position", "packed_rotation", "packed_scale", "packed_co
 def decode_sh_bytes(v, mode: str = "bin_centre"):
     """8-bit SH coefficient(s) -> float32, three readings (include/sage_gs.h SGS_SH_DECODE_*; the device applies the same arithmetic):
       "bin_centre"       (v / 256 - 0.5) * 8 + 4 / 256 = v / 32 - 4 + 1 / 64 — the centre of the bin trunc((x / 8 + 0.5) * 256) that
-                         encode_compressed (and, as far as this repo can tell, the PlayCanvas writer) puts x into.  Exact in fp32.  DEFAULT.
-      "linear255"        v * 8 / 255 - 4: the end codes are -4 and +4.
+                         encode_compressed (and, as far as this repo can tell, the PlayCanvas writer) puts x into.  Exact in fp32.
+      "linear255"        v * 8 / 255 - 4: the end codes are -4 and +4 (to this builder's recollection what the PlayCanvas readers apply).
       "bin_centre_ends"  bin centres, but 0 -> -4 and 255 -> +4 exactly.
     They differ by at most 1/64 per coefficient.  The reference delegates this decode to @playcanvas/splat-transform (README.md:197-231),
-    which is neither vendored nor installable offline, so the tool's choice could not be pinned here — hence the option."""
+    which is neither vendored nor installable offline, so the tool's choice could not be pinned here — hence NO default anywhere a file's
+    bytes are read (load_compressed_ply, Renderer.upload_compressed, sgs_compressed_scene.sh_decode): the caller says which."""
     v = np.asarray(v)
     if mode == "linear255":
         return (v.astype(np.float64) * (8.0 / 255.0) - 4.0).astype(np.float32)      # in double, as a JavaScript converter computes it; the device does the same

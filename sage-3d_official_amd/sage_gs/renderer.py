@@ -82,7 +82,7 @@ class Scene:
 
     def __init__(self, renderer: "Renderer", handle, n, sh_degree, model_to_world):
         self._r, self.handle, self.n, self.sh_degree = renderer, handle, n, sh_degree
-        self.model_to_world = None if model_to_world is None else _check_model_to_world(model_to_world)
+        self.model_to_world = model_to_world            # (validated by Renderer.upload* BEFORE the upload: _check_model_to_world)
 
     def free(self):
         if self.handle:
@@ -117,15 +117,20 @@ def _rigid(views: np.ndarray) -> np.ndarray:
 
 def _check_model_to_world(m) -> np.ndarray:
     """A scene's model -> world transform must be RIGID (rotation + translation): the renderer applies it by moving the camera into model
-    space, which is exact only then.  Off by up to 2e-6 (a rotation written in fp32): accepted as it is.  Anything more — a scale, a
-    shear, a mirror — raises here, with the fix, instead of being silently re-orthonormalised (round 4) or rejected later by the
-    library's per-frame rigidity check with a message about the camera."""
-    m = np.asarray(m, np.float64).reshape(4, 4)
+    space, which is exact only then.  Off orthonormal by up to 2e-6 (a rotation written in fp32): accepted as it is.  Up to 1e-5 — what the
+    library itself tolerates; a product of two fp32 rotations lands at 1e-6 .. 5e-6 — the 3x3 is replaced by the nearest rotation (polar
+    decomposition): rounding noise, not a transform.  Anything more — a scale (a USD xformOp:scale of 1.0003 is a REAL scale: 6e-4), a shear,
+    a mirror — raises here, with the fix, instead of being silently re-orthonormalised (round 4) or rejected later by the library's
+    per-frame rigidity check with a message about the camera.  Called BEFORE the scene is uploaded: a refusal leaves nothing on the device."""
+    m = np.array(m, np.float64, copy=True).reshape(4, 4)
     r = m[:3, :3]
     dev = float(np.abs(r @ r.T - np.eye(3)).max())
-    if not (dev <= 2.0e-6) or not np.allclose(m[3], [0.0, 0.0, 0.0, 1.0], atol=1e-12) or np.linalg.det(r) < 0:
+    if not (dev <= 1.0e-5) or not np.allclose(m[3], [0.0, 0.0, 0.0, 1.0], atol=1e-12) or np.linalg.det(r) < 0:
         raise ValueError(f"model_to_world is not a rigid transform (its 3x3 is off orthonormal by {dev:.3g}): bake the asset's scale / shear into the "
                          "Gaussians' means and scales (a USD xformOp:scale s multiplies both) and pass the rotation + translation only")
+    if dev > 2.0e-6:
+        u, _, vt = np.linalg.svd(r)
+        m[:3, :3] = u @ vt
     return m
 
 
@@ -181,6 +186,7 @@ class Renderer:
 
     # -- scene ------------------------------------------------------------------------------------
     def upload(self, g: Gaussians) -> Scene:
+        m2w = None if g.model_to_world is None else _check_model_to_world(g.model_to_world)      # (raises before anything is on the device)
         n = len(g)
         k = (g.sh_degree + 1) ** 2
         with torch.cuda.device(self.device):
@@ -194,15 +200,18 @@ class Renderer:
             self._lib.check(self._lib.sgs_scene_upload(self._ctx, n, int(g.sh_degree), means.data_ptr(),
                                                        scales.data_ptr(), quats.data_ptr(), opac.data_ptr(),
                                                        sh.data_ptr(), 1, C.byref(h)), self._ctx)
-        return Scene(self, h, n, int(g.sh_degree), g.model_to_world)
+        return Scene(self, h, n, int(g.sh_degree), m2w)
 
-    def upload_compressed(self, chunks, packed, sh, sh_degree: int, model_to_world=None, sh_decode: str = "bin_centre") -> Scene:
+    def upload_compressed(self, chunks, packed, sh, sh_degree: int, model_to_world=None, sh_decode: Optional[str] = None) -> Scene:
         """A scene from the PlayCanvas compressed.ply payload (ply.read_compressed_payload: chunks float32 [nch,18], packed uint32 [n,4],
         sh uint8 [n, 3 k_rest] or None): copied to the device as it is — 16 B + SH bytes per Gaussian — and dequantised there by the
         layout kernel (sgs_scene_upload_compressed); the 8-bit SH coefficients stay bytes in HBM and are dequantised by the projection
         kernel every frame.  NumPy arrays or tensors; tensors already on this device are used in place.
-        sh_decode: how a coefficient byte becomes a float — "bin_centre" (default), "linear255" or "bin_centre_ends" (ply.decode_sh_bytes,
-        include/sage_gs.h SGS_SH_DECODE_*): pick what the tool that wrote / would decompress your file uses."""
+        sh_decode: how a coefficient byte becomes a float — "bin_centre", "linear255" or "bin_centre_ends" (ply.decode_sh_bytes,
+        include/sage_gs.h SGS_SH_DECODE_*).  REQUIRED at degree > 0, no default: the tool the reference delegates the decode to could not be
+        inspected offline, so say what the tool that wrote / would decompress your file uses."""
+        m2w = None if model_to_world is None else _check_model_to_world(model_to_world)          # (raises before anything is on the device)
+
         def dev(a, dt):
             if a is None:
                 return None
@@ -220,13 +229,16 @@ class Renderer:
             k_rest = (int(sh_degree) + 1) ** 2 - 1
             if (k_rest > 0) != (b is not None) or (b is not None and tuple(b.shape) != (n, 3 * k_rest)):
                 raise ValueError(f"sh must be uint8 [n, {3 * k_rest}] at degree {sh_degree} (None at degree 0)")
-            if sh_decode not in _capi.SH_DECODE:
+            if k_rest > 0 and sh_decode is None:
+                raise ValueError(f"sh_decode is required for a scene with 8-bit SH coefficients: one of {sorted(_capi.SH_DECODE)} (there is no "
+                                 "default: ply.decode_sh_bytes / include/sage_gs.h say why)")
+            if sh_decode is not None and sh_decode not in _capi.SH_DECODE:
                 raise ValueError(f"sh_decode must be one of {sorted(_capi.SH_DECODE)}")
-            z = _capi.SgsCompressedScene(n, nch, int(sh_degree), _capi.SH_DECODE[sh_decode], c.data_ptr(), p.data_ptr(), b.data_ptr() if b is not None else None)
+            z = _capi.SgsCompressedScene(n, nch, int(sh_degree), _capi.SH_DECODE[sh_decode] if sh_decode is not None else 0, c.data_ptr(), p.data_ptr(), b.data_ptr() if b is not None else None)
             torch.cuda.synchronize(self.device)
             h = C.c_void_p()
             self._lib.check(self._lib.sgs_scene_upload_compressed(self._ctx, C.byref(z), 1, C.byref(h)), self._ctx)
-        return Scene(self, h, n, int(sh_degree), model_to_world)
+        return Scene(self, h, n, int(sh_degree), m2w)
 
     def _scene_of(self, g):
         if isinstance(g, Scene):

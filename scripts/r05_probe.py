@@ -80,7 +80,7 @@ for libname in LIBS:
         if mode == "packed":
             from bench import quantise_on_gpu
             dv = quantise_on_gpu(g_dev)
-            gs = r.upload_compressed(dv[0], dv[1], dv[2], sc.sh_degree, model_to_world=sc.model_to_world)
+            gs = r.upload_compressed(dv[0], dv[1], dv[2], sc.sh_degree, model_to_world=sc.model_to_world, sh_decode="bin_centre")
             del dv
         else:
             gs = r.upload(g_dev)

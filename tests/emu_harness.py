@@ -66,13 +66,13 @@ class EmuRenderer:
         self.scene = sc
         self.n = arrs[0].shape[0]
 
-    def upload_compressed(self, chunks, packed, sh, sh_degree, sh_decode="bin_centre"):
+    def upload_compressed(self, chunks, packed, sh, sh_degree, sh_decode=None):
         """sgs_scene_upload_compressed with host buffers (ply.read_compressed_payload's arrays)."""
         c = np.ascontiguousarray(chunks, np.float32); p = np.ascontiguousarray(packed, np.uint32)
         b = None if sh is None else np.ascontiguousarray(sh, np.uint8)
         if self.scene is not None:
             self.lib.sgs_scene_free(self.ctx, self.scene)
-        z = _capi.SgsCompressedScene(p.shape[0], c.shape[0], int(sh_degree), sh_decode if isinstance(sh_decode, int) else _capi.SH_DECODE[sh_decode], c.ctypes.data, p.ctypes.data, b.ctypes.data if b is not None else None)
+        z = _capi.SgsCompressedScene(p.shape[0], c.shape[0], int(sh_degree), 0 if sh_decode is None else sh_decode if isinstance(sh_decode, int) else _capi.SH_DECODE[sh_decode], c.ctypes.data, p.ctypes.data, b.ctypes.data if b is not None else None)
         sc = C.c_void_p()
         self.lib.check(self.lib.sgs_scene_upload_compressed(self.ctx, C.byref(z), 0, C.byref(sc)), self.ctx)
         self.scene, self.n = sc, p.shape[0]

@@ -11,8 +11,12 @@ Layout (little-endian uint32 per field):
                                    the other three in (w,x,y,z) order, (field / 1023 - 0.5) * sqrt(2); dropped = sqrt(1 - sum of squares)
   packed_color                     bits 31..24 r, 23..16 g, 15..8 b, 7..0 opacity, / 255; f_dc = (c - 0.5) / 0.28209479177387814 (with the
                                    chunk's colour range, if any: c = min + value (max - min))
-  sh bytes                         f_rest = (byte / 256 - 0.5) * 8 + 4 / 256   (the writer stores trunc((f / 8 + 0.5) * 256): this is the
-                                   centre of the byte's cell — the one constant of this file that is this repo's reading, see ply.py)
+  sh bytes                         three candidate readings, all listed per byte (the writer stores trunc((f / 8 + 0.5) * 256)):
+                                   bin centre (byte / 256 - 0.5) * 8 + 4 / 256, linear byte * 8 / 255 - 4, bin centre with exact ends;
+                                   f_rest_k is channel-major: k = channel * k_rest + (coefficient - 1)
+
+Nothing in this file imports sage_gs: the expected values are NOT produced by the repo's encoder or decoder (ply.encode_compressed,
+ply.load_compressed_ply, the layout kernel) — those are what the vectors are held against.
 """
 import json
 from decimal import Decimal, getcontext
@@ -57,7 +61,17 @@ for word in (0x00000000, 0xFFFFFFFF, 0x80808080, 0x10C0FF7F, 0xFF000001, 0x33669
     c = [Decimal(field(word, 31, 8)) / 255, Decimal(field(word, 23, 8)) / 255, Decimal(field(word, 15, 8)) / 255]
     cases.append({"field": "packed_color", "word": f"0x{word:08X}", "expect_dc": [float((v - Decimal("0.5")) / C0) for v in c],
                   "expect_opacity": float(Decimal(field(word, 7, 8)) / 255)})
-for byte in (0, 1, 127, 128, 200, 255):
-    cases.append({"field": "sh_byte", "byte": byte, "expect": float((Decimal(byte) / 256 - Decimal("0.5")) * 8 + Decimal(4) / 256)})
+# An SH byte has THREE candidate readings (include/sage_gs.h SGS_SH_DECODE_*; which one @playcanvas/splat-transform applies cannot be pinned
+# offline, so the caller must say): the centre of the writer's truncation bin, the linear map onto [-4, 4], and bin centres with exact ends.
+# All three in exact arithmetic, end codes included:
+for byte in (0, 1, 127, 128, 200, 254, 255):
+    centre = (Decimal(byte) / 256 - Decimal("0.5")) * 8 + Decimal(4) / 256
+    cases.append({"field": "sh_byte", "byte": byte, "expect": float(centre),
+                  "expect_linear255": float(Decimal(byte) * 8 / 255 - 4),
+                  "expect_bin_centre_ends": float(Decimal(-4) if byte == 0 else Decimal(4) if byte == 255 else centre)})
+# ... and WHERE a byte goes: the file's f_rest_k properties are channel-major (k = channel * 15 + coefficient - 1 at degree 3); the renderer
+# takes [coefficient][channel].  One vertex whose 45 bytes are 5 k + 3: coefficient c (1..15), channel ch must decode byte 5 (15 ch + c - 1) + 3.
+cases.append({"field": "sh_order", "bytes": [5 * k + 3 for k in range(45)],
+              "expect": [[float((Decimal(5 * (15 * ch + c) + 3) / 256 - Decimal("0.5")) * 8 + Decimal(4) / 256) for ch in range(3)] for c in range(15)]})
 print(json.dumps({"chunk": {k: [float(dec(x)) for x in v] for k, v in chunk.items()}, "cases": cases,
                   "note": "tests/golden/make_compressed_kat.py: hand-written words, exact arithmetic; fp32 decoders must agree to ~1e-6 relative"}, indent=1))

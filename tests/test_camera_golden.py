@@ -171,7 +171,8 @@ def test_isaac_pose_from_view_inverts_view_from_isaac_pose():
 
 def test_pose_projection_and_asset_transform_validation():
     """Python surface (renderer._rigid / _check_model_to_world): a camera pose with fp32-composition noise is projected onto the nearest
-    rotation, an orthonormal one passes bit for bit, and a scene's model_to_world is NOT projected: rigid to 2e-6 or refused — a USD
+    rotation, an orthonormal one passes bit for bit; a scene's model_to_world passes as it is when rigid to 2e-6, is projected when it is
+    off by rounding noise (a product of fp32 rotations: up to the 1e-5 the library itself tolerates) and is REFUSED beyond that — a USD
     xformOp:scale of 1.0003 is a real scale (it used to be silently re-orthonormalised away)."""
     from sage_gs import renderer, scenes
     rng = np.random.default_rng(0)
@@ -186,6 +187,14 @@ def test_pose_projection_and_asset_transform_validation():
     far = V.copy(); far[:3, :3] *= 1.01
     assert np.array_equal(renderer._rigid(far), far)                  # not rounding noise: left for the library to refuse
     assert np.array_equal(renderer._check_model_to_world(scenes.MODEL_TO_WORLD), np.asarray(scenes.MODEL_TO_WORLD, np.float64))
+    # a rotation composed in fp32 (two fp32 rotations multiplied in fp32): 1e-6 .. 5e-6 off — accepted, as the nearest rotation
+    a32 = q.astype(np.float32); b32 = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+    comp = np.eye(4); comp[:3, :3] = (a32 @ b32 @ a32.T @ b32).astype(np.float64) + 3e-6 * rng.normal(size=(3, 3))
+    comp[:3, :3] *= np.sign(np.linalg.det(comp[:3, :3]))
+    dev = np.abs(comp[:3, :3] @ comp[:3, :3].T - np.eye(3)).max()
+    assert 2e-6 < dev < 1e-5, dev
+    got = renderer._check_model_to_world(comp)
+    assert np.abs(got[:3, :3] @ got[:3, :3].T - np.eye(3)).max() < 1e-12 and np.abs(got - comp).max() < 1e-5 and np.array_equal(got[:3, 3], comp[:3, 3])
     for bad in (np.diag([1.0003, 1.0003, 1.0003, 1.0]), np.diag([1.0, -1.0, 1.0, 1.0]), np.array([[1, 1e-3, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]])):
         with pytest.raises(ValueError, match="not a rigid transform"):
             renderer._check_model_to_world(bad)

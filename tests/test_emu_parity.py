@@ -275,12 +275,18 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
     d = emu_harness.EmuRenderer(record_capacity=1 << 20)
     try:
         cases, chunks, packed, shb = _kat_payload()
-        d.upload_compressed(chunks, packed, shb, 3)
+        d.upload_compressed(chunks, packed, shb, 3, sh_decode="bin_centre")
         cam = onp.Camera(64, 48, 50.0, 50.0, 32.0, 24.0, np.eye(4, dtype=np.float32))
         d.render(cam)
         g = d.scene_geom()
         assert g.shape == (len(cases), 11)
         _check_kat(cases, g[:, 0:3], g[:, 4:7], g[:, 7:11], g[:, 3], None, None)
+        # the SH bytes under all three readings, and where a byte of the channel-major file order lands in [coefficient][channel]
+        for mode in ("bin_centre", "linear255", "bin_centre_ends"):
+            d.upload_compressed(chunks, packed, shb, 3, sh_decode=mode)
+            d.render(cam)
+            shd = d.scene_sh()
+            _check_kat(cases, None, None, None, None, None, shd[:, 1:, :], mode=mode)
         # a scene of a few chunks (so that the radix sort has several tiles... of one workgroup each), degree 3 and degree 0
         rng = np.random.default_rng(12)
         n = 5000
@@ -293,10 +299,10 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
         for deg in (3, 0):
             path = str(tmp_path / f"c{deg}.ply")
             ply.save_compressed_ply(path, means, scales, quats, opac, sh[:, :(deg + 1) ** 2], deg)
-            arrays = ply.load_compressed_ply(path)
+            arrays = ply.load_compressed_ply(path, sh_decode="bin_centre")
             d.upload(*arrays)
             ref, st_ref = d.render(cam)
-            d.upload_compressed(*ply.read_compressed_payload(path))
+            d.upload_compressed(*ply.read_compressed_payload(path), sh_decode="bin_centre")
             img, st = d.render(cam)
             g = d.scene_geom()
             assert np.allclose(g[:, 0:3], arrays[0], atol=1e-6) and np.allclose(g[:, 4:7], arrays[1], rtol=3e-6) and np.allclose(g[:, 3], arrays[3], atol=1e-7)
@@ -334,6 +340,11 @@ def test_compressed_upload_decodes_on_the_device_and_sorts_in_z_order(tmp_path):
                 bad = _capi.SgsCompressedScene(n, payload[0].shape[0], deg, 7, payload[0].ctypes.data, np.ascontiguousarray(payload[1], np.uint32).ctypes.data, shb.ctypes.data)
                 h = C.c_void_p()
                 assert d.lib.sgs_scene_upload_compressed(d.ctx, C.byref(bad), 0, C.byref(h)) == -1 and b"sh_decode" in d.lib.sgs_last_error(d.ctx)
+                # ... and there is NO default: a scene with coefficient bytes and sh_decode = 0 (unspecified) is refused, with a message
+                unset = _capi.SgsCompressedScene(n, payload[0].shape[0], deg, 0, payload[0].ctypes.data, np.ascontiguousarray(payload[1], np.uint32).ctypes.data, shb.ctypes.data)
+                assert d.lib.sgs_scene_upload_compressed(d.ctx, C.byref(unset), 0, C.byref(h)) == -1 and b"sh_decode is required" in d.lib.sgs_last_error(d.ctx)
+            else:
+                d.upload_compressed(*ply.read_compressed_payload(path))                # degree 0: no coefficient bytes, nothing to specify
     finally:
         d.close()
 

@@ -699,11 +699,11 @@ def test_compressed_ply_scene_against_the_oracle(drv, tmp_path, deg):
     m, s_, q, o, sh = m[key], s_[key], q[key], o[key], sh[key][:, :(deg + 1) ** 2]
     path = str(tmp_path / f"room_c{deg}.ply")
     ply.save_compressed_ply(path, m, s_, q, o, sh, deg)
-    arrays = ply.load_compressed_ply(path)
+    arrays = ply.load_compressed_ply(path, sh_decode="bin_centre")
     assert arrays[5] == deg
     payload = ply.read_compressed_payload(path)
     assert payload[1].shape == (30_000, 4) and (payload[2] is None) == (deg == 0)
-    scene = drv.r.upload_compressed(*payload, model_to_world=sc.model_to_world)
+    scene = drv.r.upload_compressed(*payload, model_to_world=sc.model_to_world, sh_decode="bin_centre")
     cams = scenes.room_cameras(sc, 640, 480, n_positions=1, n_yaw=4, seed=9)[1:3]
     for cam in cams:
         img = drv.r.render(cam, scene).cpu().numpy()
@@ -744,7 +744,7 @@ def test_compressed_scene_keeps_its_sh_bytes_in_hbm_and_renders_the_same_frames(
     ply.save_compressed_ply(path, m, s_, q, o, sh, deg)
     chunks, packed, shb, deg_file = ply.read_compressed_payload(path)
     assert deg_file == deg
-    scene_c = drv.r.upload_compressed(chunks, packed, shb, deg, model_to_world=sc.model_to_world)
+    scene_c = drv.r.upload_compressed(chunks, packed, shb, deg, model_to_world=sc.model_to_world, sh_decode="bin_centre")
     cams = scenes.room_cameras(sc, 1024, 768, n_positions=2, n_yaw=4, seed=4)[:5]
     frames, stats = [], []
     for cam in cams:
@@ -942,3 +942,28 @@ def test_frames_do_not_depend_on_the_tuning(drv):
         with pytest.raises(Exception, match="sgs_tuning"):
             r.set_tuning(**bad)
     r.close()
+
+
+def test_compressed_payload_known_answer_vectors_on_the_device(drv):
+    """tests/golden/compressed_ply_kat.json — packed words written out by hand from the PlayCanvas layout (11-10-11 / 2+10-10-10 / 8-8-8-8,
+    chunk min / max lerp, 8-bit SH), expected values in exact rational arithmetic by a script that imports nothing of this repo — through
+    sgs_scene_upload_compressed on the GPU: what the layout kernel dequantised (SGS_BUF_SCENE_GEOM) and what k_preprocess evaluates
+    (SGS_BUF_SCENE_SH) under each of the three readings of a coefficient byte; sh_decode has no default."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_next_rows import _kat_payload, _check_kat
+    from sage_gs import Camera, _capi
+    cases, chunks, packed, shb = _kat_payload()
+    n = len(cases)
+    cam = Camera(64, 48, 50.0, 50.0, 32.0, 24.0, np.eye(4))
+    for mode in ("bin_centre", "linear255", "bin_centre_ends"):
+        scene = drv.r.upload_compressed(chunks, packed, shb, 3, sh_decode=mode)
+        drv.r.render(cam, scene)
+        g = drv.r.debug_buffer(_capi.BUF_SCENE_GEOM, np.float32).reshape(-1, 11)
+        shd = drv.r.debug_buffer(_capi.BUF_SCENE_SH, np.float32).reshape(n, -1, 3)
+        assert g.shape == (n, 11) and shd.shape == (n, 16, 3)
+        _check_kat(cases, g[:, 0:3], g[:, 4:7], g[:, 7:11], g[:, 3], shd[:, 0, :], shd[:, 1:, :], mode=mode)
+        scene.free()
+    with pytest.raises(ValueError, match="sh_decode"):
+        drv.r.upload_compressed(chunks, packed, shb, 3)
+    drv.r.upload_compressed(chunks, packed, None, 0).free()            # degree 0: no coefficient bytes, nothing to specify

@@ -55,7 +55,7 @@ def test_compressed_ply_round_trip(tmp_path):
     q = q / np.linalg.norm(q, axis=1, keepdims=True)
     path = str(tmp_path / "c.ply")
     ply.save_compressed_ply(path, m, s, q, o, sh, 0)
-    m2, s2, q2, o2, sh2, d2 = ply.load_compressed_ply(path)
+    m2, s2, q2, o2, sh2, d2 = ply.load_compressed_ply(path, sh_decode="bin_centre")
     assert d2 == 0
     span = m.max(0) - m.min(0)
     assert np.abs(m2 - m).max() < span.max() / 1000.0
@@ -146,7 +146,7 @@ def test_compressed_ply_decoder_on_hand_assembled_bytes(tmp_path):
             f.write(struct.pack("<4I", *v))
         for row in sh_bytes:
             f.write(bytes(row))
-    m, s, q, o, sh, deg = ply.load_compressed_ply(path)
+    m, s, q, o, sh, deg = ply.load_compressed_ply(path, sh_decode="bin_centre")
     assert deg == 3 and sh.shape == (3, 16, 3) and m.dtype == np.float32
     # positions: lerp(min, max, code / (2^bits - 1))
     assert np.allclose(m[0], [10.0, -1.0, 2.0 + 2.0 * 1024 / 2047], atol=1e-6)
@@ -333,16 +333,27 @@ def _kat_payload():
     for i, c in enumerate(cases):
         if c["field"] == "sh_byte":
             shb[i, :] = c["byte"]
+        elif c["field"] == "sh_order":
+            shb[i, :] = c["bytes"]
         else:
             packed[i, col[c["field"]]] = int(c["word"], 16)
     return cases, chunks, packed, shb
 
 
-def _check_kat(cases, means, scales, quats, opac, sh_dc, sh_rest, rtol=3e-6):
+def _check_kat(cases, means, scales, quats, opac, sh_dc, sh_rest, rtol=3e-6, mode="bin_centre"):
+    """sh_rest: [n, 15, 3] ([coefficient][channel]) or its [n, 45] flattening, decoded with `mode`; any argument may be None (not checked)."""
     close = lambda a, b: np.allclose(np.asarray(a, np.float64), np.asarray(b, np.float64), rtol=rtol, atol=2e-6)
+    key = {"bin_centre": "expect", "linear255": "expect_linear255", "bin_centre_ends": "expect_bin_centre_ends"}[mode]
     for i, c in enumerate(cases):
         f = c["field"]
-        if f == "packed_position":
+        if means is None and f.startswith("packed"):
+            continue
+        if f == "sh_order" and sh_rest is not None and mode == "bin_centre":
+            assert close(np.asarray(sh_rest[i]).reshape(15, 3), c["expect"]), (i, np.asarray(sh_rest[i]).reshape(15, 3)[:2])
+        elif f == "sh_byte" and sh_rest is not None:
+            got = np.asarray(sh_rest[i], np.float64)
+            assert np.abs(got - c[key]).max() <= 1e-7 + 2e-7 * abs(c[key]), (i, c, mode, got.ravel()[:3])        # (fp32 rounding of an exact rational)
+        elif f == "packed_position":
             assert close(means[i], c["expect"]), (i, c, means[i])
         elif f == "packed_scale":
             assert close(scales[i], c["expect"]), (i, c, scales[i])
@@ -350,8 +361,6 @@ def _check_kat(cases, means, scales, quats, opac, sh_dc, sh_rest, rtol=3e-6):
             assert close(quats[i], c["expect"]), (i, c, quats[i])
         elif f == "packed_color":
             assert close(opac[i], c["expect_opacity"]) and (sh_dc is None or close(sh_dc[i], c["expect_dc"])), (i, c, opac[i])
-        elif f == "sh_byte" and sh_rest is not None:
-            assert close(sh_rest[i], np.full_like(sh_rest[i], c["expect"])), (i, c, sh_rest[i][:3])
 
 
 def test_compressed_ply_known_answer_vectors(tmp_path):
@@ -373,9 +382,13 @@ def test_compressed_ply_known_answer_vectors(tmp_path):
             f.write(f"property uchar f_rest_{k}\n".encode())
         f.write(b"end_header\n")
         f.write(chunks.astype("<f4").tobytes()); f.write(packed.astype("<u4").tobytes()); f.write(shb.tobytes())
-    m, s, q, o, sh, deg = ply.load_compressed_ply(str(path))
+    m, s, q, o, sh, deg = ply.load_compressed_ply(str(path), sh_decode="bin_centre")
     assert deg == 3 and sh.shape == (n, 16, 3)
-    _check_kat(cases, m, s, q, o, sh[:, 0, :], sh[:, 1:, :].reshape(n, -1))
+    _check_kat(cases, m, s, q, o, sh[:, 0, :], sh[:, 1:, :])
+    for mode in ("linear255", "bin_centre_ends"):               # the other two readings of a coefficient byte
+        _check_kat(cases, None, None, None, None, None, ply.load_compressed_ply(str(path), sh_decode=mode)[4][:, 1:, :], mode=mode)
+    with pytest.raises(ValueError, match="sh_decode"):          # ... and no default: the caller has to say which
+        ply.load_compressed_ply(str(path))
     c2, p2, b2, d2 = ply.read_compressed_payload(str(path))
     assert d2 == 3 and (c2 == chunks).all() and (p2 == packed).all() and (b2 == shb).all()
 
@@ -391,7 +404,7 @@ def test_compressed_encoder_round_trip_with_sh(tmp_path):
     sh = (rng.normal(size=(n, 16, 3)) * 0.4).astype(np.float32)
     path = str(tmp_path / "c3.ply")
     ply.save_compressed_ply(path, means, scales, quats, opac, sh, 3)
-    m, s, q, o, sh2, deg = ply.load_compressed_ply(path)
+    m, s, q, o, sh2, deg = ply.load_compressed_ply(path, sh_decode="bin_centre")
     assert deg == 3
     span = np.ptp(means, axis=0).max()
     assert np.abs(m - means).max() <= span / 1023 and np.abs(np.log(s / scales)).max() <= np.ptp(np.log(scales)) / 1023
