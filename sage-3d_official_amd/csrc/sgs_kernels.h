@@ -1106,26 +1106,65 @@ __device__ __forceinline__ void bin_walk(const SuperGrid& SG, const uint4* __res
                     }
                 }
             }
-        } else if (on) {
-            // lane-major: every lane walks its own rect, SGS_WALK_TILES cells per trip; every cell's (row, column) comes from
-            // its own index (i + 0.5) / w — exact in fp32 for rects of up to 256 cells — and the LDS atomics of a trip are
-            // all in flight together
-            const unsigned w = x1 - x0;
-            const float rw = 1.0f / (float)w;
-            const unsigned origin = y0 * (unsigned)SG.gxs + x0;
-            for (unsigned i = 0; i < cnt; i += SGS_WALK_TILES) {
-                unsigned tl[SGS_WALK_TILES], dst[SGS_WALK_TILES];
+        } else {
+            // lane-major for the SMALL rects: every lane walks its own, SGS_WALK_TILES cells per trip; every cell's (row, column) comes
+            // from its own index (i + 0.5) / w — exact in fp32 for rects of up to 2^21 cells — and the LDS atomics of a trip are all in
+            // flight together.
+            // A LARGER rect is walked by the WHOLE WAVE instead (round 6): its owner's record is read into scalar
+            // registers (v_readlane) and the 64 lanes take the cells 64 at a time — distinct cells, so the LDS atomics of a trip do not
+            // collide, and in the emit the record goes out as one broadcast store per cell.  Left to its owner, a lane with a 100-cell
+            // rect kept its wave for 13 trips while 63 lanes waited: on a scene with trained-3DGS statistics (heavy-tailed scales: 3.9
+            // super-tiles per splat on average, a long tail up to SGS_BIG_RECT) the walk was 36-51 k of k_bin_count's 67-88 k cycles per
+            // workgroup (profiles/r06e_bin_prof.txt).
+            // Which rects count as "more than a lane should walk" is decided per chunk (wave-uniform): with the threshold at T cells the
+            // lane-major part takes T / 8 trips (all lanes side by side) and every rect above it one or two passes of the whole wave, which
+            // cost about two trips each — twenty lanes with 12-cell rects are two lane-major trips, not twenty passes (T = 8 for every
+            // chunk made the room scene's binning 4 % slower, profiles/r06g).
+            unsigned T = SGS_WALK_TILES, best = ~0u;
 #pragma unroll
-                for (int u = 0; u < SGS_WALK_TILES; ++u) {
-                    const unsigned iu = i + (unsigned)u;
-                    const unsigned ty = (unsigned)(((float)iu + 0.5f) * rw);
-                    tl[u] = origin + ty * (unsigned)SG.gxs + (iu - ty * w);
+            for (unsigned cand = SGS_WALK_TILES; cand <= 16u * SGS_WALK_TILES; cand <<= 1) {
+                const unsigned cost = cand / SGS_WALK_TILES + 2u * (unsigned)__popcll(__ballot(on && cnt > cand));
+                if (cost < best) { best = cost; T = cand; }
+            }
+            const bool coop = on && cnt > T;
+            if (on && !coop) {
+                const unsigned w = x1 - x0;
+                const float rw = 1.0f / (float)w;
+                const unsigned origin = y0 * (unsigned)SG.gxs + x0;
+                for (unsigned i = 0; i < cnt; i += SGS_WALK_TILES) {
+                    unsigned tl[SGS_WALK_TILES], dst[SGS_WALK_TILES];
+#pragma unroll
+                    for (int u = 0; u < SGS_WALK_TILES; ++u) {
+                        const unsigned iu = i + (unsigned)u;
+                        const unsigned ty = (unsigned)(((float)iu + 0.5f) * rw);
+                        tl[u] = origin + ty * (unsigned)SG.gxs + (iu - ty * w);
+                    }
+#pragma unroll
+                    for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
+                    if (EMIT) {
+#pragma unroll
+                        for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) srec[dst[u]] = br;
+                    }
                 }
-#pragma unroll
-                for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) dst[u] = atomicAdd(&s_arr[tl[u]], 1u);
+            }
+            unsigned long long cm = __ballot(coop);
+            while (cm != 0ull) {                                      // (wave-uniform)
+                const int src = __ffsll((long long)cm) - 1;
+                cm &= cm - 1ull;
+                const unsigned rx0 = (unsigned)__builtin_amdgcn_readlane((int)x0, src), rx1 = (unsigned)__builtin_amdgcn_readlane((int)x1, src);
+                const unsigned ry0 = (unsigned)__builtin_amdgcn_readlane((int)y0, src), ry1 = (unsigned)__builtin_amdgcn_readlane((int)y1, src);
+                uint4 rbr = {0u, 0u, 0u, 0u};
                 if (EMIT) {
-#pragma unroll
-                    for (int u = 0; u < SGS_WALK_TILES; ++u) if (i + (unsigned)u < cnt) srec[dst[u]] = br;
+                    rbr.x = (unsigned)__builtin_amdgcn_readlane((int)br.x, src); rbr.y = (unsigned)__builtin_amdgcn_readlane((int)br.y, src);
+                    rbr.z = (unsigned)__builtin_amdgcn_readlane((int)br.z, src); rbr.w = (unsigned)__builtin_amdgcn_readlane((int)br.w, src);
+                }
+                const unsigned w = rx1 - rx0, total = w * (ry1 - ry0);
+                const float rw = 1.0f / (float)w;
+                const unsigned origin = ry0 * (unsigned)SG.gxs + rx0;
+                for (unsigned k = (unsigned)lane; k < total; k += 64u) {
+                    const unsigned ty = (unsigned)(((float)k + 0.5f) * rw);
+                    const unsigned d = atomicAdd(&s_arr[origin + ty * (unsigned)SG.gxs + (k - ty * w)], 1u);
+                    if (EMIT) srec[d] = rbr;
                 }
             }
         }

@@ -13,10 +13,11 @@ args = sys.argv[1:]
 modes = [a for a in args if a in ("fp32", "packed")] or ["fp32"]
 N = next((int(a[2:]) for a in args if a.startswith("n=")), 24)
 dev = torch.device("cuda", 0)
-sc = scenes.cached_room(3_000_000, seed=2)
+sc = scenes.make_trained_like(3_000_000, seed=2) if "trained" in args else scenes.cached_room(3_000_000, seed=2)
 STAGES = ("preprocess", "count", "emit", "render")
 poses = [(i * 77) % 256 for i in range(5, 105)]
 tag = os.path.basename(os.environ.get("SAGE_GS_LIB", "default"))
+SCENE_TAG = "trained" if "trained" in args else "room"
 LIBS = next((a[5:].split(",") for a in args if a.startswith("libs=")), [None])
 
 
@@ -88,7 +89,7 @@ for libname in LIBS:
             cams = scenes.room_cameras(sc, w, h, n_positions=4, n_yaw=64, seed=2)
             ring = [torch.zeros((h, w, 3), dtype=torch.float32, device=dev) for _ in range(4)]
             a = alone(r, gs, cams, ring[0], N)
-            line = f"[{tag}] {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
+            line = f"[{tag}] {SCENE_TAG} {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
             if (w, h) == (1920, 1080):
                 line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame | render_batch x20 {rate_batch(r, gs, cams, 20):.4f} x100 {rate_batch(r, gs, cams, 100):.4f}"
             else:
