@@ -425,6 +425,54 @@ def test_3m_scene_full_frames_vs_oracle_at_the_bench_poses(drv, big_scene):
     assert min(d_f) > 100_000
 
 
+def test_3m_scene_more_bench_poses_images_and_counts_vs_oracle(drv, big_scene):
+    """Twenty-two more poses of the bench's sweep (steps 16-37), whole frames: N_v, D (reference binning) and every pixel against the oracle —
+    with the ten of the test above, every eighth pose of the 256 the headline is measured on has been held against the oracle."""
+    from sage_gs import scenes
+    sc, _ = big_scene
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=4, n_yaw=64, seed=2)
+    drv.upload(*sc.as_tuple())
+    for pid in _bench_pose_ids(range(16, 38)):
+        ocam = _ocam(cams[pid], sc)
+        img, st = drv.render(ocam, stats=False)                          # the instantiation the sweep runs
+        img_ref, st_ref = drv.render(ocam, loose_cull=True)
+        ref, aux = oracle_c.render(*sc.as_tuple(), ocam, want="image")
+        assert (img_ref == img).all() and st["n_visible"] == aux["n_visible"] and st_ref["d_total"] == aux["D"] and st["d_total"] <= aux["D"]
+        assert_frame_close(img, ref, aux["margin"], aux["recheck"], what=f"3M @1080p bench pose {pid} (image + counts)")
+        aux["recheck"].close()
+
+
+def test_3m_scene_at_the_reference_resolutions_vs_oracle(drv, big_scene):
+    """The 3 M-Gaussian scene at the resolutions the reference itself renders (run_benchmark.py:1409-1419 --low-res 320x240, simple_env.py:52
+    640x480, generate_images.py:43 1024x768), whole frames through check_against_oracle at the sweep's slowest pose (129) and another: a
+    320x240 tile sees thirty-six times the scene area of a 1080p tile — queues of 10-40 k records, windows of whole buckets, the bucket-ordered
+    copy, refinements, the deep-tile cull — the composite's longest code paths, on real queues, against the oracle's queues and pixels."""
+    from sage_gs import scenes
+    sc, _ = big_scene
+    drv.upload(*sc.as_tuple())
+    deep = 0
+    for (w, h), poses in (((320, 240), (129, 206)), ((640, 480), (129,)), ((1024, 768), (27,))):
+        cams = scenes.room_cameras(sc, w, h, n_positions=4, n_yaw=64, seed=2)
+        for pid in poses:
+            _, st, aux, _ = pc.check_against_oracle(drv, sc.as_tuple(), _ocam(cams[pid], sc), what=f"3M @{w}x{h} pose {pid} (full frame)", upload=False)
+            deep += st["n_deep_windows_plain"]
+            assert st["max_tile_len"] > (4096 if w <= 640 else 1024)
+            aux["recheck"].close()
+    assert deep > 0, "no window was culled against live pixels: the deep-tile path was not exercised"
+
+
+def test_trained_like_3m_full_frame_vs_oracle(drv):
+    """A scene with trained-3DGS statistics (scenes.make_trained_like: heavy-tailed anisotropic scales, 40 % nearly transparent splats, floaters,
+    no spatial order; D = 28 M records at 1080p, six times the room scene's) — one whole 1080p frame through check_against_oracle."""
+    from sage_gs import scenes
+    sc = scenes.make_trained_like(3_000_000, seed=2)
+    cams = scenes.room_cameras(sc, 1920, 1080, n_positions=4, n_yaw=64, seed=2)
+    drv.set_record_capacity(96 << 20)
+    _, st, aux, _ = pc.check_against_oracle(drv, sc.as_tuple(), _ocam(cams[77], sc), what="trained-like 3M @1080p pose 77 (full frame)")
+    assert st["d_total"] > 10_000_000
+    aux["recheck"].close()
+
+
 def test_room_500k_full_frames_vs_oracle(drv):
     """BASELINE configs[1]: make_room(500 000, seed 1) at 1920x1080, SH degree 3 — two whole frames."""
     from sage_gs import scenes
