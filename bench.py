@@ -75,11 +75,12 @@ def parse():
     ap.add_argument("--rows-rgba8", action="store_true",
                     help="N>1: make the uint8-RGBA gather (bands packed on every rank, 4-byte pixels travel) the tile-row headline; "
                          "default: the fp32 gather north_star names at EVERY N (one metric along the 1/2/4/8 curve), uint8 under also_measured")
-    ap.add_argument("--exchange", choices=("slab", "frames"), default="slab",
+    ap.add_argument("--exchange", choices=("auto", "slab", "frames"), default="auto",
                     help="N>1, tile rows: shape of the framebuffer gatherv — 'slab': every peer sends the bands of a batch as ONE contiguous "
                          "[B, rows, W, C] message, rank 0 scatters it into the frames (world - 1 operations per exchange + one strided copy per "
                          "peer); 'frames': one receive per (peer, frame) straight into the frame rows ((world - 1) x B operations, no copy). "
-                         "Both are timed (collective.gather_us_per_frame); this picks the one the timed sweep uses")
+                         "'auto' (default): both are timed alone before the sweep (8 frames per exchange, max over ranks) and the faster one is "
+                         "used — which it was, and both timings, are in `collective`")
     ap.add_argument("--init-timeout", type=float, default=300.0,
                     help="N>1: seconds the communicator's creation and every collective may take before the rank says so (with its id) and exits")
     ap.add_argument("--no-verify", action="store_true",
@@ -299,7 +300,11 @@ def main():
         cams = scenes.room_cameras(scene, width, height, n_positions=4, n_yaw=64, seed=2)
         pose_desc = "256-pose sweep (4 positions x 64 headings)"
     n_poses = len(cams)
-    r = Renderer(device, record_capacity=(192 << 20) if config == 5 else (96 << 20))
+    # record queues: sized for a whole frame's records at N = 1; a rank of an N > 1 run renders a band of tile rows (or whole frames in the
+    # camera-sharded pass: a frame that overflows grows the queues and is rendered again, once) — a quarter is plenty for a band, and eight
+    # lanes x three record buffers x 192 Mi records x 8 B would be 37 GB per rank at config 5
+    cap = (192 << 20) if config == 5 else (96 << 20)
+    r = Renderer(device, record_capacity=cap if world == 1 else max(24 << 20, cap // 4))
     g_dev = scenes.to_gaussians(scene, device)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -347,6 +352,30 @@ def main():
     # uint8 RGBA (the array get_rgba() hands the reference's callers: a third of the bytes into rank 0) are timed afterwards
     # (also_measured.rows_rgba8).  Rounds 3-4 switched the headline's payload to uint8 from N = 4 on: a curve of two metrics.
     head_rgba8 = world > 1 and args.rows_rgba8 and args.bands != "interleave"
+    exchange_probe = None
+    if world > 1 and args.exchange == "auto":
+        # which shape of the gatherv is faster HERE is measured, not assumed (no multi-GPU node was available to the builder): the exchange
+        # alone, 8 frames of even bands, three repetitions per shape, the slowest rank's time; every rank reaches the same verdict
+        from sage_gs.dist import FrameGather
+        t_ex = []
+        for ex in ("slab", "frames"):
+            gx = FrameGather(height, width, device, batch=8, exchange=ex)
+            gx.exchange(8)
+            torch.cuda.synchronize(device); dist.barrier(); t0 = time.perf_counter()
+            for _ in range(3):
+                gx.exchange(8)
+            torch.cuda.synchronize(device); dist.barrier()
+            t_ex.append((time.perf_counter() - t0) / 24.0)
+            del gx
+        tt = torch.tensor(t_ex, dtype=torch.float64, device="cpu" if share else device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_ex = [float(v) for v in tt.tolist()]
+        args.exchange = "slab" if t_ex[0] <= t_ex[1] else "frames"
+        exchange_probe = {"slab_us_per_frame": 1e6 * t_ex[0], "frames_us_per_frame": 1e6 * t_ex[1], "chosen": args.exchange,
+                          "what": "--exchange auto: the gatherv alone in both shapes before anything else is timed (8 frames of even fp32 bands per "
+                                  "exchange, 3 repetitions, max over ranks); the faster shape carries the timed sweep"}
+    elif args.exchange == "auto":
+        args.exchange = "slab"
     if world > 1:
         sharded = sharded_f32 = ShardedRenderer(r, height, width, interleave=(args.bands == "interleave"), balance=(args.bands == "balanced"),
                                                 exchange=args.exchange)
@@ -682,7 +711,7 @@ def main():
             "verify": verify,
             "upload_ms": upload_ms,
             "collective": ({"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else 0,
-                            "exchange": args.exchange, "gather_us_per_frame": gather_us, "p2p_ops_rank0_per_exchange_of_8_frames": gather_ops,
+                            "exchange": args.exchange, "exchange_probe": exchange_probe, "gather_us_per_frame": gather_us, "p2p_ops_rank0_per_exchange_of_8_frames": gather_ops,
                             "what": "ranks = the size the communicator reports; exchange = the shape of the gatherv the timed sweep used (slab: one "
                             "contiguous [B, rows, W, C] message per peer + one strided copy per peer on rank 0; frames: one operation per (peer, frame), "
                             "no copy); gather_us_per_frame = the framebuffer gatherv ALONE in both shapes (bands already rendered), 8 frames per exchange, "
