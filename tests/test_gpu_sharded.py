@@ -39,9 +39,11 @@ def _worker(rank, world, port, mode, n_gauss, res, q, backend="gloo"):
         cams = scenes.room_cameras(sc, w, h, n_positions=1, n_yaw=10, seed=1)
         r = Renderer(dev)
         scene = r.upload(scenes.to_gaussians(sc, dev))
+        exchange = "frames" if mode.endswith("+frames") else "slab"      # (the default: one operation per peer and exchange)
+        mode = mode.replace("+frames", "")
         rgba8 = mode.startswith("rgba8")
         sr = ShardedRenderer(r, h, w, batch=4, interleave=(mode == "interleave"), balance=mode.endswith("balance"),
-                             output="rgba8" if rgba8 else "float32")
+                             output="rgba8" if rgba8 else "float32", exchange=exchange)
         ok, notes = True, []
         whole = [r.render(c, scene).clone() for c in cams] if rank == 0 else None      # the un-sharded HIP frames
         if rgba8 and rank == 0:                     # bands travel as bytes: rank 0 must hold pack_rgba8 of the un-sharded frame
@@ -62,6 +64,8 @@ def _worker(rank, world, port, mode, n_gauss, res, q, backend="gloo"):
             ids = list(range(c0, min(len(cams), c0 + 4)))
             g = sr.render_batch([cams[i] for i in ids], scene)
             bands_seen.append(tuple(g.bands))
+            if g.mode == "slab":                   # one operation per peer with rows, whatever the batch holds
+                ok = ok and g.last_ops <= world - 1 and exchange == "slab" and mode != "interleave"
             done.append((g, ids, sr._turn ^ 1))
             if len(done) == 2:
                 g0, ids0, k0 = done.pop(0)
@@ -100,7 +104,7 @@ def _worker(rank, world, port, mode, n_gauss, res, q, backend="gloo"):
 
 
 @pytest.mark.parametrize("world,mode", [(2, "even"), (3, "even"), (3, "balance"), (2, "interleave"), (3, "interleave"),
-                                        (3, "rgba8-balance")])
+                                        (3, "rgba8-balance"), (2, "even+frames"), (3, "balance+frames")])
 def test_sharded_renderer_on_one_gpu(world, mode):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -116,7 +120,7 @@ def test_sharded_renderer_on_one_gpu(world, mode):
     assert ok, notes
 
 
-@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "balance"), (2, "rgba8-balance"), (8, "even")])
+@pytest.mark.parametrize("world,mode", [(2, "even"), (2, "balance"), (2, "rgba8-balance"), (8, "even"), (2, "balance+frames"), (8, "even+frames")])
 def test_sharded_renderer_on_rccl_when_the_box_has_gpus(world, mode):
     """The same check on the backend the 8-GPU node uses: "nccl" = RCCL, one GPU per rank — two ranks (and, where the box has them, up to eight) —
     the gathered frame bit-identical to the un-sharded one.  RCCL refuses two ranks on one device, so on a 1-GPU box this SKIPS, loudly: the
@@ -223,6 +227,13 @@ def test_bench_multi_rank_line_verifies_itself_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["metric_version"] >= 4
     v = d["verify"]
-    assert v["ok"] and v["frames_checked"] == 7 and v["mismatching_pixels"] == 0 and v["ranks"] == 2
-    assert "fp32 bands" in d["config"]["parallelism"] and d["collective"]["ranks"] == 2
+    # (10 = the single-frame exchange + 3 frames through each of the two gatherv shapes + 3 through the uint8 gather)
+    assert v["ok"] and v["frames_checked"] == 10 and v["mismatching_pixels"] == 0 and v["ranks"] == 2
+    assert v["p2p_ops_rank0_per_exchange_of_3_frames"] == {"slab": 1, "frames": 3}
+    c = d["collective"]
+    assert "fp32 bands" in d["config"]["parallelism"] and c["ranks"] == 2
+    # --exchange auto: both shapes were timed before the sweep, one was chosen (the same on every rank, or the exchange would have hung), and
+    # the gatherv alone was timed in both shapes afterwards with the operations rank 0 posted
+    assert c["exchange"] == c["exchange_probe"]["chosen"] in ("slab", "frames")
+    assert set(c["gather_us_per_frame"]) == {"slab", "frames"} and c["p2p_ops_rank0_per_exchange_of_8_frames"] == {"slab": 1, "frames": 8}
     assert "[verify]" in p.stderr and "bit-identical" in p.stderr
