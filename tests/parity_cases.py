@@ -378,6 +378,31 @@ def case_sort_classes(drv, sizes=(700, 2500, 6000, 9500)):
         assert st["max_tile_len"] == n
 
 
+def case_sparse_lists(drv, n=9000, res=(48, 40)):
+    """Thousands of faint splats a pixel or two wide over a small image: no pixel saturates, every tile reads its whole queue in many batches,
+    and every listed splat reaches a handful of a quadrant's 64 pixels — the shape of a low-resolution frame's slowest tiles (and the case the
+    per-pixel-mask walk of round 6 was built for, profiles/r06n).  A second scene mixes in splats that cover whole quadrants and a few opaque
+    ones (pixels that end in the middle of a list)."""
+    w, h = res
+    f = 40.0
+    for seed, big in ((33, 0.0), (34, 0.05)):
+        rng = np.random.default_rng(seed)
+        z = rng.uniform(2.0, 30.0, n)
+        means = np.stack([rng.uniform(-0.5 * w, 0.5 * w, n) * z / f, rng.uniform(-0.5 * h, 0.5 * h, n) * z / f, z], 1).astype(np.float32)
+        s_px = np.where(rng.random(n) < big, rng.uniform(3.0, 12.0, n), rng.uniform(0.15, 0.7, n))          # sigma in pixels
+        scales = (np.repeat((s_px * z / f)[:, None], 3, 1) * rng.uniform(0.6, 1.0, (n, 3))).astype(np.float32)
+        quats = rng.normal(size=(n, 4)).astype(np.float32)
+        opac = rng.uniform(0.02, 0.25, n).astype(np.float32)
+        if big:
+            opac[(rng.random(n) < 0.03) & (s_px < 1.0)] = 0.995                  # (a pixel here and there ends inside a chunk)
+            opac[s_px >= 3.0] *= 0.2
+        sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
+        cam = onp.Camera(w, h, f, f, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+        img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what=f"sparse lists (seed {seed})")
+        assert st["max_tile_len"] > 512, st["max_tile_len"]
+        assert float((aux["final_T"] > 0.05).mean()) > 0.5 or big
+
+
 def case_deep_tile(drv, n_back=6000):
     """Tiles that keep consuming batches for a few pixels: three opaque layers saturate every pixel of a 32x32 image except a 5x5 hole
     per tile, and thousands of splats behind them are visible only through the holes.  After SGS_DEEP_AFTER batches such a tile culls every

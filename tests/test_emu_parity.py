@@ -76,6 +76,10 @@ def test_sort_classes(drv):
     pc.case_sort_classes(drv, sizes=(700, 2500, 9500))
 
 
+def test_sparse_lists(drv):
+    pc.case_sparse_lists(drv, n=5000, res=(40, 32))
+
+
 def test_deep_tile(drv):
     pc.case_deep_tile(drv, n_back=5000)
 

@@ -162,6 +162,10 @@ def test_sort_classes(drv):
     pc.case_sort_classes(drv, sizes=(700, 2500, 6000, 9500, 20000))
 
 
+def test_sparse_lists(drv):
+    pc.case_sparse_lists(drv)
+
+
 def test_deep_tile(drv):
     pc.case_deep_tile(drv, n_back=12000)
 
