@@ -397,3 +397,60 @@ def _buffer_limit_worker(rank, world, port, q):
 
 def test_sharded_renderer_buffer_limit_is_the_same_verdict_on_every_rank():
     assert _spawn(_buffer_limit_worker, 2) is True
+
+
+class _SleepingRenderer(_RowCopyRenderer):
+    """_RowCopyRenderer whose render_batch TAKES TIME: a fixed cost per call plus a cost per tile row rendered (seconds), so that the band times
+    ShardedRenderer measures with the host clock carry a real skew."""
+
+    def __init__(self, frames, costs, row_seconds, fixed_seconds):
+        super().__init__(frames, costs)
+        self.row_seconds, self.fixed_seconds = row_seconds, fixed_seconds
+
+    def render_batch(self, cameras, scene, *, config=None, out=None, tile_rows=None, want_stats=False, out_bands=None, interleave=None):
+        import time
+        r0, r1 = tile_rows
+        time.sleep(self.fixed_seconds + len(cameras) * float(self.row_seconds[r0:r1].sum()))
+        return super().render_batch(cameras, scene, config=config, out=out, tile_rows=tile_rows, want_stats=want_stats, out_bands=out_bands,
+                                    interleave=interleave)
+
+
+def _skew_worker(rank, world, port, q):
+    """balance=True end to end against a REAL skew (the re-balancing uses host wall-clock per rank, untested against real skew): a few
+    'horizon' rows cost 20x the others and their records mispredict it (a cheap ceiling row queues as many).  Bands re-cut from the measured band
+    times must bring the slowest band's true cost well below the even split's within a few batches, identically on every rank, and the gathered
+    frames must stay right throughout."""
+    _init(rank, world, port)
+    try:
+        h, w, n_frames, B = 16 * 24, 32, 24, 3
+        gy = (h + 15) // 16
+        rng = np.random.default_rng(9)
+        frames = torch.from_numpy(rng.random((n_frames, h, w, 3)).astype(np.float32))
+        true = np.full(gy, 0.15e-3); true[9:13] = 3.0e-3                         # seconds per frame and row: the horizon
+        records = np.full((n_frames, gy), 4000, np.int64); records[:, 9:13] = 9000; records[:, 0:3] = 9000      # the ceiling queues as many, costs nothing
+        rr = _SleepingRenderer(frames, records, true, 0.5e-3)
+        sr = ShardedRenderer(rr, h, w, batch=B, balance=True)
+        cost_of = lambda bands: max(float(true[a:b].sum()) for a, b in bands)
+        ok, seen = True, []
+        for c0 in range(0, n_frames, B):
+            cams = list(range(c0, c0 + B))
+            g = sr.render_batch(cams, None)
+            seen.append(tuple(g.bands))
+            sr.finish()
+            if rank == 0:
+                ok = ok and all(bool((g.frame(i) == frames[c]).all()) for i, c in enumerate(cams))
+        even = tuple(row_partition(gy, world))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, seen)
+        ok = ok and all(b == gathered[0] for b in gathered) and seen[0] == even
+        ok = ok and cost_of(seen[-1]) < 0.7 * cost_of(even) and min(cost_of(b) for b in seen[3:]) <= cost_of(seen[-1]) * 1.3
+        if rank == 0:
+            q.put((ok, [round(1e3 * cost_of(b), 2) for b in seen], [[b - a for a, b in bs] for bs in (seen[0], seen[-1])]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_balanced_bands_follow_a_real_skew_gloo():
+    ok, costs, bands = _spawn(_skew_worker, 3)
+    assert ok, (costs, bands)
