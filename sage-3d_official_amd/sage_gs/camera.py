@@ -58,14 +58,21 @@ def quat_to_matrix_wxyz(q: Sequence[float]) -> np.ndarray:
 def view_from_isaac_pose(position: Sequence[float], orientation_wxyz: Sequence[float]) -> np.ndarray:
     """world->camera 4x4 for `cam.set_world_pose(position, orientation)` (simple_env.py:1284;
     generate_images.py:419-421), camera axes "world": +X forward, +Z up at identity."""
-    R = quat_to_matrix_wxyz(orientation_wxyz)
-    fwd, up = R[:, 0], R[:, 2]
-    right = np.cross(fwd, up)
-    rot = np.stack([right, -up, fwd])
-    V = np.eye(4)
-    V[:3, :3] = rot
-    V[:3, 3] = -rot @ np.asarray(position, float)
-    return V
+    # (scalar arithmetic: this runs once per get_rgba() of the adapter, and the small-array NumPy form of the same eight lines took 50 us of a
+    #  0.5-ms call)
+    w, x, y, z = (float(v) for v in orientation_wxyz)
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    if n == 0.0:
+        raise ValueError("zero quaternion")
+    w, x, y, z = w / n, x / n, y / n, z / n
+    fx, fy, fz = 1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)          # the rotation's first column: forward
+    ux, uy, uz = 2 * (x * z + w * y), 2 * (y * z - w * x), 1 - 2 * (x * x + y * y)          # its third column: up
+    rx, ry, rz = fy * uz - fz * uy, fz * ux - fx * uz, fx * uy - fy * ux                    # right = forward x up
+    px, py, pz = (float(v) for v in position)
+    return np.array([[rx, ry, rz, -(rx * px + ry * py + rz * pz)],
+                     [-ux, -uy, -uz, ux * px + uy * py + uz * pz],
+                     [fx, fy, fz, -(fx * px + fy * py + fz * pz)],
+                     [0.0, 0.0, 0.0, 1.0]])
 
 
 def isaac_pose_from_view(view) -> tuple:
