@@ -856,8 +856,26 @@ def main():
                     r.render(lc[p], gs, out=buf, timing=True)
                     for n in STAGE_NAMES:
                         stage_l[n].append(r.last_stats["ms"][n])
+                n_tiles_l = r.last_stats["n_tiles"]
+                side_l = next((c_ for c_ in (16, 8, 4) if -(-lw // c_) * -(-lh // c_) == n_tiles_l), None)
                 entry = {"latency_ms": pct(lat), "fps_one_at_a_time": 1e3 / float(np.mean(lat)),
-                         "stages_ms_alone": {n: mean(stage_l[n]) for n in STAGE_NAMES}}
+                         "stages_ms_alone": {n: mean(stage_l[n]) for n in STAGE_NAMES},
+                         "tile_px": side_l, "n_tiles": n_tiles_l}
+                if side_l != 16:
+                    # fine tiles (sgs_tuning.fine_tile_pixels): the same poses through 16x16-pixel tiles, for comparison
+                    lat16, st16 = [], {n: [] for n in STAGE_NAMES}
+                    for p in sel_l[:4]:
+                        r.render(lc[p], gs, out=buf, fine_tiles=False)
+                    for p in sel_l:
+                        t0 = time.perf_counter()
+                        r.render(lc[p], gs, out=buf, fine_tiles=False)
+                        lat16.append(1e3 * (time.perf_counter() - t0))
+                    for p in sel_l:
+                        r.render(lc[p], gs, out=buf, timing=True, fine_tiles=False)
+                        for n in STAGE_NAMES:
+                            st16[n].append(r.last_stats["ms"][n])
+                    entry["with_16x16_tiles"] = {"latency_ms": pct(lat16), "stages_ms_alone": {n: mean(st16[n]) for n in STAGE_NAMES},
+                                                 "what": "SGS_FLAG_NO_FINE_TILES: the same frames through 16x16-pixel tiles (rounds 1-5)"}
                 # the boundary the reference really has: cam.set_world_pose(...) ; cam.get_rgba() -> uint8 [H,W,4] on the HOST
                 # (simple_env.py:1284,1380-1386), through the GsCamera adapter: render + pack + copy into a pinned buffer, one wait
                 gcam = GsCamera(r, gs, resolution=(lw, lh))

@@ -26,9 +26,9 @@
 extern "C" {
 #endif
 
-#define SGS_VERSION 112            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
+#define SGS_VERSION 113            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
                                     * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points; 111: sgs_stats grew n_deep_windows, sgs_compressed_scene.reserved_ became sh_decode; 112: SGS_FLAG_NO_DEEP; sgs_set_tuning,
-                                    * SGS_BUF_SCENE_SH): a caller compiled against
+                                    * SGS_BUF_SCENE_SH; 113: fine tiles — sgs_tuning grew fine_tile_pixels, SGS_FLAG_NO_FINE_TILES): a caller compiled against
                                     * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
                                     * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
                                     * that takes a struct.  The library writes whole structs (sgs_stats arrays with ITS stride). */
@@ -63,6 +63,15 @@ enum {
                                     * the chunks that cannot reach it).  N_v, D, queues and frames must not change */
     SGS_FLAG_NO_DEEP = 1u << 8,    /* tests, A/B: never cull a resident window of a long-lived tile against its live pixels before ranking it
                                     * (DESIGN.md §4.2 item 8).  Frames must not change, bit for bit */
+    SGS_FLAG_NO_FINE_TILES = 1u << 9, /* tests, A/B: render this frame through 16x16-pixel tiles whatever its size.  By default a frame of at
+                                    * most sgs_tuning.fine_tile_pixels pixels (640x480: the reference's own resolutions, simple_env.py:52,
+                                    * run_benchmark.py:1409-1419) is rendered through 8x8-pixel tiles — four times the workgroups, a quarter of the
+                                    * queue and of the per-wave splat lists in each: such a frame's time is its slowest tile's.  WHICH splats reach
+                                    * a pixel does not change (S3's rect stays a rect of 16x16-pixel tiles); the tile origin the blend's
+                                    * coordinates are relative to does, so the two renderings of a frame agree to fp32 rounding (both within the
+                                    * parity tolerance of the oracle), not bit for bit.  SGS_FLAG_FULL_SORT / SGS_FLAG_LOOSE_CULL imply this flag:
+                                    * the reference's integer structures are those of 16x16-pixel tiles.  sgs_stats.n_tiles, d_total, d_super,
+                                    * max_tile_len and SGS_BUF_TILE_OFFSETS count the tiles actually used.  Version 113 */
     SGS_FLAG_PIPELINED = 1u << 4   /* with SGS_FLAG_ASYNC: the frame may run CONCURRENTLY with other pipelined frames on
                                     * the library's internal streams (a few frames in flight, each with its own
                                     * intermediates: one frame's binning fills the compute units another frame's
@@ -155,7 +164,8 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
  * sgs_create; four of them — the grids of the binning and projection launches — were settled by A/B runs and are constants now).
  * sgs_tuning_default() fills what the bench runs; sgs_set_tuning() takes effect for the scenes uploaded and the frames issued AFTER it
  * (it completes the frames in flight first).  Frames do not depend on any of these, bit for bit (tests/test_gpu_parity.py).  No
- * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112. */
+ * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112 (113: fine_tile_pixels — the one
+ * field frames DO depend on, to fp32 rounding). */
 typedef struct sgs_tuning {
     int32_t lanes;            /* 3  frames in flight for SGS_FLAG_PIPELINED single frames: each lane has its own stream and intermediates (1..8) */
     int32_t group;            /* 4  frames per set of launches in sgs_render_batch* (blockIdx.y selects the frame; 1..8) */
@@ -163,6 +173,8 @@ typedef struct sgs_tuning {
     int32_t morton;           /* 1  lay the scene out in Z-order at upload (device radix sort); 0 keeps the caller's order */
     int64_t record_capacity;  /* 16 Mi  (Gaussian, tile) records the queues of a lane hold; an overflowing frame grows them and is rendered again
                                *        (= sgs_set_record_capacity) */
+    int64_t fine_tile_pixels; /* 307200 (640x480)  frames of at most this many pixels are rendered through 8x8-pixel tiles (SGS_FLAG_NO_FINE_TILES
+                               *        above); 0 = never.  Version 113 */
 } sgs_tuning;
 void sgs_tuning_default(sgs_tuning* out);
 int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* tuning);

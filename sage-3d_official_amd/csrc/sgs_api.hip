@@ -96,6 +96,8 @@ struct sgs_ctx {
     int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (settled by A/B: r03, r04)
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (<= SGS_BIN_BLOCKS)
     int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP: its waves loop over the live list (r03y)
+    int64_t fine_tile_pixels = 640 * 480;    // sgs_tuning.fine_tile_pixels: frames of at most this many pixels are rendered through 8x8-pixel
+                                             // tiles (fine_shift_of; sgs_common.h "Fine tiles"); 0 = never
     bool morton = true;                      // Z-order the scene at upload (sgs_tuning.morton = 0 keeps the caller's order): a chunk of 64
                                              // Gaussians is then a compact patch, which is what makes the per-chunk bounds
                                              // (k_chunk_bounds / chunk_outside) worth testing — trained scenes come in no spatial order
@@ -233,6 +235,17 @@ int drain_lanes(sgs_ctx* ctx) {
     return SGS_OK;
 }
 
+// Fine tiles (sgs_common.h): the shift z of a call — its frame is rendered through tiles of (16 >> z)^2 pixels.  Small frames only (a large one
+// fills the chip with 16x16 tiles, and a wave of 64 pixels evaluates a splat once where four waves of 16 evaluate it up to four times); never
+// under the test hooks whose point is the REFERENCE's integer structures — queues and offsets of 16x16-pixel tiles.
+int fine_shift_of(const sgs_ctx* ctx, const sgs_camera* cam, uint32_t flags) {
+    if (flags & (SGS_FLAG_NO_FINE_TILES | SGS_FLAG_FULL_SORT | SGS_FLAG_LOOSE_CULL)) return 0;
+    // halved while the frame has at most fine_tile_pixels / 4^z pixels, twice at most: 640x480 -> 8x8-pixel tiles, 320x240 -> 4x4 under the default
+    int z = 0;
+    while (z < 2 && (((int64_t)cam->width * cam->height) << (2 * z)) <= ctx->fine_tile_pixels) ++z;
+    return z;
+}
+
 int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
              int& row_begin, int& row_end, const float* out_rgb) {
     if (!scene || !cam || !out_rgb) SGS_FAIL(ctx, SGS_ERR_INVALID, "null scene / camera / output");
@@ -269,11 +282,13 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
                     SGS_FAIL(ctx, SGS_ERR_INVALID, "camera view is not rigid: rows %d.%d of its 3x3 give %g", r, c, d);
             }
     }
-    const int gx = (cam->width + SGS_TILE - 1) / SGS_TILE;
     if (gy_frame > SGS_MAX_ROWS) SGS_FAIL(ctx, SGS_ERR_INVALID, "height %d exceeds %d tile rows", cam->height, SGS_MAX_ROWS);
-    // level 1 of the binning keeps one counter per super-tile of the band in LDS
-    const int64_t ns = (int64_t)((gx + SGS_ST - 1) / SGS_ST) * (((row_end + SGS_ST - 1) / SGS_ST) - row_begin / SGS_ST);
-    if (ns > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d super-tiles", row_end - row_begin, gx, SGS_WT);
+    // level 1 of the binning keeps one counter per super-tile of the band in LDS (the band's rows and tiles as the kernels count them:
+    // cells of (16 >> z)^2 pixels, sgs_common.h "Fine tiles")
+    const int z = fine_shift_of(ctx, cam, cfg ? cfg->flags : 0u), cp = SGS_TILE >> z;
+    const int gx = (cam->width + cp - 1) / cp, rb = row_begin << z, re = row_end << z;
+    const int64_t ns = (int64_t)((gx + SGS_ST - 1) / SGS_ST) * (((re + SGS_ST - 1) / SGS_ST) - rb / SGS_ST);
+    if (ns > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d super-tiles", re - rb, gx, SGS_WT);
     return SGS_OK;
 }
 
@@ -289,13 +304,18 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.alpha_min = cfg.alpha_min; P.alpha_max = cfg.alpha_max; P.t_min = cfg.t_min;
     for (int c = 0; c < 3; ++c) P.bg[c] = cfg.bg[c];
     P.width = cam->width; P.height = cam->height;
-    P.gx = (cam->width + SGS_TILE - 1) / SGS_TILE; P.gy = (cam->height + SGS_TILE - 1) / SGS_TILE;
-    P.row_begin = row_begin; P.row_end = row_end;
+    // Fine tiles (sgs_common.h): the grid, the band and every tile index the kernels see count CELLS of (16 >> z)^2 pixels; row_begin / row_end
+    // arrive in 16-pixel rows (the C ABI's unit), each of which is 2^z rows of cells — but for the frame's last one when the height leaves it short
+    const int z = fine_shift_of(ctx, cam, cfg.flags), cp = SGS_TILE >> z;
+    const int gx16 = (cam->width + SGS_TILE - 1) / SGS_TILE, gy16 = (cam->height + SGS_TILE - 1) / SGS_TILE;
+    P.gx = (cam->width + cp - 1) / cp; P.gy = (cam->height + cp - 1) / cp;
     P.row_stride = cfg.tile_row_stride > 1 ? cfg.tile_row_stride : 1;
     P.row_phase = P.row_stride > 1 ? cfg.tile_row_phase : 0;
+    P.row_begin = row_begin << z; P.row_end = row_end << z;
+    if (row_end > row_begin && (row_end - 1) * P.row_stride + P.row_phase == gy16 - 1) P.row_end -= (gy16 << z) - P.gy;
     // a contiguous band ignores what projects outside its pixel rows; interleaved rows span the frame
     P.cull_y0 = P.row_stride > 1 ? 0 : SGS_TILE * row_begin;
-    P.cull_y1 = P.row_stride > 1 ? SGS_TILE * P.gy : SGS_TILE * row_end;
+    P.cull_y1 = P.row_stride > 1 ? SGS_TILE * gy16 : SGS_TILE * row_end;
     P.sh_degree = cfg.sh_degree < 0 ? scene->sh_degree : std::min(cfg.sh_degree, scene->sh_degree);
     P.sh_rows = scene->sh_rows;
     P.n = scene->n; P.n_chunks = scene->n_chunks;
@@ -304,13 +324,14 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.limx = (double)P.clamp * (0.5 * (double)P.width / (double)P.fx); P.limy = (double)P.clamp * (0.5 * (double)P.height / (double)P.fy);
     P.rec_capacity = L.rec_cap;
     P.job_capacity = (int32_t)std::min<int64_t>(L.job_cap, 0x7fffffff);
-    P.flags = (cfg.flags & ~SGS_PFLAG_INTERNAL) | (scene->sh_packed ? SGS_PFLAG_SH_PACKED | ((uint32_t)scene->sh_decode << SGS_PFLAG_SH_MODE_SHIFT) : 0u);
+    P.flags = (cfg.flags & ~SGS_PFLAG_INTERNAL) | (scene->sh_packed ? SGS_PFLAG_SH_PACKED | ((uint32_t)scene->sh_decode << SGS_PFLAG_SH_MODE_SHIFT) : 0u) |
+              ((uint32_t)z << SGS_PFLAG_FINE_SHIFT);
     {   // k_chunk_cull's planes (sgs_kernels.h chunk_outside: the derivation and why each constant is conservative)
         const double lx = P.limx, ly = P.limy;
         P.cull_A = 1.001 * 3.0 * std::sqrt(2.0 * (2.0 + lx * lx + ly * ly)) * std::max((double)P.fx, (double)P.fy) * 1.0001;
         const double c0 = 1.001 * (3.0 * std::sqrt(2.0 * (double)P.dilation + 0.3163) + 1.0) + 0.5 + 1.0;      // + one pixel of slack
         P.cull_off[0] = (double)P.cx - 0.5 + c0;                                     // px + rb >= 0
-        P.cull_off[1] = (double)(SGS_TILE * P.gx) - (double)P.cx + 0.5 + c0;         // px - rb <  16 gx
+        P.cull_off[1] = (double)(SGS_TILE * gx16) - (double)P.cx + 0.5 + c0;         // px - rb <  16 gx (gx: 16-pixel tiles)
         P.cull_off[2] = (double)P.cy - 0.5 - (double)P.cull_y0 + c0;                 // py + rb >= cull_y0
         P.cull_off[3] = (double)P.cull_y1 - (double)P.cy + 0.5 + c0;                 // py - rb <  cull_y1
         const double f[4] = {(double)P.fx, (double)P.fx, (double)P.fy, (double)P.fy};
@@ -390,7 +411,8 @@ void launch_composite(const FrameGroup& G, int nf, hipStream_t stream, bool aux,
 int build_group(sgs_ctx* ctx, FrameGroup& G, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
                 int row_begin, int row_end, float* const* outs, int slot0, float* out_aux, int set0) {
     int rc;
-    const int gx = (cams->width + SGS_TILE - 1) / SGS_TILE, gy = (cams->height + SGS_TILE - 1) / SGS_TILE;
+    const int cp = SGS_TILE >> fine_shift_of(ctx, cams, cfg.flags);      // (the frames of a group share a resolution and a configuration)
+    const int gx = (cams->width + cp - 1) / cp, gy = (cams->height + cp - 1) / cp;
     memset(&G, 0, sizeof G);
     G.geom = scene->geom; G.shq = scene->shq; G.cbound = scene->cbound; G.row_acc = ctx->row_acc;
     for (int f = 0; f < nf; ++f) {
@@ -423,9 +445,11 @@ void note_last(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
     ctx->last_t_lo = row_begin * gx; ctx->last_t_hi = row_end * gx;
     ctx->last_scene = scene;
     int64_t pixel_rows = 0;                       // pixel rows of the frame this call wrote
+    const int z = (int)((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u), cp = SGS_TILE >> z;     // (rows of cells: sgs_common.h "Fine tiles")
     for (int k = row_begin; k < row_end; ++k) {
-        const int y0 = (k * P.row_stride + P.row_phase) * SGS_TILE;
-        pixel_rows += std::max(0, std::min(y0 + SGS_TILE, cam->height) - y0);
+        const int k16 = k >> z;
+        const int y0 = (((k16 * P.row_stride + P.row_phase) << z) + (k - (k16 << z))) * cp;
+        pixel_rows += std::max(0, std::min(y0 + cp, cam->height) - y0);
     }
     ctx->last_pixels = pixel_rows * cam->width;
 }
@@ -622,12 +646,13 @@ int sgs_destroy(sgs_ctx* ctx) {
 void sgs_tuning_default(sgs_tuning* out) {
     if (!out) return;
     out->lanes = 3; out->group = 4; out->group_lanes = 2; out->morton = 1; out->record_capacity = 16ll << 20;
+    out->fine_tile_pixels = 640 * 480;
 }
 
 int sgs_get_tuning(const sgs_ctx* ctx, sgs_tuning* out) {
     if (!ctx || !out) return SGS_ERR_INVALID;
     out->lanes = ctx->n_lanes; out->group = ctx->group; out->group_lanes = ctx->group_lanes; out->morton = ctx->morton ? 1 : 0;
-    out->record_capacity = ctx->rec_cap_wanted;
+    out->record_capacity = ctx->rec_cap_wanted; out->fine_tile_pixels = ctx->fine_tile_pixels;
     return SGS_OK;
 }
 
@@ -639,9 +664,11 @@ int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* t) {
     if (t->group_lanes < 1 || t->group * t->group_lanes > kMaxLanes)
         SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.group x group_lanes = %d x %d exceeds the %d lanes of a context", t->group, t->group_lanes, kMaxLanes);
     if (t->record_capacity <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.record_capacity must be positive");
+    if (t->fine_tile_pixels < 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.fine_tile_pixels must not be negative (0 = never)");
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();                          // frames in flight were issued under the old values (their verdicts stay for sgs_frame_sync)
     ctx->n_lanes = t->lanes; ctx->next_lane = 0; ctx->group = t->group; ctx->group_lanes = t->group_lanes; ctx->morton = t->morton != 0;
+    ctx->fine_tile_pixels = t->fine_tile_pixels;
     if (t->record_capacity != ctx->rec_cap_wanted) return sgs_set_record_capacity(ctx, t->record_capacity);
     return SGS_OK;
 }

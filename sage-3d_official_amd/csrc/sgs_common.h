@@ -50,7 +50,19 @@
 
 #define SGS_PFLAG_SH_PACKED 0x80000000u   // FrameParams.flags, set by the library (never by a caller's sgs_config): the scene's SH rows are packed bytes,
 #define SGS_PFLAG_SH_MODE_SHIFT 29        // ... decoded with mode (flags >> 29) & 3 (sage_gs.h SGS_SH_DECODE_*)
-#define SGS_PFLAG_INTERNAL 0xE0000000u
+#define SGS_PFLAG_FINE_SHIFT 27           // ... bits 27-28, set by the library: z, the frame's FINE-TILE shift.  Its tiles are (16 >> z)^2 pixels
+                                          //     (FrameParams.gx / gy / row_begin / row_end count THOSE tiles), see "Fine tiles" below
+#define SGS_PFLAG_INTERNAL 0xF8000000u
+// Fine tiles.  The composite puts a workgroup on a tile and a lane on a pixel; a frame of 320x240 pixels is 300 tiles of 16x16 — a chip of
+// 256 CUs is a quarter full, and the frame takes as long as its slowest tile, whose four waves walk lists of thousands of splats one after
+// the other (profiles/r06c: 3.9 M of a 320x240 frame's 3.9 M cycles are ONE tile).  Such frames are rendered through tiles of
+// (16 >> z)^2 pixels instead, WITHOUT a second set of kernels: every kernel keeps working on a grid of 16x16 "cells", and k_preprocess hands
+// it the splats in coordinates scaled by 2^z — positions and extents times 2^z, the roots a, a k, c of the conic divided by 2^z (powers of
+// two: exact) — so that pixel (i, j) of the frame is cell-pixel (i << z, j << z); the composite's lanes on the other cell-pixels are
+// "outside the image" from the start (Tm = 0), the same mechanism that handles a tile at the frame's edge.  A 16x16 cell is then
+// (16 >> z)^2 real pixels, a wave's quadrant (8 >> z)^2, the slowest tile's queue is split over 4^z workgroups and its waves' lists over
+// 4^z times as many waves.  What S3 defines — a splat reaches the pixels of the 16x16-pixel tiles its rect covers — is kept: the rect is
+// computed on the 16-pixel grid and mapped to the cells it covers (k_preprocess).  z is chosen per call by the library (sgs_api.hip).
 // Per-frame parameters, passed BY VALUE to every kernel (kernarg segment, scalar-loaded).
 struct FrameParams {
     float view[12];                 // rows 0..2 of the model->camera matrix (row-major 3x4)

@@ -543,12 +543,25 @@ __device__ __forceinline__ int tile_clamp(double v, int lo, int hi) {
     return (int)f;
 }
 
+// Fine tiles (sgs_common.h): the shift z of the frame; every row / tile index of FrameParams counts cells of (16 >> z)^2 pixels.
+__device__ __forceinline__ int fine_shift(const FrameParams& P) { return (int)((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u); }
 // The first row this call owns that is not above frame tile row f (clamped to [row_begin, row_end]): frame rows [a, b)
-// are the owned rows [owned_row(a), owned_row(b)).  Owned row k is frame row k * row_stride + row_phase.
+// are the owned rows [owned_row(a), owned_row(b)).  Owned 16-pixel row k is frame 16-pixel row k * row_stride + row_phase; with fine
+// tiles a 16-pixel row is 2^z rows of cells, owned or not as a whole: owned row (k << z) + s is frame row ((k stride + phase) << z) + s.
 __device__ __forceinline__ int owned_row(const FrameParams& P, int f) {
     int k = f;
-    if (P.row_stride > 1) k = f > P.row_phase ? (f - P.row_phase + P.row_stride - 1) / P.row_stride : 0;
+    if (P.row_stride > 1) {
+        const int z = fine_shift(P), F = f >> z;
+        const int k16 = F > P.row_phase ? (F - P.row_phase + P.row_stride - 1) / P.row_stride : 0;
+        k = (k16 << z) + (k16 * P.row_stride + P.row_phase == F ? f - (F << z) : 0);
+    }
     return min(max(k, P.row_begin), P.row_end);
+}
+// ... and back: the frame's row of cells that owned row r of this call is
+__device__ __forceinline__ unsigned frame_row_of(const FrameParams& P, unsigned r) {
+    if (P.row_stride <= 1) return r;
+    const unsigned z = (unsigned)fine_shift(P), k16 = r >> z;
+    return ((k16 * (unsigned)P.row_stride + (unsigned)P.row_phase) << z) + (r - (k16 << z));
 }
 
 // One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
@@ -593,7 +606,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float rb = (3.0f * sqrtf(2.0f * lmax + 0.3163f) + 1.0f) * 1.001f + 0.5f;
         const float pxf = P.fx * (float)tx * inv + P.cx - 0.5f, pyf = P.fy * (float)ty * inv + P.cy - 0.5f;
         const float ex = 1.0e-5f * fabsf(pxf) + 0.01f, ey = 1.0e-5f * fabsf(pyf) + 0.01f;
-        const bool out_x = pxf + rb + ex < 1.0f || pxf - rb - ex >= (float)(SGS_TILE_PX * P.gx);
+        const bool out_x = pxf + rb + ex < 1.0f || pxf - rb - ex >= (float)(SGS_TILE_PX * ((P.gx + (1 << fine_shift(P)) - 1) >> fine_shift(P)));   // (16 x the frame's 16-pixel tiles)
         const bool out_y = pyf + rb + ey < (float)P.cull_y0 + 1.0f || pyf - rb - ey >= (float)P.cull_y1;
         maybe = !(out_x || out_y);                   // (NaN anywhere keeps the Gaussian)
     }
@@ -646,12 +659,16 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const double radius = ceil(3.0 * sqrt(lam));
             const double px = fx * xz + (double)P.cx - 0.5;
             const double py = fy * yz + (double)P.cy - 0.5;
-            const int x0 = tile_clamp((px - radius) / SGS_TILE_PX, 0, P.gx);
-            const int x1 = tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gx);
+            // (S3's rect is a rect of 16x16-PIXEL tiles whatever the frame's cells are: with fine tiles — z > 0, sgs_common.h — it is
+            //  computed on the frame's 16-pixel grid and then mapped to the cells it covers, 2^z per tile and axis, clipped to the grid of cells)
+            const int z = fine_shift(P), zr = (1 << z) - 1;
+            const int gx16 = (P.gx + zr) >> z, gy16 = (P.gy + zr) >> z;
+            const int x0 = min(tile_clamp((px - radius) / SGS_TILE_PX, 0, gx16) << z, P.gx);
+            const int x1 = min(tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gx16) << z, P.gx);
             // frame rows [fy0, fy1) -> the rows this call owns: the contiguous band, or every row_stride-th row from
             // row_phase (then a rect's rows are again a contiguous range of OWNED rows, so binning never knows)
-            const int fy0 = tile_clamp((py - radius) / SGS_TILE_PX, 0, P.gy);
-            const int fy1 = tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, P.gy);
+            const int fy0 = min(tile_clamp((py - radius) / SGS_TILE_PX, 0, gy16) << z, P.gy);
+            const int fy1 = min(tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gy16) << z, P.gy);
             const int y0 = owned_row(P, fy0), y1 = owned_row(P, fy1);
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
@@ -694,8 +711,10 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                         const float hx = hx_ < 1.0e9f ? hx_ : 1.0e9f, hy = hy_ < 1.0e9f ? hy_ : 1.0e9f;          // (inf / NaN -> the whole rect)
                         const float fpx = (float)px, fpy = (float)py;
                         const float epx = 1.0e-6f * fabsf(fpx), epy = 1.0e-6f * fabsf(fpy);
-                        const float lo_x = ceilf((fpx - hx - epx - 15.0f) * (1.0f / SGS_TILE_PX)), hi_x = floorf((fpx + hx + epx) * (1.0f / SGS_TILE_PX)) + 1.0f;
-                        const float lo_y = ceilf((fpy - hy - epy - 15.0f) * (1.0f / SGS_TILE_PX)), hi_y = floorf((fpy + hy + epy) * (1.0f / SGS_TILE_PX)) + 1.0f;
+                        // (a cell holds the pixel centres cp t .. cp t + cp - 1, cp = 16 >> z: a power of two, the products are exact)
+                        const float cpl = (float)((SGS_TILE_PX >> z) - 1), icp = (float)(1 << z) * (1.0f / SGS_TILE_PX);
+                        const float lo_x = ceilf((fpx - hx - epx - cpl) * icp), hi_x = floorf((fpx + hx + epx) * icp) + 1.0f;
+                        const float lo_y = ceilf((fpy - hy - epy - cpl) * icp), hi_y = floorf((fpy + hy + epy) * icp) + 1.0f;
                         const int bx0 = max(x0, (int)fmaxf(lo_x, -1.0e6f)), bx1 = min(x1, (int)fminf(hi_x, 1.0e6f));
                         const int by0 = owned_row(P, max(fy0, (int)fmaxf(lo_y, -1.0e6f))), by1 = owned_row(P, min(fy1, (int)fminf(hi_y, 1.0e6f)));
                         if (bx1 > bx0 && by1 > by0) {
@@ -775,9 +794,12 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const double a64 = sqrt(A64 > 0.0 ? A64 : 0.0), c64 = copysign(sqrt(fabs(Cp64)), Cp64);
         // the opacity enters the composite's exponent: alpha / alpha_max = min(1, 2^-(q2 + nlo)),  nlo = log2(alpha_max / o)
         const float nlo = __log2f(P.alpha_max) - __log2f(g0.w);
-        sp[0] = make_float4(sx, sy, (float)a64, (float)(a64 * k64));
-        sp[1] = make_float4((float)c64, nlo, r, g);
-        sp[2] = make_float4(b, depth, ext_x, ext_y);
+        // Fine tiles (sgs_common.h): the composite works in CELL pixels, 2^z per pixel — positions and extents times 2^z, the roots divided
+        // by it (exact), so that U, V and q come out as they would on the frame's own pixel grid, bit for bit up to the cell's origin
+        const float up = (float)(1 << fine_shift(P)), dn = 1.0f / up;
+        sp[0] = make_float4(sx * up, sy * up, (float)a64 * dn, (float)(a64 * k64) * dn);
+        sp[1] = make_float4((float)c64 * dn, nlo, r, g);
+        sp[2] = make_float4(b, depth, fminf(ext_x * up, 3.0e38f), fminf(ext_y * up, 3.0e38f));
         sp[3] = make_float4(qmax, g0.w, __uint_as_float(rect01), __uint_as_float(rect23));
         // what the binning kernels need, densely: one coalesced 1-KiB row per chunk instead of a 48-B-stride gather
         binrec[pos] = uint4{__float_as_uint(depth), brect01, brect23, slot};
@@ -942,7 +964,7 @@ __global__ __launch_bounds__(SGS_SCAN_THREADS) void k_tile_scan(const FrameGroup
         __syncthreads();
         for (int i = tid; i < SGS_SCAN_THREADS + 2; i += SGS_SCAN_THREADS) {
             const unsigned v = s_row[i];
-            const int fr = (first_y + i) * P.row_stride + P.row_phase;
+            const int fr = (int)(frame_row_of(P, (unsigned)(first_y + i)) >> fine_shift(P));     // (the frame's 16-pixel row)
             if (v && fr < SGS_MAX_ROWS) atomicAdd(&row_acc[fr], (unsigned long long)v);
         }
     }
@@ -2047,13 +2069,16 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
 #endif
     const unsigned tile = job.x;
     const unsigned tile_x = tile % (unsigned)P.gx, tile_y = tile / (unsigned)P.gx;
+    // (px, py: CELL pixels — the frame's own pixels unless the frame is rendered through fine tiles, sgs_common.h: then pixel (i, j) of the
+    //  frame is cell pixel (i << z, j << z) and the other lanes have no pixel)
+    const unsigned zf = (unsigned)fine_shift(P), zmask = (1u << zf) - 1u;
     const unsigned px = tile_x * 16u + (unsigned)(wave & 1) * 8u + (unsigned)(lane & 7);
     // tile_y counts the rows this call owns; the pixels it covers are those of frame row tile_y * stride + phase,
     // and it is stored at row tile_y of the (compact, when stride > 1) output image
-    const unsigned frame_y = tile_y * (unsigned)P.row_stride + (unsigned)P.row_phase;
+    const unsigned frame_y = frame_row_of(P, tile_y);
     const unsigned in_y = (unsigned)(wave >> 1) * 8u + (unsigned)(lane >> 3);
     const unsigned py = frame_y * 16u + in_y;
-    const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;      // (again at the end, for the store)
+    const bool inside = ((px | py) & zmask) == 0u && (px >> zf) < (unsigned)P.width && (py >> zf) < (unsigned)P.height;      // (again at the end, for the store)
     const float tile_fx = (float)(tile_x * 16u), tile_fy = (float)(frame_y * 16u);
     // per-frame constants of the trip (the header of the blend macros): all in VGPRs, an SGPR operand costs 1.6 issues
     float amax = P.alpha_max, big = SGS_BIG;
@@ -2688,9 +2713,10 @@ __device__ __forceinline__ void render_tile(const FrameSlot& S, const unsigned b
     {   // (the pixel's coordinates again, from a fresh copy of the thread index: see the group loop)
         int tid_out = tid_entry; SGS_PIN_VGPR(tid_out);
         const unsigned lane_o = (unsigned)tid_out & 63u, wave_o = (unsigned)tid_out >> 6;
-        const unsigned px = tile_x * 16u + (wave_o & 1u) * 8u + (lane_o & 7u), in_y = (wave_o >> 1) * 8u + (lane_o >> 3);
-        const unsigned py = frame_y * 16u + in_y, out_py = tile_y * 16u + in_y;
-        const bool inside = px < (unsigned)P.width && py < (unsigned)P.height;
+        const unsigned cpx = tile_x * 16u + (wave_o & 1u) * 8u + (lane_o & 7u), in_y = (wave_o >> 1) * 8u + (lane_o >> 3);
+        const unsigned cpy = frame_y * 16u + in_y;
+        const bool inside = ((cpx | cpy) & zmask) == 0u && (cpx >> zf) < (unsigned)P.width && (cpy >> zf) < (unsigned)P.height;
+        const unsigned px = cpx >> zf, out_py = (tile_y * 16u + in_y) >> zf;          // cell pixels -> the frame's
     if (inside) {
         float* o = out_rgb + ((size_t)out_py * P.width + px) * 3;
         if (TF) {

@@ -10,12 +10,13 @@ import ctypes as C
 import os
 
 SH_DECODE = {"bin_centre": 3, "linear255": 1, "bin_centre_ends": 2}      # include/sage_gs.h SGS_SH_DECODE_* (0 = unspecified: refused at degree > 0)
-ABI_VERSION = 112        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
+ABI_VERSION = 113        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
 FLAG_ASYNC, FLAG_TIMING, FLAG_STATS, FLAG_FULL_SORT, FLAG_PIPELINED, FLAG_LOOSE_CULL, FLAG_NO_CHUNK_CULL = 1, 2, 4, 8, 16, 32, 64
 FLAG_NO_DEEP = 256
+FLAG_NO_FINE_TILES = 512
 BACKEND_CPU, BACKEND_HIP = 0, 1
 BUF_TILE_OFFSETS, BUF_SORTED_SLOTS, BUF_SLOT_IDS, BUF_SPLATS, BUF_CHUNK_SKIPPED, BUF_SCENE_GEOM, BUF_SCENE_SH = 0, 1, 2, 3, 4, 5, 6
 
@@ -58,7 +59,7 @@ class SgsCompressedScene(C.Structure):
 class SgsTuning(C.Structure):
     """include/sage_gs.h sgs_tuning: the library's whole tuning surface (it reads nothing from the environment)."""
     _fields_ = [("lanes", C.c_int32), ("group", C.c_int32), ("group_lanes", C.c_int32), ("morton", C.c_int32),
-                ("record_capacity", C.c_int64)]
+                ("record_capacity", C.c_int64), ("fine_tile_pixels", C.c_int64)]
 
 
 class SgsStats(C.Structure):

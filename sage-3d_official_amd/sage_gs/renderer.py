@@ -148,9 +148,11 @@ class Renderer:
 
     def __init__(self, device=None, record_capacity: Optional[int] = None, lib: Optional[_capi.Lib] = None, *,
                  lanes: Optional[int] = None, group: Optional[int] = None, group_lanes: Optional[int] = None,
-                 morton: Optional[bool] = None):
-        """lanes / group / group_lanes / morton / record_capacity: include/sage_gs.h `sgs_tuning` (None = the library's default, what the
-        bench runs).  The library reads nothing from the environment; frames do not depend on any of these, bit for bit."""
+                 morton: Optional[bool] = None, fine_tile_pixels: Optional[int] = None):
+        """lanes / group / group_lanes / morton / record_capacity / fine_tile_pixels: include/sage_gs.h `sgs_tuning` (None = the library's
+        default, what the bench runs).  The library reads nothing from the environment; frames do not depend on any of these, bit for bit —
+        except fine_tile_pixels (frames of at most that many pixels are rendered through 8x8-pixel tiles, of a quarter of it through 4x4:
+        the same splats reach every pixel, the blend's coordinates are relative to another tile origin, so frames agree to fp32 rounding)."""
         self._lib = lib or _capi.Lib()
         if not torch.cuda.is_available():
             raise RuntimeError("sage_gs.Renderer needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -163,8 +165,9 @@ class Renderer:
         ctx = C.c_void_p()
         self._lib.check(self._lib.sgs_create(index, _capi.BACKEND_HIP, C.byref(ctx)))
         self._ctx = ctx
-        if any(v is not None for v in (record_capacity, lanes, group, group_lanes, morton)):
-            self.set_tuning(lanes=lanes, group=group, group_lanes=group_lanes, morton=morton, record_capacity=record_capacity)
+        if any(v is not None for v in (record_capacity, lanes, group, group_lanes, morton, fine_tile_pixels)):
+            self.set_tuning(lanes=lanes, group=group, group_lanes=group_lanes, morton=morton, record_capacity=record_capacity,
+                            fine_tile_pixels=fine_tile_pixels)
         self.last_stats = None
 
     def tuning(self) -> dict:
@@ -173,7 +176,7 @@ class Renderer:
         return {k: int(getattr(t, k)) for k, _ in t._fields_}
 
     def set_tuning(self, **kw):
-        """sgs_set_tuning: any of lanes, group, group_lanes, morton, record_capacity (the others keep their values); applies to the scenes
+        """sgs_set_tuning: any of lanes, group, group_lanes, morton, record_capacity, fine_tile_pixels (the others keep their values); applies to the scenes
         uploaded and the frames issued afterwards."""
         t = _capi.SgsTuning()
         self._lib.check(self._lib.sgs_get_tuning(self._ctx, C.byref(t)), self._ctx)
@@ -305,8 +308,11 @@ class Renderer:
                out: Optional[torch.Tensor] = None, out_band: Optional[torch.Tensor] = None,
                tile_rows=None, timing=False, sync=True, full_sort=False, out_aux: Optional[torch.Tensor] = None,
                return_aux=False, pipelined=False, loose_cull=False, interleave=None, chunk_cull=True, stats=False,
-               deep_cull=True):
+               deep_cull=True, fine_tiles=True):
         """One frame -> float32 tensor [H,W,3] on this renderer's device (linear RGB).
+
+        fine_tiles=False (tests, A/B): SGS_FLAG_NO_FINE_TILES — 16x16-pixel tiles whatever the frame's size (by default a frame of at most
+        `fine_tile_pixels` pixels, 640x480, goes through 8x8-pixel tiles and one of a quarter of that through 4x4: DESIGN.md §4.8).
 
         stats=True also counts D_f (records consumed by the composite; SGS_FLAG_STATS) — bookkeeping that costs a sweep ~4 %,
         so it is opt-in; N_v, D and the stage times (timing=True) are always available.
@@ -363,7 +369,7 @@ class Renderer:
                 (_capi.FLAG_FULL_SORT if full_sort else 0) | \
                 (_capi.FLAG_LOOSE_CULL if loose_cull else 0) | \
                 (0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL) | (_capi.FLAG_STATS if stats else 0) | \
-                (0 if deep_cull else _capi.FLAG_NO_DEEP) | \
+                (0 if deep_cull else _capi.FLAG_NO_DEEP) | (0 if fine_tiles else _capi.FLAG_NO_FINE_TILES) | \
                 (_capi.FLAG_PIPELINED if (pipelined and not sync) else 0)   # full_sort: test hook, orders every queue completely
         cam, cfg, st = self._c_camera(camera, scene), self._c_config(config, flags), _capi.SgsStats()
         cfg.tile_row_stride, cfg.tile_row_phase = stride, phase
@@ -398,7 +404,7 @@ class Renderer:
 
     def render_batch(self, cameras: Sequence[Camera], gaussians, *, config: Optional[RenderConfig] = None,
                      out: Optional[torch.Tensor] = None, tile_rows=None, want_stats=False, stats=False,
-                     out_bands: Optional[torch.Tensor] = None, interleave=None):
+                     out_bands: Optional[torch.Tensor] = None, interleave=None, fine_tiles=True):
         """B frames of one scene in ONE call into the library (camera-sweep batch): the frames go through the pipelined
         lanes, and the per-frame host work (stream fork, status clear / copy, completion) is paid once per batch.
 
@@ -415,7 +421,7 @@ class Renderer:
         if any(c.height != h or c.width != w for c in cameras):
             raise ValueError("all cameras of a batch must share a resolution")
         r0, r1 = (0, -1) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
-        cfg = self._c_config(config, _capi.FLAG_STATS if stats else 0)     # (D_f is counted on request only: stats=True)
+        cfg = self._c_config(config, (_capi.FLAG_STATS if stats else 0) | (0 if fine_tiles else _capi.FLAG_NO_FINE_TILES))     # (D_f is counted on request only: stats=True)
         if out_bands is not None:
             if out is not None:
                 raise ValueError("give out or out_bands, not both")

@@ -86,8 +86,9 @@ class EmuRenderer:
         return self.debug(_capi.BUF_SCENE_SH, np.float32).reshape(self.n, -1, 3)
 
     def render(self, cam, cfg=None, rows=(0, -1), out=None, flags=0, full_sort=False, loose_cull=False, interleave=None,
-               chunk_cull=True, stats=True, deep=True):
+               chunk_cull=True, stats=True, deep=True, fine=True):
         flags |= 0 if chunk_cull else _capi.FLAG_NO_CHUNK_CULL
+        flags |= 0 if fine else _capi.FLAG_NO_FINE_TILES
         flags |= 0 if deep else _capi.FLAG_NO_DEEP
         flags |= _capi.FLAG_STATS if stats else 0
         flags |= _capi.FLAG_FULL_SORT if full_sort else 0
@@ -113,10 +114,11 @@ class EmuRenderer:
                                            out.ctypes.data, C.byref(st), None), self.ctx)
         return out, st.as_dict()
 
-    def render_aux(self, cam, cfg=None):
+    def render_aux(self, cam, cfg=None, fine=True):
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                               np.asarray(cam.view, np.float32).reshape(4, 4).tolist())
         k = self.lib.default_config()
+        k.flags = 0 if fine else _capi.FLAG_NO_FINE_TILES
         out = np.zeros((cam.height, cam.width, 3), np.float32)
         aux = np.zeros((cam.height, cam.width, 2), np.float32)
         st = _capi.SgsStats()
@@ -126,6 +128,18 @@ class EmuRenderer:
 
     def set_record_capacity(self, n):
         self.lib.check(self.lib.sgs_set_record_capacity(self.ctx, int(n)), self.ctx)
+
+    def set_tuning(self, **kw):
+        t = _capi.SgsTuning()
+        self.lib.check(self.lib.sgs_get_tuning(self.ctx, C.byref(t)), self.ctx)
+        for k, v in kw.items():
+            setattr(t, k, int(v))
+        self.lib.check(self.lib.sgs_set_tuning(self.ctx, C.byref(t)), self.ctx)
+
+    def tuning(self):
+        t = _capi.SgsTuning()
+        self.lib.check(self.lib.sgs_get_tuning(self.ctx, C.byref(t)), self.ctx)
+        return {k: int(getattr(t, k)) for k, _ in t._fields_}
 
     def chunk_skipped(self):
         return self.debug(_capi.BUF_CHUNK_SKIPPED, np.uint8)

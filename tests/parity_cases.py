@@ -45,24 +45,25 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     of a multi-million-Gaussian scene are checked against one upload)."""
     if upload:
         drv.upload(*scene)
-    # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them
-    img, st = drv.render(cam, cfg, rows)
+    # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them — on 16x16-pixel tiles, the tiling
+    # of the reference's integer structures and of the test hooks (a small frame's default, fine tiles, is checked at the end)
+    img, st = drv.render(cam, cfg, rows, fine=False)
     # ... which counts D_f only on request (the drivers ask for it): the instantiation without the bookkeeping — the one
     # a sweep runs — must produce the same frame from the same queues
-    img_plain, st_plain = drv.render(cam, cfg, rows, stats=False)
+    img_plain, st_plain = drv.render(cam, cfg, rows, stats=False, fine=False)
     assert (img_plain == img).all() and st_plain["d_total"] == st["d_total"] and st_plain["n_visible"] == st["n_visible"] \
         and st_plain["d_fetched"] == 0, f"{what}: the frame depends on whether D_f is counted"
     # (the instantiation without D_f is also the only one that takes the deep-tile path: windows of a long-lived tile culled against its
     #  live pixels before anything is ranked — the comparison above holds the two paths against each other, bit for bit; and so does the
     #  runtime switch, SGS_FLAG_NO_DEEP, inside the one instantiation)
-    img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, deep=False)
+    img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, deep=False, fine=False)
     assert (img_nodeep == img).all() and st_nodeep["n_deep_windows"] == 0, f"{what}: the deep-tile cull changed a pixel"
     assert st["n_deep_windows"] == 0
     st["n_deep_windows_plain"] = st_plain["n_deep_windows"]
     # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
     # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
     drv.row_records(0, reset=True)
-    img_all, st_all = drv.render(cam, cfg, rows, chunk_cull=False)
+    img_all, st_all = drv.render(cam, cfg, rows, chunk_cull=False, fine=False)
     assert (img_all == img).all() and st_all["n_visible"] == st["n_visible"] and st_all["d_total"] == st["d_total"] \
         and st_all["d_fetched"] == st["d_fetched"], f"{what}: chunk culling changed the frame"
     # the per-row record counters (what cost-balanced bands are cut from) add up to D
@@ -109,6 +110,22 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     if "d_fetched" in st_loose and st_loose["d_fetched"]:
         # D_f (reference binning) only differs from the oracle's where a pixel sat on the termination threshold
         assert abs(st_loose["d_fetched"] - aux["D_f"]) <= max(8, 2e-3 * aux["D_f"]), (what, st_loose["d_fetched"], aux["D_f"])
+    # FINE TILES — what the library does with a frame this small unless told otherwise (sgs_tuning.fine_tile_pixels; sgs_common.h): the frame
+    # through tiles of 8x8 or 4x4 pixels.  The same splats reach every pixel (S3's rect stays a rect of 16x16-pixel tiles: N_v is the
+    # oracle's), the blend's coordinates are relative to another origin: the oracle's frame within the same tolerance, every pixel,
+    # threshold-sensitive ones two-sidedly — and the instantiations / switches that must not change a frame do not change this one either.
+    img_f, st_f = drv.render(cam, cfg, rows)
+    st["n_tiles_default"] = st_f["n_tiles"]
+    if st_f["n_tiles"] != st["n_tiles"]:
+        assert st_f["n_visible"] == aux["n_visible"], (what, st_f["n_visible"], aux["n_visible"])
+        img_fp, st_fp = drv.render(cam, cfg, rows, stats=False)
+        assert (img_fp == img_f).all() and st_fp["d_total"] == st_f["d_total"], f"{what}: fine tiles: the frame depends on whether D_f is counted"
+        img_fn, _ = drv.render(cam, cfg, rows, stats=False, deep=False)
+        img_fa, st_fa = drv.render(cam, cfg, rows, chunk_cull=False)
+        assert (img_fn == img_f).all() and (img_fa == img_f).all() and st_fa["d_total"] == st_f["d_total"], f"{what}: fine tiles: a switch changed the frame"
+        worst = max(worst, assert_frame_close(img_f[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " [fine tiles]", y0=ya))
+    else:
+        assert (img_f == img).all(), f"{what}: SGS_FLAG_NO_FINE_TILES changed a frame that is not rendered through fine tiles"
     return img, st, aux, worst
 
 
@@ -254,35 +271,40 @@ def case_empty(drv):
 
 def case_interleaved_rows(drv, stride, n=2500, res=(208, 150)):
     """Interleaved tile-row shards (rank p of `stride` owns frame rows p, p+stride, ...): every shard's compact image
-    holds exactly those rows of the full frame, bit for bit, and the shards' queues add up to the frame's."""
+    holds exactly those rows of the full frame, bit for bit, and the shards' queues add up to the frame's — on 16x16-pixel tiles and on
+    the fine tiles a frame this small gets by default (a 16-pixel row is then 2 or 4 rows of tiles, owned or not as a whole)."""
     scene = random_scene(n, 7, 2, scale=(0.03, 0.3))
     w, h = res
     cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    full, st_full = drv.render(cam)
-    _, st_full_ref = drv.render(cam, loose_cull=True)
     gy = (h + 15) // 16
-    d_sum = d_ref_sum = pix = 0
-    seen = np.zeros(gy, bool)
-    for phase in range(stride):
-        img, st = drv.render(cam, interleave=(stride, phase))
-        _, st_ref = drv.render(cam, interleave=(stride, phase), loose_cull=True)
-        owned = list(range(phase, gy, stride))
-        assert img.shape[0] == 16 * len(owned) and st["n_tiles"] == len(owned) * ((w + 15) // 16)
-        for k, row in enumerate(owned):
-            y0, y1 = 16 * row, min(16 * row + 16, h)
-            assert (img[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"stride {stride} phase {phase}: frame row {row}"
-            assert (img[16 * k + (y1 - y0): 16 * k + 16] == -1).all(), "pixels below the frame must stay untouched"
-            seen[row] = True
-            pix += (y1 - y0) * w
-        d_sum += st["d_total"]; d_ref_sum += st_ref["d_total"]
-        # a sub-range of the owned rows: only those are written
-        if len(owned) >= 2:
-            part, st_p = drv.render(cam, rows=(1, 2), interleave=(stride, phase))
-            y0, y1 = 16 * owned[1], min(16 * owned[1] + 16, h)
-            assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
-    assert seen.all() and pix == w * h
-    assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
+    for fine in (False, True):
+        full, st_full = drv.render(cam, fine=fine)
+        _, st_full_ref = drv.render(cam, loose_cull=True)
+        assert (st_full["n_tiles"] != gy * ((w + 15) // 16)) == fine, "this frame is meant to be small enough for fine tiles"
+        cp = next(c for c in (16, 8, 4) if -(-w // c) * -(-h // c) == st_full["n_tiles"])          # the tile's side in pixels
+        d_sum = d_ref_sum = pix = 0
+        seen = np.zeros(gy, bool)
+        for phase in range(stride):
+            img, st = drv.render(cam, interleave=(stride, phase), fine=fine)
+            _, st_ref = drv.render(cam, interleave=(stride, phase), loose_cull=True)
+            owned = list(range(phase, gy, stride))
+            rows_of_tiles = sum(-(-(min(16 * row + 16, h) - 16 * row) // cp) for row in owned)
+            assert img.shape[0] == 16 * len(owned) and st["n_tiles"] == rows_of_tiles * (-(-w // cp)), (st["n_tiles"], rows_of_tiles, cp)
+            for k, row in enumerate(owned):
+                y0, y1 = 16 * row, min(16 * row + 16, h)
+                assert (img[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"stride {stride} phase {phase}: frame row {row} (fine {fine})"
+                assert (img[16 * k + (y1 - y0): 16 * k + 16] == -1).all(), "pixels below the frame must stay untouched"
+                seen[row] = True
+                pix += (y1 - y0) * w
+            d_sum += st["d_total"]; d_ref_sum += st_ref["d_total"]
+            # a sub-range of the owned rows: only those are written
+            if len(owned) >= 2:
+                part, st_p = drv.render(cam, rows=(1, 2), interleave=(stride, phase), fine=fine)
+                y0, y1 = 16 * owned[1], min(16 * owned[1] + 16, h)
+                assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
+        assert seen.all() and pix == w * h
+        assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
 
 
 def case_chunk_bounds(drv, n=6000, res=(208, 150)):
@@ -317,28 +339,31 @@ def case_chunk_bounds(drv, n=6000, res=(208, 150)):
 
 
 def case_tile_rows(drv, n=2500, res=(208, 150)):
-    """Tile-row shards: each band equals the oracle's band; their union equals the full frame bit-exactly."""
+    """Tile-row shards: each band equals the oracle's band; their union equals the full frame bit-exactly (16x16-pixel tiles and the fine
+    tiles a frame this small gets by default)."""
     scene = random_scene(n, 7, 2, scale=(0.03, 0.3))
     w, h = res
     cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    full, st_full = drv.render(cam)
     gy = (h + 15) // 16
     cuts = [0, gy // 3, gy // 3 + 1, gy]
-    union = np.full_like(full, -1.0)
-    d_sum = 0
-    for r0, r1 in zip(cuts[:-1], cuts[1:]):
-        out = np.full_like(full, -1.0)
-        img, st = drv.render(cam, None, (r0, r1), out=out)
-        y0, y1 = r0 * 16, min(r1 * 16, h)
-        assert (img[:y0] == -1).all() and (img[y1:] == -1).all(), "rows outside the band must be untouched"
-        ref, aux = oracle_c.render(*scene, cam, None, r0, r1)
-        _, st_ref = drv.render(cam, None, (r0, r1), loose_cull=True)      # reference binning: the oracle's D
-        assert st_ref["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"] and st["d_total"] <= aux["D"]
-        union[y0:y1] = img[y0:y1]
-        d_sum += st["d_total"]
-    assert (union == full).all(), "union of tile-row bands != full frame"
-    assert d_sum == st_full["d_total"]
+    for fine in (False, True):
+        full, st_full = drv.render(cam, fine=fine)
+        union = np.full_like(full, -1.0)
+        d_sum = 0
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            out = np.full_like(full, -1.0)
+            img, st = drv.render(cam, None, (r0, r1), out=out, fine=fine)
+            y0, y1 = r0 * 16, min(r1 * 16, h)
+            assert (img[:y0] == -1).all() and (img[y1:] == -1).all(), "rows outside the band must be untouched"
+            ref, aux = oracle_c.render(*scene, cam, None, r0, r1)
+            _, st_ref = drv.render(cam, None, (r0, r1), loose_cull=True)      # reference binning: the oracle's D
+            assert st_ref["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"] and (fine or st["d_total"] <= aux["D"])
+            assert_frame_close(img[y0:y1], ref[y0:y1], aux["margin"][y0:y1], aux["recheck"], what=f"tile rows [{r0}, {r1}) fine={fine}", y0=y0)
+            union[y0:y1] = img[y0:y1]
+            d_sum += st["d_total"]
+        assert (union == full).all(), f"union of tile-row bands != full frame (fine {fine})"
+        assert d_sum == st_full["d_total"]
 
 
 def case_depth_ties(drv):
@@ -483,7 +508,7 @@ def case_overflow_retry(drv):
     img, st, aux, _ = check_against_oracle(drv, scene, cam, what="overflow -> grow -> retry")
     assert st["d_total"] > 1024 and st["retries"] >= 1
     # and once grown, no more retries
-    img2, st2 = drv.render(cam)
+    img2, st2 = drv.render(cam, fine=False)
     assert st2["retries"] == 0 and (img2 == img).all()
 
 
@@ -509,12 +534,15 @@ def case_determinism(drv, n=4000):
     scene = random_scene(n, 31, 1, scale=(0.03, 0.3))
     cam = onp.Camera(176, 144, 120.0, 120.0, 88.0, 72.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    a, _ = drv.render(cam, full_sort=True)
+    a, st = drv.render(cam, full_sort=True)
     ids_a = drv.intermediates()[1].copy()
     b, _ = drv.render(cam, full_sort=True)
     ids_b = drv.intermediates()[1]
-    c, _ = drv.render(cam)
+    c, _ = drv.render(cam, fine=False)
     assert (c == a).all()
-    p1, _ = drv.render(cam, stats=False); p2, _ = drv.render(cam, stats=False)      # the production instantiation twice
+    p1, _ = drv.render(cam, stats=False, fine=False); p2, _ = drv.render(cam, stats=False, fine=False)      # the production instantiation twice
     assert (p1 == p2).all() and (p1 == a).all(), "two production renders of the same frame differ"
     assert (a == b).all() and (ids_a == ids_b).all(), "two renders of the same frame differ"
+    f1, st1 = drv.render(cam, stats=False); f2, st2 = drv.render(cam, stats=False)  # ... and as a frame this small is rendered by default: fine tiles
+    assert st1["n_tiles"] > st["n_tiles"] and (f1 == f2).all() and st1 == st2, "two fine-tile renders of the same frame differ"
+    assert float(np.mean(np.abs(f1 - a).max(axis=-1) > 1e-5)) < 2e-3 and float(np.median(np.abs(f1 - a))) < 1e-6, "fine tiles moved the frame by more than rounding"

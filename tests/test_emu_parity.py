@@ -127,13 +127,16 @@ def test_against_committed_golden_fixture(drv):
     scene, _ = onp.config1_scene(n=int(g["n"]), seed=int(g["seed"]))
     cam = onp.Camera(int(g["width"]), int(g["height"]), float(g["f"]), float(g["f"]), 64.0, 64.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    prod, st_prod = drv.render(cam)                                   # production: tight bin rects, lazy sort
+    prod, st_prod = drv.render(cam, fine=False)                       # production: tight bin rects, lazy sort (16x16-pixel tiles, as the hooks)
     img, st = drv.render(cam, full_sort=True, loose_cull=True)          # reference binning: the fixture's integer structures
     assert (prod == img).all() and st_prod["d_total"] <= st["d_total"]
     off, ids, _, _ = drv.intermediates()
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
     assert_frame_close(img, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1")
+    fine, st_fine = drv.render(cam)                                   # ... and the frame as it is rendered by default: fine tiles
+    assert st_fine["n_tiles"] > st_prod["n_tiles"] and st_fine["n_visible"] == int(g["n_visible"])
+    assert_frame_close(fine, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1 [fine tiles]")
 
 
 def test_pipelined_frames_and_batch_rotate_over_lanes(drv):
@@ -386,26 +389,43 @@ def test_tuning_surface(drv):
     lib, ctx = drv.lib, drv.ctx
     t = _capi.SgsTuning()
     lib.sgs_tuning_default(C.byref(t))
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == (3, 4, 2, 1, 16 << 20)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == (3, 4, 2, 1, 16 << 20, 640 * 480)
     scene = pc.random_scene(900, 41, 1, scale=(0.05, 0.3))
     cam = onp.Camera(96, 64, 70.0, 70.0, 48.0, 32.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
     want, st0 = drv.render(cam, stats=False)
+    want16, st16 = drv.render(cam, stats=False, fine=False)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity)
+    keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels)
     for bad in ((0, 4, 2), (9, 4, 2), (3, 9, 1), (3, 4, 3), (3, 0, 1)):
-        u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20)
+        u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20, 640 * 480)
         assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"sgs_tuning" in lib.sgs_last_error(ctx)
-    u = _capi.SgsTuning(3, 4, 2, 1, 0)
+    u = _capi.SgsTuning(3, 4, 2, 1, 0, 640 * 480)
     assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1
+    u = _capi.SgsTuning(3, 4, 2, 1, 1 << 20, -1)
+    assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"fine_tile_pixels" in lib.sgs_last_error(ctx)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == keep, "a refused tuning changed the context"
-    u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == keep, "a refused tuning changed the context"
+    u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, 640 * 480)
     lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity) == (5, 2, 3, 0, 1 << 20)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == (5, 2, 3, 0, 1 << 20, 640 * 480)
     drv.upload(*scene)                                   # (morton = 0: the caller's order is kept)
     got, st1 = drv.render(cam, stats=False)
     assert (got == want).all() and st1["n_visible"] == st0["n_visible"] and st1["d_total"] == st0["d_total"]
+    # fine_tile_pixels is the one field a frame depends on (to rounding): which tiles a frame of W x H pixels is rendered through —
+    # 4x4-pixel tiles up to a quarter of it, 8x8 up to it, 16x16 above (= SGS_FLAG_NO_FINE_TILES, bit for bit); the count of tiles says which
+    tiles = lambda c: -(-96 // c) * -(-64 // c)
+    assert st0["n_tiles"] == tiles(4) and st16["n_tiles"] == tiles(16)
+    for fp, side in ((0, 16), (96 * 64 - 1, 16), (96 * 64, 8), (4 * 96 * 64 - 1, 8), (4 * 96 * 64, 4), (1 << 40, 4)):
+        u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, fp)
+        lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)
+        img, st = drv.render(cam, stats=False)
+        assert st["n_tiles"] == tiles(side), (fp, side, st["n_tiles"])
+        assert st["n_visible"] == st0["n_visible"] and float(np.abs(img - want16).max()) < 1e-5        # (no pixel of this frame sits on a threshold)
+        if side == 16:
+            assert (img == want16).all() and st["d_total"] == st16["d_total"]
+        if side == 4:
+            assert (img == want).all() and st["d_total"] == st0["d_total"]
     u = _capi.SgsTuning(*keep)
     lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)

@@ -33,7 +33,7 @@ class GpuDriver:
         self.scene = self.r.upload(Gaussians(t(means), t(scales), t(quats), t(opac), t(sh), deg))
 
     def render(self, cam, cfg=None, rows=(0, -1), out=None, full_sort=False, loose_cull=False, interleave=None,
-               chunk_cull=True, stats=True, deep=True):
+               chunk_cull=True, stats=True, deep=True, fine=True):
         from sage_gs import Camera, RenderConfig
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
         k = None if cfg is None else RenderConfig(cfg.near, cfg.far, cfg.dilation, cfg.clamp, cfg.alpha_min,
@@ -43,17 +43,17 @@ class GpuDriver:
             band = self.torch.full((16 * owned, cam.width, 3), -1.0, dtype=self.torch.float32, device="cuda:0")
             img = self.r.render(c, self.scene, config=k, out_band=band, tile_rows=None if rows == (0, -1) else rows,
                                 full_sort=full_sort, loose_cull=loose_cull, interleave=interleave, chunk_cull=chunk_cull, stats=stats,
-                                deep_cull=deep)
+                                deep_cull=deep, fine_tiles=fine)
             return img.cpu().numpy(), self.r.last_stats
         o = None if out is None else self.torch.from_numpy(out).to("cuda:0")
         img = self.r.render(c, self.scene, config=k, out=o, tile_rows=None if rows == (0, -1) else rows,
-                            full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull, stats=stats, deep_cull=deep)
+                            full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull, stats=stats, deep_cull=deep, fine_tiles=fine)
         return img.cpu().numpy(), self.r.last_stats
 
-    def render_aux(self, cam, cfg=None):
+    def render_aux(self, cam, cfg=None, fine=True):
         from sage_gs import Camera
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
-        img, aux = self.r.render(c, self.scene, return_aux=True)
+        img, aux = self.r.render(c, self.scene, return_aux=True, fine_tiles=fine)
         return img.cpu().numpy(), aux.cpu().numpy()
 
     def intermediates(self):
@@ -61,6 +61,12 @@ class GpuDriver:
 
     def set_record_capacity(self, n):
         self.r.set_record_capacity(n)
+
+    def set_tuning(self, **kw):
+        self.r.set_tuning(**kw)
+
+    def tuning(self):
+        return self.r.tuning()
 
     def chunk_skipped(self):
         from sage_gs import _capi
@@ -573,13 +579,25 @@ def test_culling_never_changes_a_pixel_stress(drv):
         c, si = np.cos(yaw), np.sin(yaw)
         V = np.eye(4); V[:3, :3] = np.array([[c, 0, -si], [0, 1, 0], [si, 0, c]])
         cam = Camera(640, 480, 400.0, 400.0, 320.0, 240.0, V)
-        prod = drv.r.render(cam, scene).clone()
+        prod = drv.r.render(cam, scene, fine_tiles=False).clone()
         st = drv.r.last_stats
         ref = drv.r.render(cam, scene, loose_cull=True)
         st_ref = drv.r.last_stats
         assert (prod == ref).all(), f"yaw {yaw}: {(prod != ref).sum().item()} values differ"
         assert st["n_visible"] == st_ref["n_visible"] and st["d_total"] < st_ref["d_total"]
         assert torch.isfinite(prod).all()
+        # ... and as a 640x480 frame is rendered by default — through 8x8-pixel tiles (sgs_tuning.fine_tile_pixels): the same splats reach
+        # every pixel, the blend's coordinates are relative to another origin; held against the ORACLE here, every pixel, threshold-sensitive
+        # ones two-sidedly (the needles' exponents cancel from ~1e6 to ~1: the scene the completed-square form was made for)
+        fine = drv.r.render(cam, scene).cpu().numpy()
+        st_f = drv.r.last_stats
+        assert st_f["n_tiles"] == 80 * 60 and st_f["n_visible"] == st["n_visible"]
+        ocam = onp.Camera(640, 480, 400.0, 400.0, 320.0, 240.0, V.astype(np.float32))
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        o_ref, aux = oracle_c.render(f32(means), f32(s), f32(quats), f32(opac), f32(sh), 3, ocam)
+        assert st_f["n_visible"] == aux["n_visible"]
+        assert_frame_close(fine, o_ref, aux["margin"], aux["recheck"], what=f"adversarial splats, yaw {yaw} [fine tiles]")
+        aux["recheck"].close()
     scene.free()
 
 
@@ -596,13 +614,16 @@ def test_against_committed_golden_fixture(drv):
     scene, _ = onp.config1_scene(n=int(g["n"]), seed=int(g["seed"]))
     cam = onp.Camera(int(g["width"]), int(g["height"]), float(g["f"]), float(g["f"]), 64.0, 64.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    prod, st_prod = drv.render(cam)                                   # production: tight bin rects, lazy sort
+    prod, st_prod = drv.render(cam, fine=False)                       # production: tight bin rects, lazy sort (16x16-pixel tiles, as the hooks)
     img, st = drv.render(cam, full_sort=True, loose_cull=True)          # reference binning: the fixture's integer structures
     assert (prod == img).all() and st_prod["d_total"] <= st["d_total"]
     off, ids, _, _ = drv.intermediates()
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
     assert_frame_close(img, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1")
+    fine, st_fine = drv.render(cam)                                   # ... and the frame as it is rendered by default: fine tiles
+    assert st_fine["n_tiles"] > st_prod["n_tiles"] and st_fine["n_visible"] == int(g["n_visible"])
+    assert_frame_close(fine, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1 [fine tiles]")
 
 
 def test_batch_equals_single_frames(drv):
@@ -962,7 +983,8 @@ def test_frames_do_not_depend_on_the_tuning(drv):
     cams = scenes.room_cameras(sc, 800, 600, n_positions=2, n_yaw=5, seed=6)
     g = scenes.to_gaussians(sc, "cuda:0")
     scene = drv.r.upload(g)
-    assert drv.r.tuning() == {"lanes": 3, "group": 4, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"]}
+    assert drv.r.tuning() == {"lanes": 3, "group": 4, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"],
+                              "fine_tile_pixels": 640 * 480}
     want, stats = [], []
     for c in cams:
         want.append(drv.r.render(c, scene).clone()); stats.append((drv.r.last_stats["n_visible"], drv.r.last_stats["d_total"]))
@@ -987,10 +1009,32 @@ def test_frames_do_not_depend_on_the_tuning(drv):
         s2.free(); r.close()
     # refused, with a message, not clamped
     r = Renderer("cuda:0")
-    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5)):
+    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5), dict(fine_tile_pixels=-1)):
         with pytest.raises(Exception, match="sgs_tuning"):
             r.set_tuning(**bad)
-    r.close()
+    # fine_tile_pixels — the one field a frame depends on, to rounding: which tiles a frame of W x H pixels is rendered through.  A frame
+    # issued alone, pipelined and in a batch is the same frame under every value; 0 = SGS_FLAG_NO_FINE_TILES, bit for bit
+    s2 = r.upload(g)
+    small = scenes.room_cameras(sc, 400, 300, n_positions=2, n_yaw=3, seed=6)
+    w16 = [r.render(c, s2, fine_tiles=False).clone() for c in small]
+    n16 = r.last_stats["n_tiles"]
+    for fp, side in ((0, 16), (400 * 300, 8), (640 * 480, 8), (4 * 400 * 300, 4)):
+        r.set_tuning(fine_tile_pixels=fp)
+        one = [r.render(c, s2).clone() for c in small]
+        assert r.last_stats["n_tiles"] == -(-400 // side) * -(-300 // side), (fp, side, r.last_stats["n_tiles"])
+        outs = [torch.zeros_like(one[0]) for _ in small]
+        for c, o in zip(small, outs):
+            r.render(c, s2, out=o, sync=False, pipelined=True)
+        r.sync()
+        batch = r.render_batch(small, s2)
+        for i in range(len(small)):
+            assert (outs[i] == one[i]).all() and (batch[i] == one[i]).all(), f"fine_tile_pixels {fp}: frame {i} depends on how it is issued"
+            d = (one[i] - w16[i]).abs().amax(dim=-1)
+            assert float((d > 1e-5).float().mean()) < 1e-3 and float(d.median()) < 1e-6, (fp, i, float(d.max()))
+            if side == 16:
+                assert (one[i] == w16[i]).all()
+    assert n16 == 25 * 19
+    s2.free(); r.close()
 
 
 def test_compressed_payload_known_answer_vectors_on_the_device(drv):
