@@ -354,10 +354,14 @@ void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t
     // a wave per chunk of the scene (most end at once) — except for a group of narrow bands, whose frames share
     // pre_grid workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
     const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
-    if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all)
-        hipLaunchKernelGGL((sgs::k_preprocess<true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
-    else
-        hipLaunchKernelGGL((sgs::k_preprocess<false>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
+    const bool fine = ((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u) != 0u;        // (fine tiles: the instantiation that scales the splats, sgs_common.h)
+    if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all) {
+        if (fine) hipLaunchKernelGGL((sgs::k_preprocess<true, true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
+        else hipLaunchKernelGGL((sgs::k_preprocess<true, false>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
+    } else {
+        if (fine) hipLaunchKernelGGL((sgs::k_preprocess<false, true>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
+        else hipLaunchKernelGGL((sgs::k_preprocess<false, false>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
+    }
 }
 // S4, two levels (six launches); ev_mid (nullable) is recorded between the levels
 int launch_binning(sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t stream, hipEvent_t ev_mid) {

@@ -564,7 +564,10 @@ __device__ __forceinline__ unsigned frame_row_of(const FrameParams& P, unsigned 
     return ((k16 * (unsigned)P.row_stride + (unsigned)P.row_phase) << z) + (r - (k16 << z));
 }
 
-// One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.
+// One wave's worth of S1-S3: 64 Gaussians of chunk `chunk`.  FINE: the frame may be rendered through fine tiles (sgs_common.h; z from the
+// frame's flags) — an instantiation of its own, so that the ordinary frame's kernel carries none of it (the shifts and scalings cost the
+// HBM-bound 1080p projection 2 us of 64 when they were unconditional, r06t).
+template <bool FINE>
 __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const float4* __restrict__ geom,
                                                  const float4* __restrict__ shq, Splat* __restrict__ splats,
                                                  unsigned long long* __restrict__ vismask,
@@ -572,6 +575,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                                                  uint4* __restrict__ binrec,
                                                  FrameStatus* __restrict__ st, long long chunk, int lane) {
     const long long pos = chunk * SGS_WAVE + lane;      // position in the (Z-ordered) scene layout
+    const int zf = FINE ? fine_shift(P) : 0;            // (uniform; the compiler folds every use away when !FINE)
 
     // all three geometry rows of the chunk are requested at once (1-KiB rows; a live chunk nearly always has lanes that need
     // the second and third): loading each one only behind the test that needs it made three dependent trips to HBM
@@ -606,7 +610,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float rb = (3.0f * sqrtf(2.0f * lmax + 0.3163f) + 1.0f) * 1.001f + 0.5f;
         const float pxf = P.fx * (float)tx * inv + P.cx - 0.5f, pyf = P.fy * (float)ty * inv + P.cy - 0.5f;
         const float ex = 1.0e-5f * fabsf(pxf) + 0.01f, ey = 1.0e-5f * fabsf(pyf) + 0.01f;
-        const bool out_x = pxf + rb + ex < 1.0f || pxf - rb - ex >= (float)(SGS_TILE_PX * ((P.gx + (1 << fine_shift(P)) - 1) >> fine_shift(P)));   // (16 x the frame's 16-pixel tiles)
+        const bool out_x = pxf + rb + ex < 1.0f || pxf - rb - ex >= (float)(SGS_TILE_PX * ((P.gx + (1 << zf) - 1) >> zf));   // (16 x the frame's 16-pixel tiles)
         const bool out_y = pyf + rb + ey < (float)P.cull_y0 + 1.0f || pyf - rb - ey >= (float)P.cull_y1;
         maybe = !(out_x || out_y);                   // (NaN anywhere keeps the Gaussian)
     }
@@ -661,14 +665,14 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
             const double py = fy * yz + (double)P.cy - 0.5;
             // (S3's rect is a rect of 16x16-PIXEL tiles whatever the frame's cells are: with fine tiles — z > 0, sgs_common.h — it is
             //  computed on the frame's 16-pixel grid and then mapped to the cells it covers, 2^z per tile and axis, clipped to the grid of cells)
-            const int z = fine_shift(P), zr = (1 << z) - 1;
-            const int gx16 = (P.gx + zr) >> z, gy16 = (P.gy + zr) >> z;
-            const int x0 = min(tile_clamp((px - radius) / SGS_TILE_PX, 0, gx16) << z, P.gx);
-            const int x1 = min(tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gx16) << z, P.gx);
+            const int zr = (1 << zf) - 1;
+            const int gx16 = (P.gx + zr) >> zf, gy16 = (P.gy + zr) >> zf;
+            const int x0 = min(tile_clamp((px - radius) / SGS_TILE_PX, 0, gx16) << zf, P.gx);
+            const int x1 = min(tile_clamp((px + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gx16) << zf, P.gx);
             // frame rows [fy0, fy1) -> the rows this call owns: the contiguous band, or every row_stride-th row from
             // row_phase (then a rect's rows are again a contiguous range of OWNED rows, so binning never knows)
-            const int fy0 = min(tile_clamp((py - radius) / SGS_TILE_PX, 0, gy16) << z, P.gy);
-            const int fy1 = min(tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gy16) << z, P.gy);
+            const int fy0 = min(tile_clamp((py - radius) / SGS_TILE_PX, 0, gy16) << zf, P.gy);
+            const int fy1 = min(tile_clamp((py + radius + (SGS_TILE_PX - 1)) / SGS_TILE_PX, 0, gy16) << zf, P.gy);
             const int y0 = owned_row(P, fy0), y1 = owned_row(P, fy1);
             const int nt = (x1 - x0) * (y1 - y0);
             if (nt > 0) {
@@ -712,7 +716,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
                         const float fpx = (float)px, fpy = (float)py;
                         const float epx = 1.0e-6f * fabsf(fpx), epy = 1.0e-6f * fabsf(fpy);
                         // (a cell holds the pixel centres cp t .. cp t + cp - 1, cp = 16 >> z: a power of two, the products are exact)
-                        const float cpl = (float)((SGS_TILE_PX >> z) - 1), icp = (float)(1 << z) * (1.0f / SGS_TILE_PX);
+                        const float cpl = (float)((SGS_TILE_PX >> zf) - 1), icp = (float)(1 << zf) * (1.0f / SGS_TILE_PX);
                         const float lo_x = ceilf((fpx - hx - epx - cpl) * icp), hi_x = floorf((fpx + hx + epx) * icp) + 1.0f;
                         const float lo_y = ceilf((fpy - hy - epy - cpl) * icp), hi_y = floorf((fpy + hy + epy) * icp) + 1.0f;
                         const int bx0 = max(x0, (int)fmaxf(lo_x, -1.0e6f)), bx1 = min(x1, (int)fminf(hi_x, 1.0e6f));
@@ -796,7 +800,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
         const float nlo = __log2f(P.alpha_max) - __log2f(g0.w);
         // Fine tiles (sgs_common.h): the composite works in CELL pixels, 2^z per pixel — positions and extents times 2^z, the roots divided
         // by it (exact), so that U, V and q come out as they would on the frame's own pixel grid, bit for bit up to the cell's origin
-        const float up = (float)(1 << fine_shift(P)), dn = 1.0f / up;
+        const float up = (float)(1 << zf), dn = 1.0f / up;
         sp[0] = make_float4(sx * up, sy * up, (float)a64 * dn, (float)(a64 * k64) * dn);
         sp[1] = make_float4((float)c64 * dn, nlo, r, g);
         sp[2] = make_float4(b, depth, fminf(ext_x * up, 3.0e38f), fminf(ext_y * up, 3.0e38f));
@@ -819,7 +823,7 @@ __device__ __forceinline__ void preprocess_chunk(const FrameParams& P, const flo
 //               Not for full frames: the loop makes the compiler keep the frame's constants (the view matrix as doubles, ...)
 //               in 43 more VGPRs — 135 instead of 92, three waves per SIMD instead of five, and a wave that no longer fits
 //               beside the composite's workgroups of the frames in flight (a sweep was 2 % slower, r03z).
-template <bool LOOP>
+template <bool LOOP, bool FINE>
 __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];                  // this workgroup's frame of the group
     const FrameParams& P = S.P;
@@ -832,11 +836,11 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     const unsigned n_live = st->n_live, k0 = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (!LOOP) {
         if (k0 >= n_live) return;                          // wave-uniform
-        preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k0], lane);
+        preprocess_chunk<FINE>(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k0], lane);
     } else {
         const unsigned nw = gridDim.x * (blockDim.x >> 6);
         for (unsigned k = k0; k < n_live; k += nw)         // wave-uniform
-            preprocess_chunk(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
+            preprocess_chunk<FINE>(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
     }
 }
 

@@ -74,7 +74,7 @@ for set_, log in (("default", "pmc_default_sq1.log"), ("k20", "pmc_k20_sq1.log")
     line = [l for l in open("$OUT/" + log) if l.startswith("{")][-1]
     tag = json.loads(line)["config"]["pose_set"]
     # (two-level binning: stage "count" = level 1, splats -> super-tile queues; stage "emit" = level 2, super-tile queues -> tile queues)
-    stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess<false>", "sgs::k_preprocess<true>"], "count": ["sgs::k_bin_count", "sgs::k_stile_scan", "sgs::k_bin_emit"],
+    stage = {"preprocess": ["sgs::k_chunk_cull", "sgs::k_preprocess<false, false>", "sgs::k_preprocess<true, false>", "sgs::k_preprocess<false, true>", "sgs::k_preprocess<true, true>"], "count": ["sgs::k_bin_count", "sgs::k_stile_scan", "sgs::k_bin_emit"],
              "emit": ["sgs::k_expand<false>", "sgs::k_tile_scan", "sgs::k_expand<true>"],
              # the instantiation a sweep runs (no aux output, no D_f bookkeeping), however the profiler spells it
              "render": ["sgs::k_tile_render<false, false, false>"]}
