@@ -153,6 +153,5 @@ def make_camera(width, height, fx, fy, cx, cy, view):
     flat = [float(v) for row in view for v in (row if hasattr(row, "__len__") else [row])]
     if len(flat) != 16:
         raise ValueError("view must be 4x4")
-    for i in range(16):
-        cam.view[i] = flat[i]
+    cam.view[:] = flat                   # (one slice assignment: a loop over the sixteen ctypes elements was 6 us of a 0.3-ms call)
     return cam
