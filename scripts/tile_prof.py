@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, "sage-3d_official_amd"))
 os.environ["SAGE_GS_LIB"] = os.path.join(ROOT, "build", "lib", "libsage_gs_prof.so")
 import numpy as np, torch
 from sage_gs import Renderer, scenes
-sc = scenes.cached_room(int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, seed=2)
+sc = scenes.make_trained_like(3_000_000, seed=2) if os.environ.get("SCENE") == "trained" else scenes.cached_room(int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000, seed=2)
 W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 cams = scenes.room_cameras(sc, W, H, 4, 64, seed=2)
 r = Renderer("cuda:0", record_capacity=96 << 20)
