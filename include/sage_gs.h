@@ -26,9 +26,10 @@
 extern "C" {
 #endif
 
-#define SGS_VERSION 113            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
+#define SGS_VERSION 114            /* major*100 + minor.  The version changes whenever a struct below changes size or meaning
                                     * (100 -> 101: sgs_stats grew d_super; 110: round-4 entry points; 111: sgs_stats grew n_deep_windows, sgs_compressed_scene.reserved_ became sh_decode; 112: SGS_FLAG_NO_DEEP; sgs_set_tuning,
-                                    * SGS_BUF_SCENE_SH; 113: fine tiles — sgs_tuning grew fine_tile_pixels, SGS_FLAG_NO_FINE_TILES): a caller compiled against
+                                    * SGS_BUF_SCENE_SH; 113: fine tiles — sgs_tuning grew fine_tile_pixels, SGS_FLAG_NO_FINE_TILES;
+                                    * 114: sgs_tuning grew fine_tile_growth): a caller compiled against
                                     * another header MUST refuse to run — check sgs_version() == SGS_VERSION and, for bindings
                                     * that restate the structs by hand (ctypes, cgo), sgs_struct_sizes() — before the first call
                                     * that takes a struct.  The library writes whole structs (sgs_stats arrays with ITS stride). */
@@ -66,7 +67,8 @@ enum {
     SGS_FLAG_NO_FINE_TILES = 1u << 9, /* tests, A/B: render this frame through 16x16-pixel tiles whatever its size.  By default a frame of at
                                     * most sgs_tuning.fine_tile_pixels pixels (640x480: the reference's own resolutions, simple_env.py:52,
                                     * run_benchmark.py:1409-1419) is rendered through 8x8-pixel tiles — four times the workgroups, a quarter of the
-                                    * queue and of the per-wave splat lists in each: such a frame's time is its slowest tile's.  WHICH splats reach
+                                    * queue and of the per-wave splat lists in each: such a frame's time is its slowest tile's — unless its splats are
+                                    * so large that the split would more than double the records (sgs_tuning.fine_tile_growth).  WHICH splats reach
                                     * a pixel does not change (S3's rect stays a rect of 16x16-pixel tiles); the tile origin the blend's
                                     * coordinates are relative to does, so the two renderings of a frame agree to fp32 rounding (both within the
                                     * parity tolerance of the oracle), not bit for bit.  SGS_FLAG_FULL_SORT / SGS_FLAG_LOOSE_CULL imply this flag:
@@ -164,8 +166,8 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
  * sgs_create; four of them — the grids of the binning and projection launches — were settled by A/B runs and are constants now).
  * sgs_tuning_default() fills what the bench runs; sgs_set_tuning() takes effect for the scenes uploaded and the frames issued AFTER it
  * (it completes the frames in flight first).  Frames do not depend on any of these, bit for bit (tests/test_gpu_parity.py).  No
- * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112 (113: fine_tile_pixels — the one
- * field frames DO depend on, to fp32 rounding). */
+ * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112 (113: fine_tile_pixels, 114: fine_tile_growth — the two
+ * fields frames DO depend on, to fp32 rounding). */
 typedef struct sgs_tuning {
     int32_t lanes;            /* 3  frames in flight for SGS_FLAG_PIPELINED single frames: each lane has its own stream and intermediates (1..8) */
     int32_t group;            /* 4  frames per set of launches in sgs_render_batch* (blockIdx.y selects the frame; 1..8) */
@@ -173,8 +175,13 @@ typedef struct sgs_tuning {
     int32_t morton;           /* 1  lay the scene out in Z-order at upload (device radix sort); 0 keeps the caller's order */
     int64_t record_capacity;  /* 16 Mi  (Gaussian, tile) records the queues of a lane hold; an overflowing frame grows them and is rendered again
                                *        (= sgs_set_record_capacity) */
-    int64_t fine_tile_pixels; /* 307200 (640x480)  frames of at most this many pixels are rendered through 8x8-pixel tiles (SGS_FLAG_NO_FINE_TILES
-                               *        above); 0 = never.  Version 113 */
+    int64_t fine_tile_pixels; /* 307200 (640x480)  frames of at most this many pixels MAY be rendered through 8x8-pixel tiles, of at most a quarter
+                               *        of it through 4x4 (SGS_FLAG_NO_FINE_TILES above); 0 = never.  Version 113 */
+    double fine_tile_growth;  /* 2.2  ... and ARE, as long as halving the tiles multiplies the frame's (Gaussian, tile) records by no more than this
+                               *        (what a split costs; estimated per frame on the host from 512 Gaussians of the scene, ~6 us).
+                               *        Indoor scenes of small splats grow by 1.5-2.0 and gain 20-50 % of a frame; scenes with trained-3DGS
+                               *        statistics grow by 2.5-3.5 and would lose 30 %.  >= 16 = whenever the pixel rule allows
+                               *        (tests); must be >= 1.  Version 114 */
 } sgs_tuning;
 void sgs_tuning_default(sgs_tuning* out);
 int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* tuning);

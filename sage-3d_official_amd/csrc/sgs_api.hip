@@ -33,7 +33,15 @@ struct Scratch {
 
 }  // namespace
 
+// One Gaussian of a scene's PROBE (fine_shift_of): mean, 3-D covariance (+ its trace), ln(opacity), sampling weight — 512 of them, drawn at
+// upload (layout_scene) and kept on the host.  Half of the draws are uniform over the scene, half proportional to the Gaussian's squared size
+// (trace of its covariance): the record count of a scene with trained-3DGS statistics is carried by a few per cent of large splats, which a
+// uniform sample of 512 holds a handful of — the estimate of the growth under a split was off by 20 % on such scenes and decided wrongly for
+// one pose in six (r06w); with the mixture (each draw weighted by the inverse of its probability) the estimate follows the frame's real ratio.
+struct ProbeSample { float m[3]; float S[6]; float ln_o; float trace; float wgt; };
+
 struct sgs_scene {
+    std::vector<ProbeSample> probe;     // (empty: fewer Gaussians than a probe is worth)
     int64_t n = 0, n_chunks = 0;
     int sh_degree = 0, sh_rows = 0;     // sh_rows: 16-byte rows of SH per Gaussian (12 at degree 3; 4 when sh_packed)
     bool sh_packed = false;             // uploaded from the compressed payload: the 8-bit coefficients stay bytes in HBM (k_scene_layout<true>)
@@ -96,8 +104,9 @@ struct sgs_ctx {
     int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (settled by A/B: r03, r04)
     int bin_grid = SGS_BIN_BLOCKS;           // binning workgroups per launch (<= SGS_BIN_BLOCKS)
     int pre_grid = 8192;                     // k_preprocess workgroups per launch of a frame GROUP: its waves loop over the live list (r03y)
-    int64_t fine_tile_pixels = 640 * 480;    // sgs_tuning.fine_tile_pixels: frames of at most this many pixels are rendered through 8x8-pixel
+    int64_t fine_tile_pixels = 640 * 480;    // sgs_tuning.fine_tile_pixels: frames of at most this many pixels may be rendered through 8x8-pixel
                                              // tiles (fine_shift_of; sgs_common.h "Fine tiles"); 0 = never
+    double fine_tile_growth = 2.2;           // sgs_tuning.fine_tile_growth: ... while a split multiplies the frame's records by no more than this
     bool morton = true;                      // Z-order the scene at upload (sgs_tuning.morton = 0 keeps the caller's order): a chunk of 64
                                              // Gaussians is then a compact patch, which is what makes the per-chunk bounds
                                              // (k_chunk_bounds / chunk_outside) worth testing — trained scenes come in no spatial order
@@ -235,19 +244,80 @@ int drain_lanes(sgs_ctx* ctx) {
     return SGS_OK;
 }
 
-// Fine tiles (sgs_common.h): the shift z of a call — its frame is rendered through tiles of (16 >> z)^2 pixels.  Small frames only (a large one
-// fills the chip with 16x16 tiles, and a wave of 64 pixels evaluates a splat once where four waves of 16 evaluate it up to four times); never
-// under the test hooks whose point is the REFERENCE's integer structures — queues and offsets of 16x16-pixel tiles.
-int fine_shift_of(const sgs_ctx* ctx, const sgs_camera* cam, uint32_t flags) {
-    if (flags & (SGS_FLAG_NO_FINE_TILES | SGS_FLAG_FULL_SORT | SGS_FLAG_LOOSE_CULL)) return 0;
-    // halved while the frame has at most fine_tile_pixels / 4^z pixels, twice at most: 640x480 -> 8x8-pixel tiles, 320x240 -> 4x4 under the default
+// Fine tiles (sgs_common.h): the shift z of a call — its frame is rendered through tiles of (16 >> z)^2 pixels.  A function of the scene, the
+// camera and the configuration ALONE, so that a frame is the same frame however it is issued (alone, pipelined, in a batch, as a band).
+//   * Never under the test hooks whose point is the REFERENCE's integer structures — queues and offsets of 16x16-pixel tiles.
+//   * Small frames only: z <= the number of times the frame's pixel count, quadrupled, stays within sgs_tuning.fine_tile_pixels (640x480
+//     -> 1, 320x240 -> 2) — a large frame fills the chip with 16x16 tiles.
+//   * And only while halving the tiles does not multiply the RECORDS by more than sgs_tuning.fine_tile_growth (2.2).  Every record is binned, partitioned, ranked and
+//     quadrant-tested once per tile it lands in, so what a split costs is the growth of D — small where splats are smaller than the tiles
+//     (x1.5-2.0 on the indoor scenes: the split wins 20-50 % of a frame), towards x4 where they are larger (x2.5-3.5 on scenes with
+//     trained-3DGS statistics, whose pixels saturate inside the first batch anyway: there the split LOSES 30 %).  Measured per pose, both
+//     scene kinds, three resolutions (profiles/r06w_fine_tiles_growth_rule.txt): the frame's time is shorter with the split below a growth of
+//     2.1-2.4 and longer above; the rule lands within 1 % of choosing the better tiling per pose.  D at each tile size is ESTIMATED here, on
+//     the host, from the scene's probe — a thousand Gaussians projected with S2's arithmetic (fp32) and binned over the extent of
+//     {alpha >= alpha_min} as k_preprocess bins it: ~10 us per frame, within a few per cent of the frame's real D ratio.
+// floor / ceil of a value well inside the int range, without the libm call a portable build makes of std::floor
+inline int ifloor(float v) { const int i = (int)v; return i - (v < (float)i ? 1 : 0); }
+inline int iceil(float v) { const int i = (int)v; return i + (v > (float)i ? 1 : 0); }
+int fine_shift_of(const sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config& cfg) {
+    if (cfg.flags & (SGS_FLAG_NO_FINE_TILES | SGS_FLAG_FULL_SORT | SGS_FLAG_LOOSE_CULL)) return 0;
+    int zcap = 0;
+    while (zcap < 2 && (((int64_t)cam->width * cam->height) << (2 * zcap)) <= ctx->fine_tile_pixels) ++zcap;
+    if (zcap == 0 || !scene || scene->probe.empty() || ctx->fine_tile_growth >= 16.0) return zcap;
+    const float* V = cam->view;
+    const float fx = cam->fx, fy = cam->fy, W = (float)cam->width, H = (float)cam->height;
+    const float limx = cfg.clamp * (0.5f * W / fx), limy = cfg.clamp * (0.5f * H / fy);
+    const float ln_amin = std::log(cfg.alpha_min);
+    const float jb = std::max(fx, fy), jk = 2.0f + limx * limx + limy * limy;
+    double D[3] = {0.0, 0.0, 0.0};
+    for (const ProbeSample& g : scene->probe) {
+        const float tz = V[8] * g.m[0] + V[9] * g.m[1] + V[10] * g.m[2] + V[11];
+        if (!(tz > cfg.near_z) || !(tz <= cfg.far_z)) continue;
+        const float K = 2.0f * (g.ln_o - ln_amin);                    // alpha >= alpha_min  <=>  d^T Sigma'^-1 d <= K
+        if (!(K > 0.0f)) continue;                                    // (never blended: nothing is binned)
+        const float tx = V[0] * g.m[0] + V[1] * g.m[1] + V[2] * g.m[2] + V[3], ty = V[4] * g.m[0] + V[5] * g.m[1] + V[6] * g.m[2] + V[7];
+        const float itz = 1.0f / tz, xz = tx * itz, yz = ty * itz;
+        const float px = fx * xz + cam->cx - 0.5f, py = fy * yz + cam->cy - 0.5f;
+        {   // off screen by more than any footprint it can have (k_preprocess's own pre-check: lambda_max <= |J|_F^2 trace(Sigma) + dilation,
+            // radius <= 3 sqrt(2 lambda_max + 0.3163) + 1, squared and rounded up): most of a probe ends here
+            const float jf = jb * itz, lmax = jf * jf * jk * g.trace + cfg.dilation;
+            const float rb2 = 9.5f * (2.0f * lmax + 0.3163f) + 4.0f;
+            const float ox = px < 0.0f ? -px : px > W ? px - W : 0.0f, oy = py < 0.0f ? -py : py > H ? py - H : 0.0f;
+            if (ox * ox > rb2 || oy * oy > rb2) continue;
+        }
+        const float txc = std::min(limx, std::max(-limx, xz)) * tz, tyc = std::min(limy, std::max(-limy, yz)) * tz;
+        const float j00 = fx * itz, j02 = -fx * txc * itz * itz, j11 = fy * itz, j12 = -fy * tyc * itz * itz;
+        const float T0[3] = {j00 * V[0] + j02 * V[8], j00 * V[1] + j02 * V[9], j00 * V[2] + j02 * V[10]};
+        const float T1[3] = {j11 * V[4] + j12 * V[8], j11 * V[5] + j12 * V[9], j11 * V[6] + j12 * V[10]};
+        const float* S = g.S;                                         // (00, 01, 02, 11, 12, 22)
+        const float u0 = S[0] * T0[0] + S[1] * T0[1] + S[2] * T0[2], u1 = S[1] * T0[0] + S[3] * T0[1] + S[4] * T0[2], u2 = S[2] * T0[0] + S[4] * T0[1] + S[5] * T0[2];
+        const float w0 = S[0] * T1[0] + S[1] * T1[1] + S[2] * T1[2], w1 = S[1] * T1[0] + S[3] * T1[1] + S[4] * T1[2], w2 = S[2] * T1[0] + S[4] * T1[1] + S[5] * T1[2];
+        const float a = T0[0] * u0 + T0[1] * u1 + T0[2] * u2 + cfg.dilation, b = T1[0] * u0 + T1[1] * u1 + T1[2] * u2,
+                    c = T1[0] * w0 + T1[1] * w1 + T1[2] * w2 + cfg.dilation;
+        const float det = a * c - b * b;
+        if (!(det > 0.0f)) continue;
+        const float mid = 0.5f * (a + c), r3 = 3.0f * __builtin_sqrtf(mid + __builtin_sqrtf(std::max(0.1f, mid * mid - det)));     // S3
+        if (!(r3 < 1.0e6f) || !(std::fabs(px) < 1.0e6f) || !(std::fabs(py) < 1.0e6f)) continue;       // (NaN / wild values: not a probe worth counting)
+        const float radius = (float)iceil(r3);
+        const float hx = std::min(__builtin_sqrtf(K * a), radius), hy = std::min(__builtin_sqrtf(K * c), radius);
+        if (!(hx >= 0.0f) || !(hy >= 0.0f)) continue;
+        const float xa = px - hx, xb = px + hx, ya = py - hy, yb = py + hy;
+        float icp = 1.0f / SGS_TILE;
+        for (int z = 0; z <= zcap; ++z, icp *= 2.0f) {                // cells of cp = 16 >> z pixels: a cell holds the pixel centres cp t .. cp t + cp - 1
+            const int cp = SGS_TILE >> z, gxz = (cam->width + cp - 1) / cp, gyz = (cam->height + cp - 1) / cp;
+            const int nx = std::min(gxz, ifloor(xb * icp) + 1) - std::max(0, iceil((xa - (float)(cp - 1)) * icp));
+            const int ny = std::min(gyz, ifloor(yb * icp) + 1) - std::max(0, iceil((ya - (float)(cp - 1)) * icp));
+            if (nx > 0 && ny > 0) D[z] += (double)g.wgt * (double)(nx * ny);
+        }
+    }
     int z = 0;
-    while (z < 2 && (((int64_t)cam->width * cam->height) << (2 * z)) <= ctx->fine_tile_pixels) ++z;
+    while (z < zcap && D[z + 1] <= ctx->fine_tile_growth * D[z]) ++z;     // (nothing of the probe in view: 0 <= 0, the pixel rule alone)
     return z;
 }
 
 int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
-             int& row_begin, int& row_end, const float* out_rgb) {
+             int& row_begin, int& row_end, const float* out_rgb, int* fine_shift = nullptr) {
     if (!scene || !cam || !out_rgb) SGS_FAIL(ctx, SGS_ERR_INVALID, "null scene / camera / output");
     if (cam->width <= 0 || cam->height <= 0 || cam->width > 65535 * SGS_TILE || cam->height > 65535 * SGS_TILE)
         SGS_FAIL(ctx, SGS_ERR_INVALID, "bad resolution %dx%d", cam->width, cam->height);
@@ -285,7 +355,10 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
     if (gy_frame > SGS_MAX_ROWS) SGS_FAIL(ctx, SGS_ERR_INVALID, "height %d exceeds %d tile rows", cam->height, SGS_MAX_ROWS);
     // level 1 of the binning keeps one counter per super-tile of the band in LDS (the band's rows and tiles as the kernels count them:
     // cells of (16 >> z)^2 pixels, sgs_common.h "Fine tiles")
-    const int z = fine_shift_of(ctx, cam, cfg ? cfg->flags : 0u), cp = SGS_TILE >> z;
+    sgs_config cfg_d;
+    if (!cfg) sgs_config_default(&cfg_d);
+    const int z = fine_shift_of(ctx, scene, cam, cfg ? *cfg : cfg_d), cp = SGS_TILE >> z;
+    if (fine_shift) *fine_shift = z;
     const int gx = (cam->width + cp - 1) / cp, rb = row_begin << z, re = row_end << z;
     const int64_t ns = (int64_t)((gx + SGS_ST - 1) / SGS_ST) * (((re + SGS_ST - 1) / SGS_ST) - rb / SGS_ST);
     if (ns > SGS_WT) SGS_FAIL(ctx, SGS_ERR_INVALID, "band of %d tile rows x %d tiles exceeds %d super-tiles", re - rb, gx, SGS_WT);
@@ -293,7 +366,7 @@ int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const 
 }
 
 void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_scene* scene, const sgs_camera* cam,
-                 const sgs_config& cfg, int row_begin, int row_end) {
+                 const sgs_config& cfg, int row_begin, int row_end, int z) {
     memset(&P, 0, sizeof P);
     for (int i = 0; i < 12; ++i) P.view[i] = cam->view[i];
     const float* V = cam->view;
@@ -306,7 +379,7 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
     P.width = cam->width; P.height = cam->height;
     // Fine tiles (sgs_common.h): the grid, the band and every tile index the kernels see count CELLS of (16 >> z)^2 pixels; row_begin / row_end
     // arrive in 16-pixel rows (the C ABI's unit), each of which is 2^z rows of cells — but for the frame's last one when the height leaves it short
-    const int z = fine_shift_of(ctx, cam, cfg.flags), cp = SGS_TILE >> z;
+    const int cp = SGS_TILE >> z;                 // (z: fine_shift_of, decided once per call by validate)
     const int gx16 = (cam->width + SGS_TILE - 1) / SGS_TILE, gy16 = (cam->height + SGS_TILE - 1) / SGS_TILE;
     P.gx = (cam->width + cp - 1) / cp; P.gy = (cam->height + cp - 1) / cp;
     P.row_stride = cfg.tile_row_stride > 1 ? cfg.tile_row_stride : 1;
@@ -413,9 +486,9 @@ void launch_composite(const FrameGroup& G, int nf, hipStream_t stream, bool aux,
 // The FrameGroup of nf frames of one scene: frame f uses the intermediates of lane set0 + f (grown here if need be) and status slot
 // slot0 + f.
 int build_group(sgs_ctx* ctx, FrameGroup& G, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
-                int row_begin, int row_end, float* const* outs, int slot0, float* out_aux, int set0) {
+                int row_begin, int row_end, float* const* outs, int slot0, float* out_aux, int set0, int z) {
     int rc;
-    const int cp = SGS_TILE >> fine_shift_of(ctx, cams, cfg.flags);      // (the frames of a group share a resolution and a configuration)
+    const int cp = SGS_TILE >> z;                 // (the frames of a group share a resolution, a configuration and the fine-tile shift)
     const int gx = (cams->width + cp - 1) / cp, gy = (cams->height + cp - 1) / cp;
     memset(&G, 0, sizeof G);
     G.geom = scene->geom; G.shq = scene->shq; G.cbound = scene->cbound; G.row_acc = ctx->row_acc;
@@ -425,7 +498,7 @@ int build_group(sgs_ctx* ctx, FrameGroup& G, const sgs_scene* scene, const sgs_c
         if ((rc = ensure_tiles(ctx, A, gx * gy)) != SGS_OK) return rc;
         if ((rc = ensure_records(ctx, A)) != SGS_OK) return rc;
         FrameSlot& S = G.s[f];
-        fill_params(S.P, ctx, A, scene, &cams[f], cfg, row_begin, row_end);
+        fill_params(S.P, ctx, A, scene, &cams[f], cfg, row_begin, row_end, z);
         if ((S.P.flags & SGS_FLAG_FULL_SORT) && (rc = ensure_sorted_out(ctx, A)) != SGS_OK) return rc;
         S.splats = A.splats; S.vismask = A.vismask; S.bigmask = A.bigmask; S.big_list = A.big_list; S.binrec = A.binrec;
         S.live_list = A.live_list;
@@ -468,7 +541,7 @@ void note_last(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
 //     launches were ~40 us, as long as a light band of tile rows takes on the GPU).
 int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
                   int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
-                  float* out_aux, bool pipelined, bool in_batch, int set0, int stream_lane = -1) {
+                  float* out_aux, bool pipelined, bool in_batch, int set0, int z, int stream_lane = -1) {
     int rc;
     // The stream: a pipelined frame's own lane's; a batch's groups rotate over the streams of lanes 0 .. group_lanes-1 — the
     // SAME streams single pipelined frames use.  (r03y: the groups used to run on the streams of lanes 0 and 4; a process that
@@ -481,7 +554,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
         stream = L.stream;
     }
     FrameGroup G;
-    if ((rc = build_group(ctx, G, scene, cams, nf, cfg, row_begin, row_end, outs, slot0, out_aux, set0)) != SGS_OK) return rc;
+    if ((rc = build_group(ctx, G, scene, cams, nf, cfg, row_begin, row_end, outs, slot0, out_aux, set0, z)) != SGS_OK) return rc;
     const FrameParams& P = G.s[0].P;
     if (pipelined && !in_batch) {
         // start after whatever the caller already put on its stream (scene upload, consumers of the output buffer)
@@ -650,13 +723,13 @@ int sgs_destroy(sgs_ctx* ctx) {
 void sgs_tuning_default(sgs_tuning* out) {
     if (!out) return;
     out->lanes = 3; out->group = 4; out->group_lanes = 2; out->morton = 1; out->record_capacity = 16ll << 20;
-    out->fine_tile_pixels = 640 * 480;
+    out->fine_tile_pixels = 640 * 480; out->fine_tile_growth = 2.2;
 }
 
 int sgs_get_tuning(const sgs_ctx* ctx, sgs_tuning* out) {
     if (!ctx || !out) return SGS_ERR_INVALID;
     out->lanes = ctx->n_lanes; out->group = ctx->group; out->group_lanes = ctx->group_lanes; out->morton = ctx->morton ? 1 : 0;
-    out->record_capacity = ctx->rec_cap_wanted; out->fine_tile_pixels = ctx->fine_tile_pixels;
+    out->record_capacity = ctx->rec_cap_wanted; out->fine_tile_pixels = ctx->fine_tile_pixels; out->fine_tile_growth = ctx->fine_tile_growth;
     return SGS_OK;
 }
 
@@ -669,10 +742,11 @@ int sgs_set_tuning(sgs_ctx* ctx, const sgs_tuning* t) {
         SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.group x group_lanes = %d x %d exceeds the %d lanes of a context", t->group, t->group_lanes, kMaxLanes);
     if (t->record_capacity <= 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.record_capacity must be positive");
     if (t->fine_tile_pixels < 0) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.fine_tile_pixels must not be negative (0 = never)");
+    if (!(t->fine_tile_growth >= 1.0)) SGS_FAIL(ctx, SGS_ERR_INVALID, "sgs_tuning.fine_tile_growth must be at least 1 (>= 16: whenever the pixel rule allows)");
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();                          // frames in flight were issued under the old values (their verdicts stay for sgs_frame_sync)
     ctx->n_lanes = t->lanes; ctx->next_lane = 0; ctx->group = t->group; ctx->group_lanes = t->group_lanes; ctx->morton = t->morton != 0;
-    ctx->fine_tile_pixels = t->fine_tile_pixels;
+    ctx->fine_tile_pixels = t->fine_tile_pixels; ctx->fine_tile_growth = t->fine_tile_growth;
     if (t->record_capacity != ctx->rec_cap_wanted) return sgs_set_record_capacity(ctx, t->record_capacity);
     return SGS_OK;
 }
@@ -759,6 +833,58 @@ int layout_scene(sgs_ctx* ctx, sgs_scene* sc, const float* const* src, const sgs
         hipLaunchKernelGGL(sgs::k_chunk_bounds, dim3((unsigned)((sc->n_chunks + 3) / 4)), dim3(256), 0, 0, (long long)n,
                            (long long)sc->n_chunks, sc->geom, sc->cbound);
         if ((e = hipDeviceSynchronize()) != hipSuccess) fail("k_scene_layout / k_chunk_bounds", e);
+    }
+    if (rc == SGS_OK && n > 0) {
+        // the probe (fine_shift_of): a pre-sample of up to 64 Ki Gaussians at even strides through the layout comes to the host; 512 of them
+        // are drawn from it — systematically, with probability 1/2 (1 / M0 + trace_i / sum of traces) each — and their covariances formed once
+        const int M0 = (int)std::min<int64_t>(n, 65536), M = std::min(M0, 512);
+        float4* d_probe = nullptr;
+        std::vector<float4> rows((size_t)M0 * SGS_GEOM_ROWS);
+        if ((e = hipMalloc(reinterpret_cast<void**>(&d_probe), rows.size() * sizeof(float4))) != hipSuccess) fail("hipMalloc", e);
+        else {
+            hipLaunchKernelGGL(sgs::k_probe_gather, dim3((unsigned)((M0 + 255) / 256)), dim3(256), 0, 0, (long long)n, M0, sc->geom, d_probe);
+            if ((e = hipMemcpy(rows.data(), d_probe, rows.size() * sizeof(float4), hipMemcpyDeviceToHost)) != hipSuccess) fail("reading the probe", e);
+            (void)hipFree(d_probe);
+        }
+        if (rc == SGS_OK) {
+            std::vector<double> tr((size_t)M0);
+            double T = 0.0;
+            for (int i = 0; i < M0; ++i) {
+                const float4 g1 = rows[(size_t)3 * i + 1];
+                const double t = (double)g1.x * g1.x + (double)g1.y * g1.y + (double)g1.z * g1.z;       // trace(R S S^T R^T) = |s|^2
+                tr[(size_t)i] = t < 1.0e30 ? t : 0.0;                                                 // (NaN / inf scales: never drawn by size)
+                T += tr[(size_t)i];
+            }
+            sc->probe.clear(); sc->probe.reserve((size_t)M);
+            double cum = 0.0; int i = 0;
+            for (int k = 0; k < M; ++k) {
+                double pi_i = 1.0 / M0;
+                if (M0 > M) {              // (a scene smaller than a probe: every Gaussian once, weight 1)
+                    const double target = ((double)k + 0.5) / M;
+                    for (;;) {
+                        pi_i = 0.5 * (1.0 / M0 + (T > 0.0 ? tr[(size_t)i] / T : 1.0 / M0));
+                        if (cum + pi_i >= target || i == M0 - 1) break;
+                        cum += pi_i; ++i;
+                    }
+                } else i = k;
+                const float4 g0 = rows[(size_t)3 * i], g1 = rows[(size_t)3 * i + 1], g2 = rows[(size_t)3 * i + 2];
+                ProbeSample q;
+                q.m[0] = g0.x; q.m[1] = g0.y; q.m[2] = g0.z; q.ln_o = std::log(g0.w);
+                q.wgt = (float)(1.0 / (pi_i * M0));                       // (relative to a uniform draw)
+                const double qn = std::sqrt((double)g1.w * g1.w + (double)g2.x * g2.x + (double)g2.y * g2.y + (double)g2.z * g2.z);
+                const double w = g1.w / qn, x = g2.x / qn, y = g2.y / qn, z = g2.z / qn;
+                const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                                        {2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)},
+                                        {2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)}};
+                const double s2[3] = {(double)g1.x * g1.x, (double)g1.y * g1.y, (double)g1.z * g1.z};
+                int t = 0;
+                for (int a_ = 0; a_ < 3; ++a_)
+                    for (int b_ = a_; b_ < 3; ++b_)
+                        q.S[t++] = (float)(R[a_][0] * R[b_][0] * s2[0] + R[a_][1] * R[b_][1] * s2[1] + R[a_][2] * R[b_][2] * s2[2]);     // (00, 01, 02, 11, 12, 22)
+                q.trace = q.S[0] + q.S[3] + q.S[5];
+                sc->probe.push_back(q);
+            }
+        }
     }
     for (int k = 0; k < 2; ++k) { if (keys[k]) (void)hipFree(keys[k]); if (idx[k]) (void)hipFree(idx[k]); }
     if (hist) (void)hipFree(hist);
@@ -921,7 +1047,8 @@ int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
                     void* hip_stream) {
     if (!ctx) return SGS_ERR_INVALID;
     int rc;
-    if ((rc = validate(ctx, scene, cam, cfg_in, tile_row_begin, tile_row_end, out_rgb)) != SGS_OK) return rc;
+    int z = 0;                                       // the frame's fine-tile shift (fine_shift_of)
+    if ((rc = validate(ctx, scene, cam, cfg_in, tile_row_begin, tile_row_end, out_rgb, &z)) != SGS_OK) return rc;
     sgs_config cfg;
     if (cfg_in) cfg = *cfg_in; else sgs_config_default(&cfg);
     SGS_HIP(ctx, hipSetDevice(ctx->device));
@@ -942,7 +1069,7 @@ int sgs_render_rgbd(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam,
         if (pipelined) { lane = ctx->next_lane; ctx->next_lane = (ctx->next_lane + 1) % ctx->n_lanes; }
         float* outs[1] = {out_rgb};
         if ((rc = enqueue_group(ctx, scene, cam, 1, cfg, tile_row_begin, tile_row_end, outs, slot, stream, timed, out_aux,
-                                pipelined, false, lane)) != SGS_OK)
+                                pipelined, false, lane, z)) != SGS_OK)
             return rc;
         if (cfg.flags & SGS_FLAG_ASYNC) return SGS_OK;
         rc = sgs_frame_sync(ctx, stats);
@@ -980,9 +1107,11 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
     // every camera (and the stride) is validated BEFORE anything is enqueued: an error return half-way through a batch
     // would leave earlier groups running on the lane streams with nobody waiting for them
     int rb0 = tile_row_begin, re0 = tile_row_end;
+    std::vector<signed char> zs((size_t)std::max(n_cams, 1), 0);     // every frame's fine-tile shift (fine_shift_of: a function of its camera)
     for (int i = 0; i < n_cams; ++i) {
-        int rb = tile_row_begin, re = tile_row_end;
-        if ((rc = validate(ctx, scene, &cams[i], &cfg, rb, re, out_rgb)) != SGS_OK) return rc;
+        int rb = tile_row_begin, re = tile_row_end, z = 0;
+        if ((rc = validate(ctx, scene, &cams[i], &cfg, rb, re, out_rgb, &z)) != SGS_OK) return rc;
+        zs[(size_t)i] = (signed char)z;
         if (cams[i].width != cams[0].width || cams[i].height != cams[0].height)
             SGS_FAIL(ctx, SGS_ERR_INVALID, "the cameras of a batch must share a resolution");
         if (i == 0) { rb0 = rb; re0 = re; }
@@ -1019,14 +1148,16 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
         for (int sidx = 0; sidx < n_streams; ++sidx) left[sidx] = cn / n_streams + (sidx < cn % n_streams ? 1 : 0);
         for (int i = 0, g = 0; i < cn; ++g) {
             const int sidx = g % n_streams;
-            const int nf = std::min(F, left[sidx]);
+            int nf = std::min(F, left[sidx]);
             if (nf <= 0) continue;
+            // (the frames of a group share one set of launches, hence one grid of tiles: a group ends where the fine-tile shift changes)
+            for (int f = 1; f < nf; ++f) if (zs[(size_t)(c0 + i + f)] != zs[(size_t)(c0 + i)]) { nf = f; break; }
             left[sidx] -= nf;
             float* outs[SGS_MAX_GROUP];
             const int rb = rb0, re = re0;
             for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
-                                    sidx * F, sidx)) != SGS_OK)
+                                    sidx * F, zs[(size_t)(c0 + i)], sidx)) != SGS_OK)
                 return rc;
             for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
             i += nf;

@@ -401,6 +401,17 @@ __global__ __launch_bounds__(256) void k_chunk_bounds(long long n, long long n_c
     }
 }
 
+// The scene's PROBE (sgs_api.hip fine_shift_of): the geometry rows of M Gaussians at even strides through the layout, for the host.
+__global__ __launch_bounds__(256) void k_probe_gather(long long n, int M, const float4* __restrict__ geom, float4* __restrict__ out) {
+    const int k = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (k >= M) return;
+    long long p = (long long)(((double)k + 0.5) * (double)n / (double)M);
+    p = p < n ? p : n - 1;
+    const long long chunk = p >> 6, lane = p & 63;
+#pragma unroll
+    for (int r = 0; r < SGS_GEOM_ROWS; ++r) out[(size_t)k * SGS_GEOM_ROWS + r] = geom[(chunk * SGS_GEOM_ROWS + r) * SGS_WAVE + lane];
+}
+
 // Can ANY Gaussian of a chunk (means inside the sphere (c, R), scales <= s_max) be visible in this frame / band?
 // Wave-uniform, fp64, conservative with respect to the per-Gaussian exclusion in preprocess_chunk: that one keeps a
 // Gaussian only if  tz > near,  px + rb + ex >= 1,  px - rb - ex < 16 gx,  py + rb + ey >= cull_y0 + 1,  py - rb - ey < cull_y1

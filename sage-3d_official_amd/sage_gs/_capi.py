@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 SH_DECODE = {"bin_centre": 3, "linear255": 1, "bin_centre_ends": 2}      # include/sage_gs.h SGS_SH_DECODE_* (0 = unspecified: refused at degree > 0)
-ABI_VERSION = 113        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
+ABI_VERSION = 114        # include/sage_gs.h SGS_VERSION this binding restates; Lib() refuses any other library
 NUM_STAGES = 4
 STAGE_NAMES = ("preprocess", "count", "emit", "render")
 
@@ -59,7 +59,7 @@ class SgsCompressedScene(C.Structure):
 class SgsTuning(C.Structure):
     """include/sage_gs.h sgs_tuning: the library's whole tuning surface (it reads nothing from the environment)."""
     _fields_ = [("lanes", C.c_int32), ("group", C.c_int32), ("group_lanes", C.c_int32), ("morton", C.c_int32),
-                ("record_capacity", C.c_int64), ("fine_tile_pixels", C.c_int64)]
+                ("record_capacity", C.c_int64), ("fine_tile_pixels", C.c_int64), ("fine_tile_growth", C.c_double)]
 
 
 class SgsStats(C.Structure):

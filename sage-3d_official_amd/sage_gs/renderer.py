@@ -156,11 +156,12 @@ class Renderer:
 
     def __init__(self, device=None, record_capacity: Optional[int] = None, lib: Optional[_capi.Lib] = None, *,
                  lanes: Optional[int] = None, group: Optional[int] = None, group_lanes: Optional[int] = None,
-                 morton: Optional[bool] = None, fine_tile_pixels: Optional[int] = None):
+                 morton: Optional[bool] = None, fine_tile_pixels: Optional[int] = None, fine_tile_growth: Optional[float] = None):
         """lanes / group / group_lanes / morton / record_capacity / fine_tile_pixels: include/sage_gs.h `sgs_tuning` (None = the library's
         default, what the bench runs).  The library reads nothing from the environment; frames do not depend on any of these, bit for bit —
-        except fine_tile_pixels (frames of at most that many pixels are rendered through 8x8-pixel tiles, of a quarter of it through 4x4:
-        the same splats reach every pixel, the blend's coordinates are relative to another tile origin, so frames agree to fp32 rounding)."""
+        except fine_tile_pixels / fine_tile_growth (frames of at most that many pixels are rendered through 8x8-pixel tiles, of a quarter of it
+        through 4x4, as long as a split multiplies the frame's records by no more than fine_tile_growth: the same splats reach every pixel,
+        the blend's coordinates are relative to another tile origin, so frames agree to fp32 rounding)."""
         self._lib = lib or _capi.Lib()
         if not torch.cuda.is_available():
             raise RuntimeError("sage_gs.Renderer needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -173,15 +174,15 @@ class Renderer:
         ctx = C.c_void_p()
         self._lib.check(self._lib.sgs_create(index, _capi.BACKEND_HIP, C.byref(ctx)))
         self._ctx = ctx
-        if any(v is not None for v in (record_capacity, lanes, group, group_lanes, morton, fine_tile_pixels)):
+        if any(v is not None for v in (record_capacity, lanes, group, group_lanes, morton, fine_tile_pixels, fine_tile_growth)):
             self.set_tuning(lanes=lanes, group=group, group_lanes=group_lanes, morton=morton, record_capacity=record_capacity,
-                            fine_tile_pixels=fine_tile_pixels)
+                            fine_tile_pixels=fine_tile_pixels, fine_tile_growth=fine_tile_growth)
         self.last_stats = None
 
     def tuning(self) -> dict:
         t = _capi.SgsTuning()
         self._lib.check(self._lib.sgs_get_tuning(self._ctx, C.byref(t)), self._ctx)
-        return {k: int(getattr(t, k)) for k, _ in t._fields_}
+        return {k: (float if k == "fine_tile_growth" else int)(getattr(t, k)) for k, _ in t._fields_}
 
     def set_tuning(self, **kw):
         """sgs_set_tuning: any of lanes, group, group_lanes, morton, record_capacity, fine_tile_pixels (the others keep their values); applies to the scenes
@@ -192,7 +193,7 @@ class Renderer:
             if k not in dict(t._fields_):
                 raise TypeError(f"unknown tuning field {k!r}")
             if v is not None:
-                setattr(t, k, int(v))
+                setattr(t, k, float(v) if k == "fine_tile_growth" else int(v))
         self._lib.check(self._lib.sgs_set_tuning(self._ctx, C.byref(t)), self._ctx)
 
     # -- scene ------------------------------------------------------------------------------------

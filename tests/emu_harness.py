@@ -133,13 +133,13 @@ class EmuRenderer:
         t = _capi.SgsTuning()
         self.lib.check(self.lib.sgs_get_tuning(self.ctx, C.byref(t)), self.ctx)
         for k, v in kw.items():
-            setattr(t, k, int(v))
+            setattr(t, k, float(v) if k == "fine_tile_growth" else int(v))
         self.lib.check(self.lib.sgs_set_tuning(self.ctx, C.byref(t)), self.ctx)
 
     def tuning(self):
         t = _capi.SgsTuning()
         self.lib.check(self.lib.sgs_get_tuning(self.ctx, C.byref(t)), self.ctx)
-        return {k: int(getattr(t, k)) for k, _ in t._fields_}
+        return {k: (float if k == "fine_tile_growth" else int)(getattr(t, k)) for k, _ in t._fields_}
 
     def chunk_skipped(self):
         return self.debug(_capi.BUF_CHUNK_SKIPPED, np.uint8)

@@ -39,6 +39,24 @@ def look_at_view(eye, target, down=(0, 1, 0)):
     return V.astype(np.float32)
 
 
+class forced_fine:
+    """with forced_fine(drv): frames small enough for fine tiles (sgs_tuning.fine_tile_pixels) ARE rendered through them, whatever the
+    growth of their record count says (sgs_tuning.fine_tile_growth >= 16: the pixel rule alone) — the tests' way to the fine-tile path on
+    scenes of large splats, which the library itself would render through 16x16-pixel tiles."""
+
+    def __init__(self, drv):
+        self.drv = drv
+
+    def __enter__(self):
+        self.keep = self.drv.tuning()["fine_tile_growth"]
+        self.drv.set_tuning(fine_tile_growth=1.0e9)
+        return self
+
+    def __exit__(self, *exc):
+        self.drv.set_tuning(fine_tile_growth=self.keep)
+        return False
+
+
 def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True, upload=True):
     """Full comparison of one frame: counts and queues bit-exact, splat attributes to fp32 rounding,
     image within the parity tolerance.  upload=False: `scene` is already the driver's uploaded scene (several poses
@@ -110,22 +128,35 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     if "d_fetched" in st_loose and st_loose["d_fetched"]:
         # D_f (reference binning) only differs from the oracle's where a pixel sat on the termination threshold
         assert abs(st_loose["d_fetched"] - aux["D_f"]) <= max(8, 2e-3 * aux["D_f"]), (what, st_loose["d_fetched"], aux["D_f"])
-    # FINE TILES — what the library does with a frame this small unless told otherwise (sgs_tuning.fine_tile_pixels; sgs_common.h): the frame
-    # through tiles of 8x8 or 4x4 pixels.  The same splats reach every pixel (S3's rect stays a rect of 16x16-pixel tiles: N_v is the
-    # oracle's), the blend's coordinates are relative to another origin: the oracle's frame within the same tolerance, every pixel,
-    # threshold-sensitive ones two-sidedly — and the instantiations / switches that must not change a frame do not change this one either.
-    img_f, st_f = drv.render(cam, cfg, rows)
-    st["n_tiles_default"] = st_f["n_tiles"]
-    if st_f["n_tiles"] != st["n_tiles"]:
-        assert st_f["n_visible"] == aux["n_visible"], (what, st_f["n_visible"], aux["n_visible"])
-        img_fp, st_fp = drv.render(cam, cfg, rows, stats=False)
-        assert (img_fp == img_f).all() and st_fp["d_total"] == st_f["d_total"], f"{what}: fine tiles: the frame depends on whether D_f is counted"
-        img_fn, _ = drv.render(cam, cfg, rows, stats=False, deep=False)
-        img_fa, st_fa = drv.render(cam, cfg, rows, chunk_cull=False)
-        assert (img_fn == img_f).all() and (img_fa == img_f).all() and st_fa["d_total"] == st_f["d_total"], f"{what}: fine tiles: a switch changed the frame"
-        worst = max(worst, assert_frame_close(img_f[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " [fine tiles]", y0=ya))
+    # FINE TILES — the frame through tiles of 8x8 or 4x4 pixels (sgs_tuning.fine_tile_pixels; sgs_common.h), forced here for every frame small
+    # enough (the library itself also asks that the split does not multiply the records by more than fine_tile_growth).  The same splats reach
+    # every pixel (S3's rect stays a rect of 16x16-pixel tiles: N_v is the oracle's), the blend's coordinates are relative to another origin:
+    # the oracle's frame within the same tolerance, every pixel, threshold-sensitive ones two-sidedly — and the instantiations / switches
+    # that must not change a frame do not change this one either.
+    with forced_fine(drv):
+        img_f, st_f = drv.render(cam, cfg, rows)
+        st["n_tiles_fine"] = st_f["n_tiles"]
+        if st_f["n_tiles"] != st["n_tiles"]:
+            assert st_f["n_visible"] == aux["n_visible"], (what, st_f["n_visible"], aux["n_visible"])
+            img_fp, st_fp = drv.render(cam, cfg, rows, stats=False)
+            assert (img_fp == img_f).all() and st_fp["d_total"] == st_f["d_total"], f"{what}: fine tiles: the frame depends on whether D_f is counted"
+            img_fn, _ = drv.render(cam, cfg, rows, stats=False, deep=False)
+            img_fa, st_fa = drv.render(cam, cfg, rows, chunk_cull=False)
+            assert (img_fn == img_f).all() and (img_fa == img_f).all() and st_fa["d_total"] == st_f["d_total"], f"{what}: fine tiles: a switch changed the frame"
+            worst = max(worst, assert_frame_close(img_f[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " [fine tiles]", y0=ya))
+        else:
+            assert (img_f == img).all(), f"{what}: SGS_FLAG_NO_FINE_TILES changed a frame that is not rendered through fine tiles"
+    # ... and what the library does with this frame when nobody tells it: one of the tilings above (or the one between them), its own decision
+    # (fine_shift_of: the pixel rule and the growth of the record count, estimated from the scene's probe) — the same frame, bit for bit
+    img_d, st_d = drv.render(cam, cfg, rows)
+    st["n_tiles_default"] = st_d["n_tiles"]
+    if st_d["n_tiles"] == st["n_tiles"]:
+        assert (img_d == img).all(), f"{what}: the default tiling is 16x16 and the frame is not the 16x16 frame"
+    elif st_d["n_tiles"] == st_f["n_tiles"]:
+        assert (img_d == img_f).all() and st_d["d_total"] == st_f["d_total"], f"{what}: the default tiling is the forced one and the frame is not"
     else:
-        assert (img_f == img).all(), f"{what}: SGS_FLAG_NO_FINE_TILES changed a frame that is not rendered through fine tiles"
+        assert st["n_tiles"] < st_d["n_tiles"] < st_f["n_tiles"] and st_d["n_visible"] == aux["n_visible"]
+        worst = max(worst, assert_frame_close(img_d[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " [8x8-pixel tiles]", y0=ya))
     return img, st, aux, worst
 
 
@@ -278,33 +309,34 @@ def case_interleaved_rows(drv, stride, n=2500, res=(208, 150)):
     cam = onp.Camera(w, h, 0.8 * w, 0.8 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
     gy = (h + 15) // 16
-    for fine in (False, True):
-        full, st_full = drv.render(cam, fine=fine)
-        _, st_full_ref = drv.render(cam, loose_cull=True)
-        assert (st_full["n_tiles"] != gy * ((w + 15) // 16)) == fine, "this frame is meant to be small enough for fine tiles"
-        cp = next(c for c in (16, 8, 4) if -(-w // c) * -(-h // c) == st_full["n_tiles"])          # the tile's side in pixels
-        d_sum = d_ref_sum = pix = 0
-        seen = np.zeros(gy, bool)
-        for phase in range(stride):
-            img, st = drv.render(cam, interleave=(stride, phase), fine=fine)
-            _, st_ref = drv.render(cam, interleave=(stride, phase), loose_cull=True)
-            owned = list(range(phase, gy, stride))
-            rows_of_tiles = sum(-(-(min(16 * row + 16, h) - 16 * row) // cp) for row in owned)
-            assert img.shape[0] == 16 * len(owned) and st["n_tiles"] == rows_of_tiles * (-(-w // cp)), (st["n_tiles"], rows_of_tiles, cp)
-            for k, row in enumerate(owned):
-                y0, y1 = 16 * row, min(16 * row + 16, h)
-                assert (img[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"stride {stride} phase {phase}: frame row {row} (fine {fine})"
-                assert (img[16 * k + (y1 - y0): 16 * k + 16] == -1).all(), "pixels below the frame must stay untouched"
-                seen[row] = True
-                pix += (y1 - y0) * w
-            d_sum += st["d_total"]; d_ref_sum += st_ref["d_total"]
-            # a sub-range of the owned rows: only those are written
-            if len(owned) >= 2:
-                part, st_p = drv.render(cam, rows=(1, 2), interleave=(stride, phase), fine=fine)
-                y0, y1 = 16 * owned[1], min(16 * owned[1] + 16, h)
-                assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
-        assert seen.all() and pix == w * h
-        assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
+    with forced_fine(drv):              # (switches nothing for the fine=False renders and the hooks: those are 16x16 by flag)
+        for fine in (False, True):
+            full, st_full = drv.render(cam, fine=fine)
+            _, st_full_ref = drv.render(cam, loose_cull=True)
+            assert (st_full["n_tiles"] != gy * ((w + 15) // 16)) == fine, "this frame is meant to be small enough for fine tiles"
+            cp = next(c for c in (16, 8, 4) if -(-w // c) * -(-h // c) == st_full["n_tiles"])          # the tile's side in pixels
+            d_sum = d_ref_sum = pix = 0
+            seen = np.zeros(gy, bool)
+            for phase in range(stride):
+                img, st = drv.render(cam, interleave=(stride, phase), fine=fine)
+                _, st_ref = drv.render(cam, interleave=(stride, phase), loose_cull=True)
+                owned = list(range(phase, gy, stride))
+                rows_of_tiles = sum(-(-(min(16 * row + 16, h) - 16 * row) // cp) for row in owned)
+                assert img.shape[0] == 16 * len(owned) and st["n_tiles"] == rows_of_tiles * (-(-w // cp)), (st["n_tiles"], rows_of_tiles, cp)
+                for k, row in enumerate(owned):
+                    y0, y1 = 16 * row, min(16 * row + 16, h)
+                    assert (img[16 * k: 16 * k + (y1 - y0)] == full[y0:y1]).all(), f"stride {stride} phase {phase}: frame row {row} (fine {fine})"
+                    assert (img[16 * k + (y1 - y0): 16 * k + 16] == -1).all(), "pixels below the frame must stay untouched"
+                    seen[row] = True
+                    pix += (y1 - y0) * w
+                d_sum += st["d_total"]; d_ref_sum += st_ref["d_total"]
+                # a sub-range of the owned rows: only those are written
+                if len(owned) >= 2:
+                    part, st_p = drv.render(cam, rows=(1, 2), interleave=(stride, phase), fine=fine)
+                    y0, y1 = 16 * owned[1], min(16 * owned[1] + 16, h)
+                    assert (part[16: 16 + (y1 - y0)] == full[y0:y1]).all() and (part[:16] == -1).all() and (part[32:] == -1).all()
+            assert seen.all() and pix == w * h
+            assert d_sum == st_full["d_total"] and d_ref_sum == st_full_ref["d_total"]
 
 
 def case_chunk_bounds(drv, n=6000, res=(208, 150)):
@@ -347,23 +379,24 @@ def case_tile_rows(drv, n=2500, res=(208, 150)):
     drv.upload(*scene)
     gy = (h + 15) // 16
     cuts = [0, gy // 3, gy // 3 + 1, gy]
-    for fine in (False, True):
-        full, st_full = drv.render(cam, fine=fine)
-        union = np.full_like(full, -1.0)
-        d_sum = 0
-        for r0, r1 in zip(cuts[:-1], cuts[1:]):
-            out = np.full_like(full, -1.0)
-            img, st = drv.render(cam, None, (r0, r1), out=out, fine=fine)
-            y0, y1 = r0 * 16, min(r1 * 16, h)
-            assert (img[:y0] == -1).all() and (img[y1:] == -1).all(), "rows outside the band must be untouched"
-            ref, aux = oracle_c.render(*scene, cam, None, r0, r1)
-            _, st_ref = drv.render(cam, None, (r0, r1), loose_cull=True)      # reference binning: the oracle's D
-            assert st_ref["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"] and (fine or st["d_total"] <= aux["D"])
-            assert_frame_close(img[y0:y1], ref[y0:y1], aux["margin"][y0:y1], aux["recheck"], what=f"tile rows [{r0}, {r1}) fine={fine}", y0=y0)
-            union[y0:y1] = img[y0:y1]
-            d_sum += st["d_total"]
-        assert (union == full).all(), f"union of tile-row bands != full frame (fine {fine})"
-        assert d_sum == st_full["d_total"]
+    with forced_fine(drv):              # (switches nothing for the fine=False renders and the hooks: those are 16x16 by flag)
+        for fine in (False, True):
+            full, st_full = drv.render(cam, fine=fine)
+            union = np.full_like(full, -1.0)
+            d_sum = 0
+            for r0, r1 in zip(cuts[:-1], cuts[1:]):
+                out = np.full_like(full, -1.0)
+                img, st = drv.render(cam, None, (r0, r1), out=out, fine=fine)
+                y0, y1 = r0 * 16, min(r1 * 16, h)
+                assert (img[:y0] == -1).all() and (img[y1:] == -1).all(), "rows outside the band must be untouched"
+                ref, aux = oracle_c.render(*scene, cam, None, r0, r1)
+                _, st_ref = drv.render(cam, None, (r0, r1), loose_cull=True)      # reference binning: the oracle's D
+                assert st_ref["d_total"] == aux["D"] and st["n_visible"] == aux["n_visible"] and (fine or st["d_total"] <= aux["D"])
+                assert_frame_close(img[y0:y1], ref[y0:y1], aux["margin"][y0:y1], aux["recheck"], what=f"tile rows [{r0}, {r1}) fine={fine}", y0=y0)
+                union[y0:y1] = img[y0:y1]
+                d_sum += st["d_total"]
+            assert (union == full).all(), f"union of tile-row bands != full frame (fine {fine})"
+            assert d_sum == st_full["d_total"]
 
 
 def case_depth_ties(drv):
@@ -543,6 +576,48 @@ def case_determinism(drv, n=4000):
     p1, _ = drv.render(cam, stats=False, fine=False); p2, _ = drv.render(cam, stats=False, fine=False)      # the production instantiation twice
     assert (p1 == p2).all() and (p1 == a).all(), "two production renders of the same frame differ"
     assert (a == b).all() and (ids_a == ids_b).all(), "two renders of the same frame differ"
-    f1, st1 = drv.render(cam, stats=False); f2, st2 = drv.render(cam, stats=False)  # ... and as a frame this small is rendered by default: fine tiles
+    with forced_fine(drv):
+        f1, st1 = drv.render(cam, stats=False); f2, st2 = drv.render(cam, stats=False)  # ... and through fine tiles
     assert st1["n_tiles"] > st["n_tiles"] and (f1 == f2).all() and st1 == st2, "two fine-tile renders of the same frame differ"
     assert float(np.mean(np.abs(f1 - a).max(axis=-1) > 1e-5)) < 2e-3 and float(np.median(np.abs(f1 - a))) < 1e-6, "fine tiles moved the frame by more than rounding"
+    d1, sd1 = drv.render(cam, stats=False); d2, sd2 = drv.render(cam, stats=False)      # ... and as the library decides by itself
+    assert (d1 == d2).all() and sd1 == sd2 and ((d1 == f1).all() or (d1 == a).all() or sd1["n_tiles"] not in (st["n_tiles"], st1["n_tiles"]))
+
+
+def case_fine_tile_decision(drv, n=500):
+    """fine_shift_of (sgs_api.hip): a frame small enough for fine tiles is split while halving the tiles multiplies its (Gaussian, tile)
+    records by no more than sgs_tuning.fine_tile_growth — a ratio the library ESTIMATES on the host from the scene's probe (here the
+    whole scene: fewer Gaussians than a probe holds).  Scenes of splats from far below a tile to several tiles wide, at two resolutions:
+    the decision must agree with the frame's REAL record counts wherever those are clear of the threshold, the frame must be the frame of
+    the tiling it chose (bit for bit), a batch and a band must make the same choice as the single frame."""
+    g = drv.tuning()["fine_tile_growth"]
+    assert g == 2.2
+    seen = set()
+    for seed, scale in ((1, (0.004, 0.02)), (2, (0.01, 0.05)), (3, (0.03, 0.15)), (4, (0.1, 0.5)), (5, (0.3, 1.2))):
+        scene = random_scene(n, 300 + seed, 1, scale=scale, opac_mu=1.0)
+        drv.upload(*scene)
+        for (w, h) in ((96, 64), (200, 152)):
+            cam = onp.Camera(w, h, 0.9 * w, 0.9 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
+            tiles = lambda c: -(-w // c) * -(-h // c)
+            # the three tilings, each forced (the pixel rule alone: fine_tile_pixels = 0 / W H / 4 W H under a growth limit that never binds)
+            keep = drv.tuning()
+            D, img = {}, {}
+            for side, fp in ((16, 0), (8, w * h), (4, 4 * w * h)):
+                drv.set_tuning(fine_tile_pixels=fp, fine_tile_growth=1.0e9)
+                img[side], st = drv.render(cam, stats=False)
+                assert st["n_tiles"] == tiles(side)
+                D[side] = st["d_total"]
+            drv.set_tuning(fine_tile_pixels=4 * w * h, fine_tile_growth=keep["fine_tile_growth"])     # (both splits allowed by the pixel rule)
+            got, st = drv.render(cam, stats=False)
+            side = next(c for c in (16, 8, 4) if tiles(c) == st["n_tiles"])
+            assert (got == img[side]).all() and st["d_total"] == D[side], f"seed {seed} {w}x{h}: the frame is not the frame of the tiling it chose"
+            g1, g2 = D[8] / max(1, D[16]), D[4] / max(1, D[8])
+            want = 16 if g1 > g else 8 if g2 > g else 4
+            clear = abs(g1 - g) > 0.12 * g and (g1 > g or abs(g2 - g) > 0.12 * g)        # (the estimate bins extents, not the exact rects: a few per cent)
+            assert side == want or not clear, f"seed {seed} {w}x{h}: records grow by {g1:.2f}, {g2:.2f} per split, the library chose {side}x{side}"
+            seen.add(side)
+            gy = (h + 15) // 16
+            band, st_b = drv.render(cam, rows=(1, gy - 1), stats=False, out=np.full((h, w, 3), -1.0, np.float32))
+            assert (band[16:16 * (gy - 1)] == got[16:16 * (gy - 1)]).all(), f"seed {seed} {w}x{h}: a band chose another tiling than its frame"
+            drv.set_tuning(fine_tile_pixels=keep["fine_tile_pixels"], fine_tile_growth=keep["fine_tile_growth"])
+    assert seen == {16, 8, 4}, seen          # (the five scenes span the three outcomes)

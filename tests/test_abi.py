@@ -29,7 +29,7 @@ def test_header_and_binding_agree(lib):
 
 def test_version_and_default_config(lib):
     from sage_gs import _capi
-    assert lib.version() == _capi.ABI_VERSION == 113
+    assert lib.version() == _capi.ABI_VERSION == 114
     hdr = open(os.path.join(ROOT, "include", "sage_gs.h")).read()
     assert int(re.search(r"#define SGS_VERSION (\d+)", hdr).group(1)) == _capi.ABI_VERSION
     cfg = lib.default_config()

@@ -97,6 +97,10 @@ def test_depth_and_coverage_outputs(drv):
     pc.case_depth_aux(drv, n=1500, res=(96, 80))
 
 
+def test_fine_tile_decision_follows_the_growth_of_the_record_count(drv):
+    pc.case_fine_tile_decision(drv)
+
+
 def test_determinism(drv):
     pc.case_determinism(drv, n=1500)
 
@@ -134,7 +138,8 @@ def test_against_committed_golden_fixture(drv):
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
     assert_frame_close(img, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1")
-    fine, st_fine = drv.render(cam)                                   # ... and the frame as it is rendered by default: fine tiles
+    with pc.forced_fine(drv):
+        fine, st_fine = drv.render(cam)                               # ... and through fine tiles
     assert st_fine["n_tiles"] > st_prod["n_tiles"] and st_fine["n_visible"] == int(g["n_visible"])
     assert_frame_close(fine, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1 [fine tiles]")
 
@@ -219,6 +224,8 @@ def test_batch_on_a_fresh_context_survives_overflowing_frames():
 def test_kernels_against_closed_form_answers(drv, case):
     """The analytic cases that pin the oracle, run straight against the kernels (emulator) — no oracle involved."""
     case(drv)
+    with pc.forced_fine(drv):              # ... and through the fine tiles a frame this small may get (the library decides per frame)
+        case(drv)
 
 
 def test_argument_errors_are_reported_not_swallowed(drv):
@@ -389,36 +396,42 @@ def test_tuning_surface(drv):
     lib, ctx = drv.lib, drv.ctx
     t = _capi.SgsTuning()
     lib.sgs_tuning_default(C.byref(t))
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == (3, 4, 2, 1, 16 << 20, 640 * 480)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth) == (3, 4, 2, 1, 16 << 20, 640 * 480, 2.2)
     scene = pc.random_scene(900, 41, 1, scale=(0.05, 0.3))
     cam = onp.Camera(96, 64, 70.0, 70.0, 48.0, 32.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
-    want, st0 = drv.render(cam, stats=False)
+    FORCE = 1.0e9                                           # fine_tile_growth >= 16: fine tiles whenever the pixel rule allows
+    with pc.forced_fine(drv):
+        want, st0 = drv.render(cam, stats=False)
     want16, st16 = drv.render(cam, stats=False, fine=False)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels)
+    keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth)
     for bad in ((0, 4, 2), (9, 4, 2), (3, 9, 1), (3, 4, 3), (3, 0, 1)):
-        u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20, 640 * 480)
+        u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20, 640 * 480, 2.2)
         assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"sgs_tuning" in lib.sgs_last_error(ctx)
-    u = _capi.SgsTuning(3, 4, 2, 1, 0, 640 * 480)
+    u = _capi.SgsTuning(3, 4, 2, 1, 0, 640 * 480, 2.2)
     assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1
-    u = _capi.SgsTuning(3, 4, 2, 1, 1 << 20, -1)
+    u = _capi.SgsTuning(3, 4, 2, 1, 1 << 20, -1, 2.2)
     assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"fine_tile_pixels" in lib.sgs_last_error(ctx)
+    for g_bad in (0.5, float("nan")):
+        u = _capi.SgsTuning(3, 4, 2, 1, 1 << 20, 640 * 480, g_bad)
+        assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"fine_tile_growth" in lib.sgs_last_error(ctx)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == keep, "a refused tuning changed the context"
-    u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, 640 * 480)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth) == keep, "a refused tuning changed the context"
+    u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, 640 * 480, FORCE)
     lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels) == (5, 2, 3, 0, 1 << 20, 640 * 480)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth) == (5, 2, 3, 0, 1 << 20, 640 * 480, FORCE)
     drv.upload(*scene)                                   # (morton = 0: the caller's order is kept)
     got, st1 = drv.render(cam, stats=False)
     assert (got == want).all() and st1["n_visible"] == st0["n_visible"] and st1["d_total"] == st0["d_total"]
-    # fine_tile_pixels is the one field a frame depends on (to rounding): which tiles a frame of W x H pixels is rendered through —
-    # 4x4-pixel tiles up to a quarter of it, 8x8 up to it, 16x16 above (= SGS_FLAG_NO_FINE_TILES, bit for bit); the count of tiles says which
+    # fine_tile_pixels / fine_tile_growth are the fields a frame depends on (to rounding): which tiles a frame of W x H pixels is rendered
+    # through — with the growth rule out of the way (FORCE): 4x4-pixel tiles up to a quarter of fine_tile_pixels, 8x8 up to it, 16x16 above
+    # (= SGS_FLAG_NO_FINE_TILES, bit for bit); the count of tiles says which
     tiles = lambda c: -(-96 // c) * -(-64 // c)
     assert st0["n_tiles"] == tiles(4) and st16["n_tiles"] == tiles(16)
     for fp, side in ((0, 16), (96 * 64 - 1, 16), (96 * 64, 8), (4 * 96 * 64 - 1, 8), (4 * 96 * 64, 4), (1 << 40, 4)):
-        u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, fp)
+        u = _capi.SgsTuning(5, 2, 3, 0, 1 << 20, fp, FORCE)
         lib.check(lib.sgs_set_tuning(ctx, C.byref(u)), ctx)
         img, st = drv.render(cam, stats=False)
         assert st["n_tiles"] == tiles(side), (fp, side, st["n_tiles"])

@@ -586,10 +586,12 @@ def test_culling_never_changes_a_pixel_stress(drv):
         assert (prod == ref).all(), f"yaw {yaw}: {(prod != ref).sum().item()} values differ"
         assert st["n_visible"] == st_ref["n_visible"] and st["d_total"] < st_ref["d_total"]
         assert torch.isfinite(prod).all()
-        # ... and as a 640x480 frame is rendered by default — through 8x8-pixel tiles (sgs_tuning.fine_tile_pixels): the same splats reach
+        # ... and through 8x8-pixel tiles (what a 640x480 frame of smaller splats gets by default, sgs_tuning.fine_tile_pixels / _growth; forced
+        # here — these splats are large, the library itself keeps 16x16): the same splats reach
         # every pixel, the blend's coordinates are relative to another origin; held against the ORACLE here, every pixel, threshold-sensitive
         # ones two-sidedly (the needles' exponents cancel from ~1e6 to ~1: the scene the completed-square form was made for)
-        fine = drv.r.render(cam, scene).cpu().numpy()
+        with pc.forced_fine(drv):
+            fine = drv.r.render(cam, scene).cpu().numpy()
         st_f = drv.r.last_stats
         assert st_f["n_tiles"] == 80 * 60 and st_f["n_visible"] == st["n_visible"]
         ocam = onp.Camera(640, 480, 400.0, 400.0, 320.0, 240.0, V.astype(np.float32))
@@ -605,6 +607,8 @@ def test_culling_never_changes_a_pixel_stress(drv):
 def test_kernels_against_closed_form_answers(drv, case):
     """The analytic cases that pin the oracle, run straight against the HIP path — no oracle involved."""
     case(drv)
+    with pc.forced_fine(drv):              # ... and through the fine tiles a frame this small may get (the library decides per frame)
+        case(drv)
 
 
 def test_against_committed_golden_fixture(drv):
@@ -621,7 +625,8 @@ def test_against_committed_golden_fixture(drv):
     assert st["d_total"] == int(g["D"]) and st["n_visible"] == int(g["n_visible"]) and st["d_fetched"] == int(g["D_f"])
     assert (off == g["offsets"]).all() and (ids == g["ids"]).all()
     assert_frame_close(img, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1")
-    fine, st_fine = drv.render(cam)                                   # ... and the frame as it is rendered by default: fine tiles
+    with pc.forced_fine(drv):
+        fine, st_fine = drv.render(cam)                               # ... and through fine tiles
     assert st_fine["n_tiles"] > st_prod["n_tiles"] and st_fine["n_visible"] == int(g["n_visible"])
     assert_frame_close(fine, g["image"], g["margin"], stored_variants(g["flag_yx"], g["flag_ptr"], g["flag_rgb"]), what="golden config1 [fine tiles]")
 
@@ -973,6 +978,37 @@ def test_sweep_driver_against_the_oracle(drv, tmp_path):
     scene.free()
 
 
+def test_fine_tile_decision_follows_the_growth_of_the_record_count(drv):
+    pc.case_fine_tile_decision(drv)
+
+
+def test_a_batch_whose_frames_choose_different_tilings(drv):
+    """fine_shift_of decides per camera (the growth of the record count under a split depends on how large the splats are on THAT
+    screen); the frames of a launch group share one grid of tiles, so a batch's groups end where the choice changes.  A batch that zooms
+    in and out of a room — focal lengths from a quarter to four times the reference lens — must hold every frame as the single-frame
+    call renders it, bit for bit, with the count of tiles the single call reports; and both tilings must occur, or the test proves nothing."""
+    import torch
+    from sage_gs import Camera, scenes
+    sc = scenes.make_room(200_000, seed=9)
+    base = scenes.room_cameras(sc, 640, 480, n_positions=2, n_yaw=4, seed=9)
+    zooms = (1.0, 0.3, 3.5, 4.0, 0.25, 1.0, 3.0, 0.5, 0.3, 3.8, 1.2)
+    cams = [Camera(c.width, c.height, c.fx * k, c.fy * k, c.cx, c.cy, c.view) for c, k in zip(base * 2, zooms)]
+    scene = drv.r.upload(scenes.to_gaussians(sc, "cuda:0"))
+    one, tiles = [], []
+    for c in cams:
+        one.append(drv.r.render(c, scene).clone()); tiles.append(drv.r.last_stats["n_tiles"])
+    assert set(tiles) == {40 * 30, 80 * 60}, tiles
+    batch, bst = drv.r.render_batch(cams, scene, want_stats=True)
+    outs = [torch.zeros_like(one[0]) for _ in cams]
+    for c, o in zip(cams, outs):
+        drv.r.render(c, scene, out=o, sync=False, pipelined=True)
+    drv.r.sync()
+    for i in range(len(cams)):
+        assert bst[i]["n_tiles"] == tiles[i], (i, bst[i]["n_tiles"], tiles[i])
+        assert (batch[i] == one[i]).all() and (outs[i] == one[i]).all(), f"frame {i} (zoom {zooms[i]}) depends on how it is issued"
+    scene.free()
+
+
 def test_frames_do_not_depend_on_the_tuning(drv):
     """include/sage_gs.h sgs_tuning (the library's whole tuning surface: it reads nothing from the environment): lanes in flight, frames per
     launch group, streams per batch, Z-order at upload.  Pipelined single frames and a batch under non-default values must equal, bit for
@@ -984,7 +1020,7 @@ def test_frames_do_not_depend_on_the_tuning(drv):
     g = scenes.to_gaussians(sc, "cuda:0")
     scene = drv.r.upload(g)
     assert drv.r.tuning() == {"lanes": 3, "group": 4, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"],
-                              "fine_tile_pixels": 640 * 480}
+                              "fine_tile_pixels": 640 * 480, "fine_tile_growth": 2.2}
     want, stats = [], []
     for c in cams:
         want.append(drv.r.render(c, scene).clone()); stats.append((drv.r.last_stats["n_visible"], drv.r.last_stats["d_total"]))
@@ -1009,11 +1045,14 @@ def test_frames_do_not_depend_on_the_tuning(drv):
         s2.free(); r.close()
     # refused, with a message, not clamped
     r = Renderer("cuda:0")
-    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5), dict(fine_tile_pixels=-1)):
+    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5), dict(fine_tile_pixels=-1),
+                dict(fine_tile_growth=0.5)):
         with pytest.raises(Exception, match="sgs_tuning"):
             r.set_tuning(**bad)
-    # fine_tile_pixels — the one field a frame depends on, to rounding: which tiles a frame of W x H pixels is rendered through.  A frame
-    # issued alone, pipelined and in a batch is the same frame under every value; 0 = SGS_FLAG_NO_FINE_TILES, bit for bit
+    # fine_tile_pixels / fine_tile_growth — the fields a frame depends on, to rounding: which tiles a frame of W x H pixels is rendered
+    # through (here with the growth rule out of the way).  A frame issued alone, pipelined and in a batch is the same frame under every
+    # value; 0 = SGS_FLAG_NO_FINE_TILES, bit for bit
+    r.set_tuning(fine_tile_growth=1.0e9)
     s2 = r.upload(g)
     small = scenes.room_cameras(sc, 400, 300, n_positions=2, n_yaw=3, seed=6)
     w16 = [r.render(c, s2, fine_tiles=False).clone() for c in small]
