@@ -57,10 +57,12 @@ class forced_fine:
         return False
 
 
-def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True, upload=True):
+def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queues=True, upload=True, thorough=True):
     """Full comparison of one frame: counts and queues bit-exact, splat attributes to fp32 rounding,
     image within the parity tolerance.  upload=False: `scene` is already the driver's uploaded scene (several poses
-    of a multi-million-Gaussian scene are checked against one upload)."""
+    of a multi-million-Gaussian scene are checked against one upload).  thorough=False (a few long cases of the CPU emulator, whose point
+    lies elsewhere): the renders that only hold one switch against another — SGS_FLAG_NO_DEEP, no chunk culling, reference binning with
+    the lazy sort, and the same under fine tiles — are left to the other cases; everything held against the ORACLE stays."""
     if upload:
         drv.upload(*scene)
     # production path: tight bin rects, queues sorted lazily and only as far as the composite reads them — on 16x16-pixel tiles, the tiling
@@ -74,30 +76,34 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     # (the instantiation without D_f is also the only one that takes the deep-tile path: windows of a long-lived tile culled against its
     #  live pixels before anything is ranked — the comparison above holds the two paths against each other, bit for bit; and so does the
     #  runtime switch, SGS_FLAG_NO_DEEP, inside the one instantiation)
-    img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, deep=False, fine=False)
-    assert (img_nodeep == img).all() and st_nodeep["n_deep_windows"] == 0, f"{what}: the deep-tile cull changed a pixel"
+    if thorough:
+        img_nodeep, st_nodeep = drv.render(cam, cfg, rows, stats=False, deep=False, fine=False)
+        assert (img_nodeep == img).all() and st_nodeep["n_deep_windows"] == 0, f"{what}: the deep-tile cull changed a pixel"
     assert st["n_deep_windows"] == 0
     st["n_deep_windows_plain"] = st_plain["n_deep_windows"]
     # test hook: no chunk culling (every chunk of the scene projected).  The per-chunk bounds may only have skipped
     # chunks none of whose Gaussians is visible: same N_v, same queues, same frame.
-    drv.row_records(0, reset=True)
-    img_all, st_all = drv.render(cam, cfg, rows, chunk_cull=False, fine=False)
-    assert (img_all == img).all() and st_all["n_visible"] == st["n_visible"] and st_all["d_total"] == st["d_total"] \
-        and st_all["d_fetched"] == st["d_fetched"], f"{what}: chunk culling changed the frame"
-    # the per-row record counters (what cost-balanced bands are cut from) add up to D
-    gy_ = (cam.height + 15) // 16
-    rr = drv.row_records(gy_, reset=True)
-    assert int(rr.sum()) == st_all["d_total"] and (rr[:rows[0]] == 0).all() and (rows[1] < 0 or (rr[rows[1]:] == 0).all())
+    if thorough:
+        drv.row_records(0, reset=True)
+        img_all, st_all = drv.render(cam, cfg, rows, chunk_cull=False, fine=False)
+        assert (img_all == img).all() and st_all["n_visible"] == st["n_visible"] and st_all["d_total"] == st["d_total"] \
+            and st_all["d_fetched"] == st["d_fetched"], f"{what}: chunk culling changed the frame"
+        # the per-row record counters (what cost-balanced bands are cut from) add up to D
+        gy_ = (cam.height + 15) // 16
+        rr = drv.row_records(gy_, reset=True)
+        assert int(rr.sum()) == st_all["d_total"] and (rr[:rows[0]] == 0).all() and (rows[1] < 0 or (rr[rows[1]:] == 0).all())
     # test hook: order every queue completely (production binning)
     img_full, st_full = drv.render(cam, cfg, rows, full_sort=True)
     assert (img_full == img).all(), f"{what}: lazy and full sort must blend the same records in the same order"
     assert st_full["d_fetched"] == st["d_fetched"] and st_full["d_total"] == st["d_total"]
     # test hook: REFERENCE binning (S3's rect, what the oracle defines) + extent-only quadrant test.  The production
     # path may only have dropped records / (wave, splat) pairs that no pixel could use: frames bit-identical.
-    img_ref_lazy, st_ref_lazy = drv.render(cam, cfg, rows, loose_cull=True)
     img_loose, st_loose = drv.render(cam, cfg, rows, full_sort=True, loose_cull=True)
-    assert (img_loose == img).all() and (img_ref_lazy == img).all(), f"{what}: culling changed the frame"
-    assert st_ref_lazy["d_fetched"] == st_loose["d_fetched"] and st_ref_lazy["d_total"] == st_loose["d_total"]
+    assert (img_loose == img).all(), f"{what}: culling changed the frame"
+    if thorough:
+        img_ref_lazy, st_ref_lazy = drv.render(cam, cfg, rows, loose_cull=True)
+        assert (img_ref_lazy == img).all(), f"{what}: culling changed the frame (lazy sort)"
+        assert st_ref_lazy["d_fetched"] == st_loose["d_fetched"] and st_ref_lazy["d_total"] == st_loose["d_total"]
     assert st["d_total"] <= st_loose["d_total"] and st["d_fetched"] <= st_loose["d_fetched"]
     ref, aux = oracle_c.render(*scene, cam, cfg, rows[0], rows[1])
     assert st["n_visible"] == aux["n_visible"] == st_loose["n_visible"], (what, st["n_visible"], aux["n_visible"])
@@ -140,9 +146,10 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
             assert st_f["n_visible"] == aux["n_visible"], (what, st_f["n_visible"], aux["n_visible"])
             img_fp, st_fp = drv.render(cam, cfg, rows, stats=False)
             assert (img_fp == img_f).all() and st_fp["d_total"] == st_f["d_total"], f"{what}: fine tiles: the frame depends on whether D_f is counted"
-            img_fn, _ = drv.render(cam, cfg, rows, stats=False, deep=False)
-            img_fa, st_fa = drv.render(cam, cfg, rows, chunk_cull=False)
-            assert (img_fn == img_f).all() and (img_fa == img_f).all() and st_fa["d_total"] == st_f["d_total"], f"{what}: fine tiles: a switch changed the frame"
+            if thorough:
+                img_fn, _ = drv.render(cam, cfg, rows, stats=False, deep=False)
+                img_fa, st_fa = drv.render(cam, cfg, rows, chunk_cull=False)
+                assert (img_fn == img_f).all() and (img_fa == img_f).all() and st_fa["d_total"] == st_f["d_total"], f"{what}: fine tiles: a switch changed the frame"
             worst = max(worst, assert_frame_close(img_f[ya:yb], ref[ya:yb], aux["margin"][ya:yb], aux["recheck"], what=what + " [fine tiles]", y0=ya))
         else:
             assert (img_f == img).all(), f"{what}: SGS_FLAG_NO_FINE_TILES changed a frame that is not rendered through fine tiles"
@@ -166,15 +173,15 @@ def case_config1(drv, n=10_000):
     return check_against_oracle(drv, scene, cam, what=f"config1 n={n}")
 
 
-def case_sh_degrees(drv, n=1500):
+def case_sh_degrees(drv, n=1500, thorough=True):
     for deg in (0, 1, 2, 3):
         scene = random_scene(n, 20 + deg, deg, box=((-3, 3), (-2, 2), (-3, 3)))
         view = look_at_view((4.0, 0.5, 5.0), (0.0, 0.0, 0.0))
         cam = onp.Camera(160, 128, 110.0, 105.0, 81.2, 60.7, view)
-        check_against_oracle(drv, scene, cam, what=f"sh degree {deg}")
+        check_against_oracle(drv, scene, cam, what=f"sh degree {deg}", thorough=thorough or deg == 3)
         if deg == 3:     # evaluate a degree-3 scene at lower degrees
             for d in (0, 2):
-                check_against_oracle(drv, scene, cam, onp.Config(sh_degree=d), what=f"deg3 scene at degree {d}")
+                check_against_oracle(drv, scene, cam, onp.Config(sh_degree=d), what=f"deg3 scene at degree {d}", thorough=thorough)
 
 
 def case_ragged(drv):
@@ -517,7 +524,7 @@ def case_big_depth_bucket(drv, n_slab=3000):
     assert st["n_spill_tiles"] >= 1
 
 
-def case_full_grid_splat(drv, res=(1920, 1080)):
+def case_full_grid_splat(drv, res=(1920, 1080), thorough=True):
     """One huge splat covering every tile of a 1080p grid (120x68 = 8160 records from one lane) plus
     small ones: exercises the balanced duplication's row-major expansion over a wide rect."""
     w, h = res
@@ -530,7 +537,7 @@ def case_full_grid_splat(drv, res=(1920, 1080)):
     opac = np.full(n, 0.3, np.float32); opac[17] = 0.003             # below 1/255 everywhere: binned but never blended
     sh = rng.normal(size=(n, 1, 3)).astype(np.float32)
     cam = onp.Camera(w, h, 0.38 * w, 0.38 * w, w / 2.0, h / 2.0, np.eye(4, dtype=np.float32))
-    img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what="full-grid splat")
+    img, st, aux, _ = check_against_oracle(drv, (means, scales, quats, opac, sh, 0), cam, what="full-grid splat", thorough=thorough)
     assert aux["tiles"][17] == ((w + 15) // 16) * ((h + 15) // 16)
 
 

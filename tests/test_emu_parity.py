@@ -21,7 +21,7 @@ def test_config1(drv):
 
 
 def test_sh_degrees(drv):
-    pc.case_sh_degrees(drv, n=600)
+    pc.case_sh_degrees(drv, n=600, thorough=False)      # (thorough for the degree-3 scene at its own degree)
 
 
 def test_ragged_sizes(drv):
@@ -90,7 +90,7 @@ def test_full_grid_splat(drv):
 
 def test_wide_band_of_tiles(drv):
     # 129 x 65 = 8385 tiles (more than SGS_WT super-tile counters would be, were they per tile): one window of 33 x 17 super-tiles
-    pc.case_full_grid_splat(drv, res=(2064, 1040))
+    pc.case_full_grid_splat(drv, res=(2064, 1040), thorough=False)     # (the switch-against-switch renders: test_full_grid_splat)
 
 
 def test_depth_and_coverage_outputs(drv):
