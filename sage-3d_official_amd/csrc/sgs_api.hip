@@ -316,6 +316,34 @@ int fine_shift_of(const sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* 
     return z;
 }
 
+// How much of what they read of the scene do the frames of a group have in common?  The sum over the frames of the Gaussians in view,
+// over the Gaussians in view of ANY of them: 1 = disjoint views, nf = the same view nf times.  Estimated on the host from the scene's probe
+// (fine_shift_of; the samples weighted so that they count Gaussians): a sample is in view when its centre falls inside the image widened by
+// a tenth on every side, between the depth planes — ~1 us per frame.  What sgs_render_batch* decides k_preprocess_shared by: with the
+// views of a trajectory's consecutive frames (3.5-4) the group reads the scene once instead of nf times (a sweep of consecutive headings:
+// -7 % per frame, profiles/r06zb); with views that share little (the bench's stride-77 poses: 1.4) the shared grid's waves that find
+// their chunk dead in their frame cost more than the reads it saves (+8 %).
+double group_overlap(const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg) {
+    if (!scene || nf < 2 || scene->probe.size() < 64) return 1.0;
+    double sum = 0.0, uni = 0.0;
+    for (const ProbeSample& g : scene->probe) {
+        int seen = 0;
+        for (int f = 0; f < nf; ++f) {
+            const sgs_camera& c = cams[f];
+            const float* V = c.view;
+            const float tz = V[8] * g.m[0] + V[9] * g.m[1] + V[10] * g.m[2] + V[11];
+            if (!(tz > cfg.near_z) || !(tz <= cfg.far_z)) continue;
+            const float tx = V[0] * g.m[0] + V[1] * g.m[1] + V[2] * g.m[2] + V[3], ty = V[4] * g.m[0] + V[5] * g.m[1] + V[6] * g.m[2] + V[7];
+            const float px = c.fx * tx / tz + c.cx, py = c.fy * ty / tz + c.cy, mx = 0.1f * (float)c.width, my = 0.1f * (float)c.height;
+            if (px >= -mx && px < (float)c.width + mx && py >= -my && py < (float)c.height + my) ++seen;
+        }
+        sum += (double)g.wgt * seen; uni += seen ? (double)g.wgt : 0.0;
+    }
+    return uni > 0.0 ? sum / uni : 1.0;
+}
+constexpr double kShareOverlap = 1.0 / 3.0;      // k_preprocess_shared when the overlap is at least 1 + this much per further frame of the group: 2.0 of
+                                                 // 4 (groups of four, r06zb: +8 % per frame at 1.4, +2 % at 1.5, -3 % at 2.3, -5 % at 2.8, -7 % at 3.5)
+
 int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
              int& row_begin, int& row_end, const float* out_rgb, int* fine_shift = nullptr) {
     if (!scene || !cam || !out_rgb) SGS_FAIL(ctx, SGS_ERR_INVALID, "null scene / camera / output");
@@ -420,7 +448,7 @@ void launch_cull(const FrameGroup& G, int nf, hipStream_t stream) {
         hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), (unsigned)nf),
                            dim3(SGS_CULL_THREADS), 0, stream, G);
 }
-void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t stream) {
+void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t stream, bool share) {
     const FrameParams& P = G.s[0].P;
     if (P.n_chunks <= 0) return;
     launch_cull(G, nf, stream);
@@ -431,6 +459,12 @@ void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t
     if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all) {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<true, true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<true, false>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
+    }
+    else if (nf > 1 && share) {
+        // the full frames of a group share what they read of the scene (k_preprocess_shared: the grid over the scene's chunks, frames innermost)
+        const unsigned grid = (unsigned)(((all + 7) / 8) * 8 * nf);
+        if (fine) hipLaunchKernelGGL((sgs::k_preprocess_shared<true>), dim3(grid), dim3(256), 0, stream, G, (unsigned)nf);
+        else hipLaunchKernelGGL((sgs::k_preprocess_shared<false>), dim3(grid), dim3(256), 0, stream, G, (unsigned)nf);
     } else {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<false, true>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<false, false>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
@@ -541,7 +575,7 @@ void note_last(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
 //     launches were ~40 us, as long as a light band of tile rows takes on the GPU).
 int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
                   int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
-                  float* out_aux, bool pipelined, bool in_batch, int set0, int z, int stream_lane = -1) {
+                  float* out_aux, bool pipelined, bool in_batch, int set0, int z, int stream_lane = -1, bool share = false) {
     int rc;
     // The stream: a pipelined frame's own lane's; a batch's groups rotate over the streams of lanes 0 .. group_lanes-1 — the
     // SAME streams single pipelined frames use.  (r03y: the groups used to run on the streams of lanes 0 and 4; a process that
@@ -579,7 +613,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     for (int f = 0; f < nf; ++f) ctx->slot_timed[slot0 + f] = timed && f == 0;
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
-    launch_project(ctx, G, nf, stream);
+    launch_project(ctx, G, nf, stream, share);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
     launch_binning(ctx, G, nf, stream, timed ? ev[2] : nullptr);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
@@ -1156,8 +1190,9 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
             float* outs[SGS_MAX_GROUP];
             const int rb = rb0, re = re0;
             for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
+            const bool share = nf > 1 && group_overlap(scene, &cams[c0 + i], nf, cfg) >= 1.0 + kShareOverlap * (double)(nf - 1);
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
-                                    sidx * F, zs[(size_t)(c0 + i)], sidx)) != SGS_OK)
+                                    sidx * F, zs[(size_t)(c0 + i)], sidx, share)) != SGS_OK)
                 return rc;
             for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
             i += nf;

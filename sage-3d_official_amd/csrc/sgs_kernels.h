@@ -458,7 +458,9 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
     bool live = false;
     if (chunk < P.n_chunks) {
         live = (P.flags & 64u) != 0u || !chunk_outside(P, G.cbound[2 * chunk], G.cbound[2 * chunk + 1]);
-        if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; }
+        // (a live chunk's mask reads "all pending" until k_preprocess writes the wave's ballot over it: what k_preprocess_shared, which is
+        //  not given the live list's entries but the scene's chunks, tells a live chunk by)
+        if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; } else S.vismask[chunk] = ~0ull;
     }
     const unsigned long long m = __ballot(live);
     if (lane == 0) s_wcnt[wave] = (unsigned)__popcll(m);
@@ -853,6 +855,27 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
         for (unsigned k = k0; k < n_live; k += nw)         // wave-uniform
             preprocess_chunk<FINE>(P, geom, shq, splats, vismask, bigmask, big_list, binrec, st, (long long)S.live_list[k], lane);
     }
+}
+
+// The projection of a frame GROUP (full frames): the frames of a group read the SAME scene — a chunk that is live in several of them (the
+// poses of a sweep overlap: a trajectory's consecutive frames almost entirely, the bench's stride-77 poses by a quarter of what they read)
+// is 15 KiB of geometry and SH rows per frame, from HBM every time when each frame walks its own live list in its own part of the grid.  Here
+// the grid is laid over the SCENE's chunks, frames innermost and XCD-aware: workgroup b runs on XCD b mod 8 (round-robin dispatch), so
+//     b = ((q_hi nf + f) 8 + r)   <->   frame f of chunk quad q = 8 q_hi + r
+// puts the nf workgroups that want the same four chunks on ONE XCD, eight ids apart — dispatched together, the second to fourth find the
+// rows in that XCD's L2 (or merge with the request in flight).  A wave whose chunk is not live in its frame (k_chunk_cull left vismask 0)
+// ends at once, as the waves beyond the live list's end do in k_preprocess<false>: the same number of waves is launched.
+// Same per-chunk code, same outputs: frames bit-identical.
+template <bool FINE>
+__global__ __launch_bounds__(256) void k_preprocess_shared(const FrameGroup G, const unsigned nf) {
+    const unsigned b = blockIdx.x, r = b & 7u, t = b >> 3;
+    const unsigned f = t % nf, q = (t / nf) * 8u + r;
+    const FrameSlot& S = G.s[f];
+    const FrameParams& P = S.P;
+    const long long chunk = (long long)q * (blockDim.x >> 6) + (long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (chunk >= P.n_chunks) return;                                        // wave-uniform
+    if (S.vismask[chunk] == 0ull) return;                                   // not live in this frame (wave-uniform)
+    preprocess_chunk<FINE>(P, G.geom, G.shq, S.splats, S.vismask, S.bigmask, S.big_list, S.binrec, S.st, chunk, threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,8 +16,11 @@ dev = torch.device("cuda", 0)
 sc = scenes.make_trained_like(3_000_000, seed=2) if "trained" in args else scenes.cached_room(3_000_000, seed=2)
 STAGES = ("preprocess", "count", "emit", "render")
 poses = [(i * 77) % 256 for i in range(5, 105)]
+TRAJ = next((int(a[5:] or 1) for a in args if a.startswith("traj")), 0)
+if TRAJ:                   # headings TRAJ x 5.6 degrees apart from one position: what a trajectory's frames look like (traj, traj=4, ...)
+    poses = [(i * TRAJ) % 64 for i in range(5, 105)]
 tag = os.path.basename(os.environ.get("SAGE_GS_LIB", "default"))
-SCENE_TAG = "trained" if "trained" in args else "room"
+SCENE_TAG = ("trained" if "trained" in args else "room") + (f" traj={TRAJ}" if TRAJ else "")
 LIBS = next((a[5:].split(",") for a in args if a.startswith("libs=")), [None])
 
 
@@ -70,6 +73,23 @@ def latency(r, gs, cams, buf, n=32):
     return np.percentile(lat, 50), np.percentile(lat, 90)
 
 
+def group_overlap(cams, n=20):
+    """the library's group_overlap (sgs_api.hip) on 8192 Gaussians of the scene: sum over the frames of a group of four of the Gaussians in
+    view / those in view of any — averaged over the groups of the first n poses"""
+    rng = np.random.default_rng(0)
+    m = sc.means[rng.choice(sc.means.shape[0], 8192, replace=False)].astype(np.float64)
+    m = np.c_[m, np.ones(len(m))] @ (np.asarray(sc.model_to_world, np.float64).T if sc.model_to_world is not None else np.eye(4))
+    r = []
+    for g0 in range(0, n, 4):
+        seen = []
+        for p in poses[g0:g0 + 4]:
+            c = cams[p]; t = m @ np.asarray(c.view, np.float64).T
+            px, py = c.fx * t[:, 0] / t[:, 2] + c.cx, c.fy * t[:, 1] / t[:, 2] + c.cy
+            seen.append((t[:, 2] > 0.2) & (px >= -0.1 * c.width) & (px < 1.1 * c.width) & (py >= -0.1 * c.height) & (py < 1.1 * c.height))
+        r.append(sum(s_.sum() for s_ in seen) / max(1, np.logical_or.reduce(seen).sum()))
+    return float(np.mean(r))
+
+
 g_dev = scenes.to_gaussians(sc, dev)
 for libname in LIBS:
     if libname is None:
@@ -91,7 +111,7 @@ for libname in LIBS:
             a = alone(r, gs, cams, ring[0], N)
             line = f"[{tag}] {SCENE_TAG} {mode} {w}x{h}: alone us {a[0]} total {a[1]}  N_v={a[2]} D={a[3]} D_f={a[4]}"
             if (w, h) == (1920, 1080):
-                line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame | render_batch x20 {rate_batch(r, gs, cams, 20):.4f} x100 {rate_batch(r, gs, cams, 100):.4f}"
+                line += f" | pipelined {rate(r, gs, cams, ring):.4f} ms/frame | render_batch x20 {rate_batch(r, gs, cams, 20):.4f} x100 {rate_batch(r, gs, cams, 100):.4f} (group overlap {group_overlap(cams):.2f})"
             else:
                 p50, p90 = latency(r, gs, cams, ring[0])
                 line += f" | latency p50 {p50:.3f} p90 {p90:.3f} ms"

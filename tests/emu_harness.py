@@ -114,6 +114,16 @@ class EmuRenderer:
                                            out.ctypes.data, C.byref(st), None), self.ctx)
         return out, st.as_dict()
 
+    def render_batch(self, cams, fine=True):
+        """sgs_render_batch: the frames of `cams` (one resolution) as frame groups; [n, H, W, 3]."""
+        arr = (_capi.SgsCamera * len(cams))(*[_capi.make_camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy,
+                                                                np.asarray(c.view, np.float32).reshape(4, 4).tolist()) for c in cams])
+        k = self.lib.default_config()
+        k.flags = 0 if fine else _capi.FLAG_NO_FINE_TILES
+        out = np.zeros((len(cams), cams[0].height, cams[0].width, 3), np.float32)
+        self.lib.check(self.lib.sgs_render_batch(self.ctx, self.scene, arr, len(cams), C.byref(k), 0, -1, out.ctypes.data, None, None), self.ctx)
+        return out
+
     def render_aux(self, cam, cfg=None, fine=True):
         c = _capi.make_camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy,
                               np.asarray(cam.view, np.float32).reshape(4, 4).tolist())

@@ -591,6 +591,33 @@ def case_determinism(drv, n=4000):
     assert (d1 == d2).all() and sd1 == sd2 and ((d1 == f1).all() or (d1 == a).all() or sd1["n_tiles"] not in (st["n_tiles"], st1["n_tiles"]))
 
 
+def case_batch_shares_scene_reads(drv, n=4000, res=(160, 112)):
+    """sgs_render_batch*: the frames of a group whose views overlap (a trajectory's consecutive frames) are projected by ONE grid laid over
+    the scene's chunks, frames innermost (k_preprocess_shared: the group reads the scene once); frames whose views share little each walk
+    their own live list.  Which one runs is the library's choice (group_overlap, estimated from the scene's probe) and must not show: every
+    frame of a batch equals the frame rendered alone, bit for bit — for nearly identical views, for views turned a quarter circle apart, for
+    a batch that mixes them (groups of four: the kinds alternate), with fine tiles and without."""
+    scene = random_scene(n, 77, 2, box=((-4, 4), (-2, 2), (-4, 4)), scale=(0.02, 0.2))
+    drv.upload(*scene)
+    w, h = res
+
+    def cam_at(yaw_deg, dx=0.0):
+        a = np.deg2rad(yaw_deg)
+        eye = (0.3 + dx, 0.1, 0.2)
+        return onp.Camera(w, h, 0.7 * w, 0.7 * w, w / 2.0, h / 2.0, look_at_view(eye, (eye[0] + np.sin(a), eye[1], eye[2] + np.cos(a))))
+    near = [cam_at(10.0 + 2.0 * k, 0.02 * k) for k in range(6)]                  # consecutive frames of a path
+    far = [cam_at(90.0 * k) for k in range(4)] + [cam_at(45.0), cam_at(225.0)]   # views that share next to nothing
+    mixed = near[:4] + far[:4] + near[4:] + far[4:]
+    for cams in (near, far, mixed):
+        for fine in (False, True):
+            with forced_fine(drv):
+                alone = [drv.render(c, stats=False, fine=fine)[0] for c in cams]
+                batch = drv.render_batch(cams, fine=fine)
+            for i, a in enumerate(alone):
+                assert (batch[i] == a).all(), f"frame {i} of a batch of {len(cams)} differs from the frame rendered alone (fine {fine})"
+    assert any(a.max() > 0.05 for a in alone)
+
+
 def case_fine_tile_decision(drv, n=500):
     """fine_shift_of (sgs_api.hip): a frame small enough for fine tiles is split while halving the tiles multiplies its (Gaussian, tile)
     records by no more than sgs_tuning.fine_tile_growth — a ratio the library ESTIMATES on the host from the scene's probe (here the

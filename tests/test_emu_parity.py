@@ -101,6 +101,10 @@ def test_fine_tile_decision_follows_the_growth_of_the_record_count(drv):
     pc.case_fine_tile_decision(drv)
 
 
+def test_batch_shares_scene_reads(drv):
+    pc.case_batch_shares_scene_reads(drv)
+
+
 def test_determinism(drv):
     pc.case_determinism(drv, n=1500)
 

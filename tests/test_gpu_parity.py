@@ -50,6 +50,11 @@ class GpuDriver:
                             full_sort=full_sort, loose_cull=loose_cull, chunk_cull=chunk_cull, stats=stats, deep_cull=deep, fine_tiles=fine)
         return img.cpu().numpy(), self.r.last_stats
 
+    def render_batch(self, cams, fine=True):
+        from sage_gs import Camera
+        cl = [Camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy, np.asarray(c.view, np.float64)) for c in cams]
+        return self.r.render_batch(cl, self.scene, fine_tiles=fine).cpu().numpy()
+
     def render_aux(self, cam, cfg=None, fine=True):
         from sage_gs import Camera
         c = Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, np.asarray(cam.view, np.float64))
@@ -183,6 +188,10 @@ def test_full_grid_splat(drv):
 
 def test_depth_and_coverage_outputs(drv):
     pc.case_depth_aux(drv, n=20_000, res=(320, 240))
+
+
+def test_batch_shares_scene_reads(drv):
+    pc.case_batch_shares_scene_reads(drv, n=60_000, res=(640, 368))
 
 
 def test_determinism(drv):
