@@ -168,7 +168,7 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     if ((rc = grow(ctx, L.vismask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.bigmask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.binrec, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.live_list, (size_t)chunks)) != SGS_OK) return rc;
+    if ((rc = grow(ctx, L.live_list, (size_t)chunks + (size_t)(chunks + 31) / 32 + 2)) != SGS_OK) return rc;     // the list | the same as a bitmap (sgs_live_bits)
     if (!L.big_list && (rc = grow(ctx, L.big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * 2)) != SGS_OK) return rc;                      // list lengths | XCD ids
     if (!L.blk_list && (rc = grow(ctx, L.blk_list, (size_t)SGS_BIN_BLOCKS * SGS_WT)) != SGS_OK) return rc;
@@ -456,6 +456,9 @@ void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t
     // pre_grid workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
     const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
     const bool fine = ((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u) != 0u;        // (fine tiles: the instantiation that scales the splats, sgs_common.h)
+#ifdef SGS_FORCE_SHARE
+    share = true;                  // (A/B builds only: scripts/build_variant.sh ... -DSGS_FORCE_SHARE)
+#endif
     if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all) {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<true, true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<true, false>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);

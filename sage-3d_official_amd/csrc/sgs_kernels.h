@@ -448,6 +448,7 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
 // Gaussians, of which a rank's band of a sharded frame keeps a few per cent — instead of sweeping the scene.  Skipped
 // chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
 #define SGS_CULL_THREADS 256
+__device__ __forceinline__ unsigned* sgs_live_bits(unsigned* live_list, long long n_chunks) { return live_list + ((n_chunks + 1) & ~1ll); }
 __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
@@ -458,11 +459,15 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
     bool live = false;
     if (chunk < P.n_chunks) {
         live = (P.flags & 64u) != 0u || !chunk_outside(P, G.cbound[2 * chunk], G.cbound[2 * chunk + 1]);
-        // (a live chunk's mask reads "all pending" until k_preprocess writes the wave's ballot over it: what k_preprocess_shared, which is
-        //  not given the live list's entries but the scene's chunks, tells a live chunk by)
-        if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; } else S.vismask[chunk] = ~0ull;
+        if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; }
     }
     const unsigned long long m = __ballot(live);
+    // ... and the same as a BITMAP behind the list (k_preprocess_shared is not given the list's entries but the scene's chunks: 6 KiB per
+    // frame at 3 M Gaussians, a word per 32 chunks — the dead waves of its grid end on a scalar load that nearly always hits)
+    if (lane == 0 && chunk < P.n_chunks) {
+        unsigned* bits = sgs_live_bits(S.live_list, P.n_chunks);
+        bits[chunk >> 5] = (unsigned)m; bits[(chunk >> 5) + 1] = (unsigned)(m >> 32);
+    }
     if (lane == 0) s_wcnt[wave] = (unsigned)__popcll(m);
     __syncthreads();
     unsigned before = 0, total = 0;
@@ -863,7 +868,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
 // the grid is laid over the SCENE's chunks, frames innermost and XCD-aware: workgroup b runs on XCD b mod 8 (round-robin dispatch), so
 //     b = ((q_hi nf + f) 8 + r)   <->   frame f of chunk quad q = 8 q_hi + r
 // puts the nf workgroups that want the same four chunks on ONE XCD, eight ids apart — dispatched together, the second to fourth find the
-// rows in that XCD's L2 (or merge with the request in flight).  A wave whose chunk is not live in its frame (k_chunk_cull left vismask 0)
+// rows in that XCD's L2 (or merge with the request in flight).  A wave whose chunk is not live in its frame (k_chunk_cull's bitmap)
 // ends at once, as the waves beyond the live list's end do in k_preprocess<false>: the same number of waves is launched.
 // Same per-chunk code, same outputs: frames bit-identical.
 template <bool FINE>
@@ -874,7 +879,7 @@ __global__ __launch_bounds__(256) void k_preprocess_shared(const FrameGroup G, c
     const FrameParams& P = S.P;
     const long long chunk = (long long)q * (blockDim.x >> 6) + (long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (chunk >= P.n_chunks) return;                                        // wave-uniform
-    if (S.vismask[chunk] == 0ull) return;                                   // not live in this frame (wave-uniform)
+    if (!((sgs_live_bits(S.live_list, P.n_chunks)[chunk >> 5] >> (unsigned)(chunk & 31)) & 1u)) return;      // not live in this frame (wave-uniform)
     preprocess_chunk<FINE>(P, G.geom, G.shq, S.splats, S.vismask, S.bigmask, S.big_list, S.binrec, S.st, chunk, threadIdx.x & 63);
 }
 
