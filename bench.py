@@ -927,6 +927,28 @@ def main():
             out["also_measured"] = dict(out.get("also_measured") or {}, reference_resolutions=dict(
                 low, what="one frame at a time at the resolutions the reference renders (run_benchmark.py:1409-1419 --low-res 320x240, simple_env.py:52 "
                           "640x480, generate_images.py:43 1024x768), same scene and poses; get_rgba = the same through the GsCamera adapter to host uint8"))
+        if world == 1 and pipelined and not args.no_lowres and config != 5:
+            # What the reference's data generator renders is a PATH (generate_images.py:408-436: consecutive waypoints), not the headline's
+            # stride-77 pose order: the same scene at the same resolution over consecutive headings from one position (5.6 degrees apart; the
+            # lens is 105 degrees wide).  The frames of such a batch's groups see nearly the same part of the scene, and the library projects
+            # them with one grid that reads the scene once (k_preprocess_shared).
+            try:
+                cl = [cams[(W + i) % 64] for i in range(max(K, 20))]
+                ob = torch.zeros((len(cl), cl[0].height, cl[0].width, 3), dtype=torch.float32, device=device)
+                best = None
+                for rep in range(3):
+                    torch.cuda.synchronize(device); t0 = time.perf_counter()
+                    r.render_batch(cl, gs, out=ob)
+                    torch.cuda.synchronize(device)
+                    dt_ = time.perf_counter() - t0
+                    best = dt_ if best is None or dt_ < best else best
+                del ob
+                out["also_measured"] = dict(out.get("also_measured") or {}, trajectory_sweep={
+                    "value": len(cl) / best, "unit": "frames/s", "steps": len(cl), "ms_per_step": 1e3 * best / len(cl),
+                    "what": "one render_batch call over consecutive headings from one position of the same scene (poses W .. W+steps-1 of position 0; "
+                            "best of three) — a trajectory's frames, whose groups share their reads of the scene"})
+            except Exception as e:
+                out["also_measured"] = dict(out.get("also_measured") or {}, trajectory_sweep={"error": f"{type(e).__name__}: {e}"[:300]})
         if world == 1 and not args.no_trained and not args.scene and args.scene_kind == "room" and config != 5:
             # Real InteriorGS scenes are TRAINED 3DGS, not make_room: log-normal scales with a heavy tail, strong anisotropy, 40 % of the splats
             # nearly transparent, floaters, no spatial order (scenes.make_trained_like; no checkpoint is available offline).  The same sweep and
