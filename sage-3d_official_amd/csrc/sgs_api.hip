@@ -168,7 +168,7 @@ int ensure_splats(sgs_ctx* ctx, Lane& L, int64_t n) {
     if ((rc = grow(ctx, L.vismask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.bigmask, (size_t)chunks)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.binrec, (size_t)cap)) != SGS_OK) return rc;
-    if ((rc = grow(ctx, L.live_list, (size_t)chunks + (size_t)(chunks + 31) / 32 + 2)) != SGS_OK) return rc;     // the list | the same as a bitmap (sgs_live_bits)
+    if ((rc = grow(ctx, L.live_list, (size_t)chunks * (1 + SGS_MAX_GROUP) + 2)) != SGS_OK) return rc;     // the list | a group's work list (sgs_work_list)
     if (!L.big_list && (rc = grow(ctx, L.big_list, (size_t)SGS_BIG_CAP)) != SGS_OK) return rc;
     if ((rc = grow(ctx, L.blk_len, (size_t)SGS_BIN_BLOCKS * 2)) != SGS_OK) return rc;                      // list lengths | XCD ids
     if (!L.blk_list && (rc = grow(ctx, L.blk_list, (size_t)SGS_BIN_BLOCKS * SGS_WT)) != SGS_OK) return rc;
@@ -316,34 +316,6 @@ int fine_shift_of(const sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* 
     return z;
 }
 
-// How much of what they read of the scene do the frames of a group have in common?  The sum over the frames of the Gaussians in view,
-// over the Gaussians in view of ANY of them: 1 = disjoint views, nf = the same view nf times.  Estimated on the host from the scene's probe
-// (fine_shift_of; the samples weighted so that they count Gaussians): a sample is in view when its centre falls inside the image widened by
-// a tenth on every side, between the depth planes — ~1 us per frame.  What sgs_render_batch* decides k_preprocess_shared by: with the
-// views of a trajectory's consecutive frames (3.5-4) the group reads the scene once instead of nf times (a sweep of consecutive headings:
-// -7 % per frame, profiles/r06zb); with views that share little (the bench's stride-77 poses: 1.4) the shared grid's waves that find
-// their chunk dead in their frame cost more than the reads it saves (+8 %).
-double group_overlap(const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg) {
-    if (!scene || nf < 2 || scene->probe.size() < 64) return 1.0;
-    double sum = 0.0, uni = 0.0;
-    for (const ProbeSample& g : scene->probe) {
-        int seen = 0;
-        for (int f = 0; f < nf; ++f) {
-            const sgs_camera& c = cams[f];
-            const float* V = c.view;
-            const float tz = V[8] * g.m[0] + V[9] * g.m[1] + V[10] * g.m[2] + V[11];
-            if (!(tz > cfg.near_z) || !(tz <= cfg.far_z)) continue;
-            const float tx = V[0] * g.m[0] + V[1] * g.m[1] + V[2] * g.m[2] + V[3], ty = V[4] * g.m[0] + V[5] * g.m[1] + V[6] * g.m[2] + V[7];
-            const float px = c.fx * tx / tz + c.cx, py = c.fy * ty / tz + c.cy, mx = 0.1f * (float)c.width, my = 0.1f * (float)c.height;
-            if (px >= -mx && px < (float)c.width + mx && py >= -my && py < (float)c.height + my) ++seen;
-        }
-        sum += (double)g.wgt * seen; uni += seen ? (double)g.wgt : 0.0;
-    }
-    return uni > 0.0 ? sum / uni : 1.0;
-}
-constexpr double kShareOverlap = 1.0 / 3.0;      // k_preprocess_shared when the overlap is at least 1 + this much per further frame of the group: 2.0 of
-                                                 // 4 (groups of four, r06zb: +8 % per frame at 1.4, +2 % at 1.5, -3 % at 2.3, -5 % at 2.8, -7 % at 3.5)
-
 int validate(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, const sgs_config* cfg,
              int& row_begin, int& row_end, const float* out_rgb, int* fine_shift = nullptr) {
     if (!scene || !cam || !out_rgb) SGS_FAIL(ctx, SGS_ERR_INVALID, "null scene / camera / output");
@@ -442,32 +414,42 @@ void fill_params(FrameParams& P, const sgs_ctx* ctx, const Lane& L, const sgs_sc
 
 // ---- the launches of a frame (group), stage by stage.  G.s[0 .. nf) are the group's frames (same resolution and tile rows). ----
 // S1-S3: per-chunk bounds -> the frame's live list, then the projection (k_chunk_cull, k_preprocess)
-void launch_cull(const FrameGroup& G, int nf, hipStream_t stream) {
+void launch_cull(const FrameGroup& G, int nf, hipStream_t stream, bool share = false) {
     const FrameParams& P = G.s[0].P;
-    if (P.n_chunks > 0)
+    if (P.n_chunks > 0 && share)       // (the lists of all frames of the group + the group's work list, one lane per chunk)
+        hipLaunchKernelGGL(sgs::k_chunk_cull_group, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS)), dim3(SGS_CULL_THREADS), 0, stream,
+                           G, (unsigned)nf);
+    else if (P.n_chunks > 0)
         hipLaunchKernelGGL(sgs::k_chunk_cull, dim3((unsigned)((P.n_chunks + SGS_CULL_THREADS - 1) / SGS_CULL_THREADS), (unsigned)nf),
                            dim3(SGS_CULL_THREADS), 0, stream, G);
 }
-void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t stream, bool share) {
+void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t stream) {
     const FrameParams& P = G.s[0].P;
     if (P.n_chunks <= 0) return;
-    launch_cull(G, nf, stream);
+    const bool fine = ((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u) != 0u;        // (fine tiles: the instantiation that scales the splats, sgs_common.h)
+    const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
+    const bool narrow = nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all;
+    // The full frames of a GROUP share what they read of the scene: one cull kernel writes every frame's live list and the group's work
+    // list — (chunk, frame) pairs, chunk-major — and the projection's waves take THAT (k_preprocess_shared), so the frames that want a chunk
+    // run side by side and its 15 KiB of rows come from HBM once.  Never slower than every frame walking its own list in its own part of
+    // the grid, whatever the views share (profiles/r06zb: +-0 at an overlap of 1.3 of 4, -2 ... -5 % per frame at the bench's 1.4, -9 % at
+    // 2.3, -7 ... -10 % for a trajectory's consecutive headings); frames bit-identical.  (SGS_NO_SHARE: A/B builds, scripts/build_variant.sh.)
+#ifdef SGS_NO_SHARE
+    const bool share = false;
+#else
+    const bool share = nf > 1 && !narrow;
+#endif
+    launch_cull(G, nf, stream, share);
     // a wave per chunk of the scene (most end at once) — except for a group of narrow bands, whose frames share
     // pre_grid workgroups that loop over the live list (r03y: 0.0454 -> 0.0425 ms per frame of a 3-row band)
-    const int64_t all = (P.n_chunks + 3) / 4, cap = std::max(256, ctx->pre_grid / nf);
-    const bool fine = ((P.flags >> SGS_PFLAG_FINE_SHIFT) & 3u) != 0u;        // (fine tiles: the instantiation that scales the splats, sgs_common.h)
-#ifdef SGS_FORCE_SHARE
-    share = true;                  // (A/B builds only: scripts/build_variant.sh ... -DSGS_FORCE_SHARE)
-#endif
-    if (nf > 1 && 2 * (P.row_end - P.row_begin) < P.gy && cap < all) {
+    if (narrow) {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<true, true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<true, false>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
     }
-    else if (nf > 1 && share) {
-        // the full frames of a group share what they read of the scene (k_preprocess_shared: the grid over the scene's chunks, frames innermost)
-        const unsigned grid = (unsigned)(((all + 7) / 8) * 8 * nf);
-        if (fine) hipLaunchKernelGGL((sgs::k_preprocess_shared<true>), dim3(grid), dim3(256), 0, stream, G, (unsigned)nf);
-        else hipLaunchKernelGGL((sgs::k_preprocess_shared<false>), dim3(grid), dim3(256), 0, stream, G, (unsigned)nf);
+    else if (share) {
+        const unsigned grid = (unsigned)((all * nf + SGS_XCDS - 1) / SGS_XCDS + 1) * SGS_XCDS;       // (every XCD's eighth of the list, rounded up)
+        if (fine) hipLaunchKernelGGL((sgs::k_preprocess_shared<true>), dim3(grid), dim3(256), 0, stream, G);
+        else hipLaunchKernelGGL((sgs::k_preprocess_shared<false>), dim3(grid), dim3(256), 0, stream, G);
     } else {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<false, true>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<false, false>), dim3((unsigned)all, (unsigned)nf), dim3(256), 0, stream, G);
@@ -578,7 +560,7 @@ void note_last(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cam, cons
 //     launches were ~40 us, as long as a light band of tile rows takes on the GPU).
 int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, int nf, const sgs_config& cfg,
                   int row_begin, int row_end, float* const* outs, int slot0, hipStream_t caller_stream, bool timed,
-                  float* out_aux, bool pipelined, bool in_batch, int set0, int z, int stream_lane = -1, bool share = false) {
+                  float* out_aux, bool pipelined, bool in_batch, int set0, int z, int stream_lane = -1) {
     int rc;
     // The stream: a pipelined frame's own lane's; a batch's groups rotate over the streams of lanes 0 .. group_lanes-1 — the
     // SAME streams single pipelined frames use.  (r03y: the groups used to run on the streams of lanes 0 and 4; a process that
@@ -616,7 +598,7 @@ int enqueue_group(sgs_ctx* ctx, const sgs_scene* scene, const sgs_camera* cams, 
     for (int f = 0; f < nf; ++f) ctx->slot_timed[slot0 + f] = timed && f == 0;
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[0], stream));
 
-    launch_project(ctx, G, nf, stream, share);
+    launch_project(ctx, G, nf, stream);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[1], stream));
     launch_binning(ctx, G, nf, stream, timed ? ev[2] : nullptr);
     if (timed) SGS_HIP(ctx, hipEventRecord(ev[3], stream));
@@ -1193,9 +1175,8 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
             float* outs[SGS_MAX_GROUP];
             const int rb = rb0, re = re0;
             for (int f = 0; f < nf; ++f) outs[f] = out_rgb + (size_t)(c0 + i + f) * (size_t)frame_stride;
-            const bool share = nf > 1 && group_overlap(scene, &cams[c0 + i], nf, cfg) >= 1.0 + kShareOverlap * (double)(nf - 1);
             if ((rc = enqueue_group(ctx, scene, &cams[c0 + i], nf, cfg, rb, re, outs, i, stream, false, nullptr, lanes, true,
-                                    sidx * F, zs[(size_t)(c0 + i)], sidx, share)) != SGS_OK)
+                                    sidx * F, zs[(size_t)(c0 + i)], sidx)) != SGS_OK)
                 return rc;
             for (int f = 0; f < nf; ++f) { px[i + f] = ctx->last_pixels; tl[i + f] = ctx->last_tiles; }
             i += nf;

@@ -105,7 +105,8 @@ struct alignas(128) FrameStatus {
     uint32_t max_tile_len;
     uint32_t ds_total;              // records in the super-tile queues (level 1 of the binning)
     uint32_t n_jobs;                // level-2 jobs (k_stile_scan)
-    uint32_t pad0_[10];
+    uint32_t n_work;                // (the FIRST frame of a group only) entries of the group's work list: (chunk, frame) pairs (k_chunk_cull_group)
+    uint32_t pad0_[9];
     // line 1: counters that workgroups ADD to while others of the same kernel read line 0 (a device-scope atomic occupies
     // its line in the fabric for ~12 ns: on one line the readers queued behind the adders)
     uint32_t n_visible;             // N_v

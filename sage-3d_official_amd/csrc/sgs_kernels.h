@@ -448,7 +448,8 @@ __device__ __forceinline__ bool chunk_outside(const FrameParams& P, const float4
 // Gaussians, of which a rank's band of a sharded frame keeps a few per cent — instead of sweeping the scene.  Skipped
 // chunks get an empty visibility mask here (bigmask all-ones marks "skipped by its bounds" for the tests).
 #define SGS_CULL_THREADS 256
-__device__ __forceinline__ unsigned* sgs_live_bits(unsigned* live_list, long long n_chunks) { return live_list + ((n_chunks + 1) & ~1ll); }
+// (behind the live list of a group's first frame: the group's WORK LIST, k_chunk_cull_group)
+__device__ __forceinline__ unsigned* sgs_work_list(unsigned* live_list, long long n_chunks) { return live_list + ((n_chunks + 1) & ~1ll); }
 __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGroup G) {
     const FrameSlot& S = G.s[blockIdx.y];
     const FrameParams& P = S.P;
@@ -462,12 +463,6 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
         if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; }
     }
     const unsigned long long m = __ballot(live);
-    // ... and the same as a BITMAP behind the list (k_preprocess_shared is not given the list's entries but the scene's chunks: 6 KiB per
-    // frame at 3 M Gaussians, a word per 32 chunks — the dead waves of its grid end on a scalar load that nearly always hits)
-    if (lane == 0 && chunk < P.n_chunks) {
-        unsigned* bits = sgs_live_bits(S.live_list, P.n_chunks);
-        bits[chunk >> 5] = (unsigned)m; bits[(chunk >> 5) + 1] = (unsigned)(m >> 32);
-    }
     if (lane == 0) s_wcnt[wave] = (unsigned)__popcll(m);
     __syncthreads();
     unsigned before = 0, total = 0;
@@ -476,6 +471,60 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
     if (tid == 0) s_base = total ? atomicAdd(&S.st->n_live, total) : 0u;
     __syncthreads();
     if (live) S.live_list[s_base + before + lanes_below(m)] = (unsigned)chunk;
+}
+
+// The same for the nf frames of a GROUP whose projection shares its reads of the scene (k_preprocess_shared): one lane per chunk tests it
+// against every frame of the group — every frame's live list as above — and the survivors of ANY frame go, chunk-major, into the group's WORK
+// LIST of (chunk << 3 | frame) pairs behind the first frame's live list (FrameStatus.n_work of that frame counts them): the frames that want a
+// chunk are neighbours in it.
+__global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull_group(const FrameGroup G, const unsigned nf) {
+    __shared__ unsigned s_wcnt[SGS_MAX_GROUP + 1][SGS_CULL_THREADS / SGS_WAVE];
+    __shared__ unsigned s_base[SGS_MAX_GROUP + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long chunk = (long long)blockIdx.x * SGS_CULL_THREADS + tid;
+    const long long n_chunks = G.s[0].P.n_chunks;
+    unsigned lm = 0u;                                   // the frames this chunk is live in
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (chunk < n_chunks) { b0 = G.cbound[2 * chunk]; b1 = G.cbound[2 * chunk + 1]; }
+    for (unsigned f = 0; f < nf; ++f) {
+        const FrameSlot& S = G.s[f];
+        const FrameParams& P = S.P;
+        bool live = false;
+        if (chunk < n_chunks) {
+            live = (P.flags & 64u) != 0u || !chunk_outside(P, b0, b1);
+            if (!live) { S.vismask[chunk] = 0ull; S.bigmask[chunk] = ~0ull; }
+        }
+        lm |= live ? 1u << f : 0u;
+        const unsigned long long m = __ballot(live);
+        if (lane == 0) s_wcnt[f][wave] = (unsigned)__popcll(m);
+    }
+    const unsigned mine = (unsigned)__builtin_popcount(lm);
+    const unsigned incl = wave_incl_scan(mine, lane);
+    if (lane == 63) s_wcnt[nf][wave] = incl;
+    __syncthreads();
+    if (tid <= (int)nf) {          // one atomic per frame's list and one for the work list
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < SGS_CULL_THREADS / SGS_WAVE; ++w) total += s_wcnt[tid][w];
+        s_base[tid] = total ? atomicAdd(tid < (int)nf ? &G.s[tid].st->n_live : &G.s[0].st->n_work, total) : 0u;
+    }
+    __syncthreads();
+    for (unsigned f = 0; f < nf; ++f) {
+        const bool live = (lm >> f) & 1u;
+        const unsigned long long m = __ballot(live);
+        unsigned before = 0;
+#pragma unroll
+        for (int w = 0; w < SGS_CULL_THREADS / SGS_WAVE; ++w) before += w < wave ? s_wcnt[f][w] : 0u;
+        if (live) G.s[f].live_list[s_base[f] + before + lanes_below(m)] = (unsigned)chunk;
+    }
+    {
+        unsigned before = incl - mine;
+#pragma unroll
+        for (int w = 0; w < SGS_CULL_THREADS / SGS_WAVE; ++w) before += w < wave ? s_wcnt[nf][w] : 0u;
+        unsigned* work = sgs_work_list(G.s[0].live_list, n_chunks) + s_base[nf] + before;
+        for (unsigned f = 0, k = 0; f < nf; ++f)
+            if ((lm >> f) & 1u) work[k++] = ((unsigned)chunk << 3) | f;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,25 +911,25 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     }
 }
 
-// The projection of a frame GROUP (full frames): the frames of a group read the SAME scene — a chunk that is live in several of them (the
-// poses of a sweep overlap: a trajectory's consecutive frames almost entirely, the bench's stride-77 poses by a quarter of what they read)
-// is 15 KiB of geometry and SH rows per frame, from HBM every time when each frame walks its own live list in its own part of the grid.  Here
-// the grid is laid over the SCENE's chunks, frames innermost and XCD-aware: workgroup b runs on XCD b mod 8 (round-robin dispatch), so
-//     b = ((q_hi nf + f) 8 + r)   <->   frame f of chunk quad q = 8 q_hi + r
-// puts the nf workgroups that want the same four chunks on ONE XCD, eight ids apart — dispatched together, the second to fourth find the
-// rows in that XCD's L2 (or merge with the request in flight).  A wave whose chunk is not live in its frame (k_chunk_cull's bitmap)
-// ends at once, as the waves beyond the live list's end do in k_preprocess<false>: the same number of waves is launched.
-// Same per-chunk code, same outputs: frames bit-identical.
+// The projection of a frame GROUP (full frames) whose views overlap: the frames of a group read the SAME scene — a chunk that is live in
+// several of them (a trajectory's consecutive frames: almost all) is 15 KiB of geometry and SH rows per frame, from HBM every time when each
+// frame walks its own live list in its own part of the grid.  Here the waves take the entries of the group's WORK LIST (k_chunk_cull_group:
+// (chunk, frame) pairs, chunk-major), so that the frames that want a chunk run side by side — mostly in one workgroup, always on one XCD:
+// workgroup b runs on XCD b mod 8 (round-robin dispatch) and takes position (b mod 8) ceil(n / 8) + b / 8 of the n live workgroups, i.e.
+// every XCD walks ONE contiguous eighth of the list, in order — and the second to fourth find the rows in the CU's L1 / the XCD's L2 (or merge
+// with the request in flight).  Waves beyond the list's end end at once, as in k_preprocess<false>.  Same per-chunk code, same outputs:
+// frames bit-identical.
 template <bool FINE>
-__global__ __launch_bounds__(256) void k_preprocess_shared(const FrameGroup G, const unsigned nf) {
-    const unsigned b = blockIdx.x, r = b & 7u, t = b >> 3;
-    const unsigned f = t % nf, q = (t / nf) * 8u + r;
-    const FrameSlot& S = G.s[f];
-    const FrameParams& P = S.P;
-    const long long chunk = (long long)q * (blockDim.x >> 6) + (long long)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (chunk >= P.n_chunks) return;                                        // wave-uniform
-    if (!((sgs_live_bits(S.live_list, P.n_chunks)[chunk >> 5] >> (unsigned)(chunk & 31)) & 1u)) return;      // not live in this frame (wave-uniform)
-    preprocess_chunk<FINE>(P, G.geom, G.shq, S.splats, S.vismask, S.bigmask, S.big_list, S.binrec, S.st, chunk, threadIdx.x & 63);
+__global__ __launch_bounds__(256) void k_preprocess_shared(const FrameGroup G) {
+    const unsigned n_work = G.s[0].st->n_work;
+    const unsigned wpb = blockDim.x >> 6, n_wg = (n_work + wpb - 1) / wpb, per_xcd = (n_wg + SGS_XCDS - 1) / SGS_XCDS;
+    const unsigned b = blockIdx.x, r = b % SGS_XCDS, t = b / SGS_XCDS;
+    if (t >= per_xcd) return;                                               // workgroup-uniform
+    const unsigned k = (r * per_xcd + t) * wpb + (unsigned)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (k >= n_work) return;                                                // wave-uniform
+    const unsigned e = sgs_work_list(G.s[0].live_list, G.s[0].P.n_chunks)[k];
+    const FrameSlot& S = G.s[e & 7u];
+    preprocess_chunk<FINE>(S.P, G.geom, G.shq, S.splats, S.vismask, S.bigmask, S.big_list, S.binrec, S.st, (long long)(e >> 3), threadIdx.x & 63);
 }
 
 // ------------------------------------------------------------------------------------------------

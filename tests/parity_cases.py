@@ -592,11 +592,11 @@ def case_determinism(drv, n=4000):
 
 
 def case_batch_shares_scene_reads(drv, n=4000, res=(160, 112)):
-    """sgs_render_batch*: the frames of a group whose views overlap (a trajectory's consecutive frames) are projected by ONE grid laid over
-    the scene's chunks, frames innermost (k_preprocess_shared: the group reads the scene once); frames whose views share little each walk
-    their own live list.  Which one runs is the library's choice (group_overlap, estimated from the scene's probe) and must not show: every
-    frame of a batch equals the frame rendered alone, bit for bit — for nearly identical views, for views turned a quarter circle apart, for
-    a batch that mixes them (groups of four: the kinds alternate), with fine tiles and without."""
+    """sgs_render_batch*: the full frames of a group are projected by ONE launch whose waves take the group's work list — (chunk, frame)
+    pairs, chunk-major (k_chunk_cull_group / k_preprocess_shared: the frames that want a chunk run side by side, the group reads the scene
+    once).  That must not show: every frame of a batch equals the frame rendered alone, bit for bit — for nearly identical views (every
+    chunk wanted by all frames), for views turned a quarter circle apart (hardly a chunk wanted twice), for a batch that mixes them
+    (groups of four: the kinds alternate), with fine tiles and without."""
     scene = random_scene(n, 77, 2, box=((-4, 4), (-2, 2), (-4, 4)), scale=(0.02, 0.2))
     drv.upload(*scene)
     w, h = res
