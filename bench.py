@@ -392,8 +392,11 @@ def main():
     # sweeps of up to SHORT steps are ONE render_batch call (round 4: with this round's kernels the batch entry is ahead of frames issued one by one on
     # the lanes at 100 steps too: 4 710-4 740 vs 4 590-4 640 frames/s, same box, profiles/r04zi; it was 32 while the per-frame path won from ~40 frames on)
     SHORT = int(os.environ.get("SGS_BENCH_SHORT", "128"))
-    batch_frames = torch.zeros((min(SHORT, max(K, W, 8)), height, width, 3), dtype=torch.float32, device=device) \
+    batch_frames = torch.zeros((min(SHORT, max(K, W, 16)), height, width, 3), dtype=torch.float32, device=device) \
         if pipelined and not args.no_batch and K <= SHORT else None
+
+    _tun = r.tuning()
+    N_SETS = int(_tun["group"]) * int(_tun["group_lanes"])     # lanes a batch rotates over (16 by default)
 
     def short_sweep(count):
         return batch_frames is not None and 0 < count <= batch_frames.shape[0] and K <= SHORT
@@ -402,12 +405,12 @@ def main():
         """Camera shards: step i is one pose PER RANK (rank rk renders pose (i * world + rk) of the strided sweep); no
         data-path collective.  Returns this rank's per-frame average statistics; every frame is checked for overflow."""
         if short_sweep(count):
-            # a short sweep is ONE call of the batch entry (the generate_images.py loop, SURVEY A4): frame groups of four per
+            # a short sweep is ONE call of the batch entry (the generate_images.py loop, SURVEY A4): frame groups (eight frames) per
             # set of launches fill and drain the pipeline faster than frames issued one by one (round 3: 0.235 vs 0.256 ms/frame at
             # 20 frames; round 4: 0.212 vs 0.217 at 100)
             n = count
-            if warming[0]:           # the batch path rotates over eight sets of intermediates (4 frames x 2 streams): touch them
-                n = max(count, 8)    # all before the clock starts (buffers are allocated on first use), whatever W is
+            if warming[0]:           # the batch path rotates over group x group_lanes sets of intermediates (8 frames x 2 streams): touch
+                n = max(count, N_SETS)   # them all before the clock starts (buffers are allocated on first use), whatever W is
             r.render_batch([cams[pose((first + i % max(1, count)) * world + rank)] for i in range(n)], gs, out=batch_frames)
             return None
         for i in range(count):
@@ -421,9 +424,9 @@ def main():
         sharded = sharded or sharded_head
         acc, n_acc, i = None, 0, 0
         if warming[0] and pipelined and count > 0:
-            # the library's batch path rotates over eight sets of intermediates (buffers allocated on first use): touch them
-            # all before the clock starts, whatever W is
-            sharded.render_batch([cams[pose(first + j % count)] for j in range(8)], gs)
+            # the library's batch path rotates over group x group_lanes sets of intermediates (buffers allocated on first use): touch
+            # them all before the clock starts, whatever W is
+            sharded.render_batch([cams[pose(first + j % count)] for j in range(N_SETS)], gs)
         while i < count:
             nb = min(sharded.batch, count - i) if pipelined else 1
             if warming[0] and nb > 2:          # warm-up: several short batches, so that the bands are re-cut a few times
@@ -732,7 +735,7 @@ def main():
                            if world > 1 else None),
             "config": {"workload": workload,
                        "pose_set": pose_set,
-                       "parallelism": ("1 GPU, " + ("the sweep issued as one render_batch call (frame groups of four on two streams)"
+                       "parallelism": ("1 GPU, " + ("the sweep issued as one render_batch call (frame groups of eight on two streams)"
                                                     if short_sweep(K) else "frames pipelined on the library's three lanes")
                                        if pipelined else "1 GPU, one frame at a time") if world == 1 else
                                       (f"tile-row shard x{world} ({bands_desc}) + RCCL gatherv to rank 0"

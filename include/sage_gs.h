@@ -169,9 +169,11 @@ int sgs_set_record_capacity(sgs_ctx* ctx, int64_t max_records);
  * counterpart in the reference (one synchronous SimulationApp per process, simple_env.py:163).  Version 112 (113: fine_tile_pixels, 114: fine_tile_growth — the two
  * fields frames DO depend on, to fp32 rounding). */
 typedef struct sgs_tuning {
-    int32_t lanes;            /* 3  frames in flight for SGS_FLAG_PIPELINED single frames: each lane has its own stream and intermediates (1..8) */
-    int32_t group;            /* 4  frames per set of launches in sgs_render_batch* (blockIdx.y selects the frame; 1..8) */
-    int32_t group_lanes;      /* 2  streams the groups of a batch alternate over (group x group_lanes <= 8) */
+    int32_t lanes;            /* 3  frames in flight for SGS_FLAG_PIPELINED single frames: each lane has its own stream and intermediates (1..16) */
+    int32_t group;            /* 8  frames per set of launches in sgs_render_batch* (blockIdx.y selects the frame; 1..8).  The full frames of a
+                               *    group are projected by ONE launch that reads what they share of the scene once (r06zb); 8 x 2 against
+                               *    4 x 2: -4.5 % per frame on the bench's poses (r06ze) */
+    int32_t group_lanes;      /* 2  streams the groups of a batch alternate over (group x group_lanes <= 16) */
     int32_t morton;           /* 1  lay the scene out in Z-order at upload (device radix sort); 0 keeps the caller's order */
     int64_t record_capacity;  /* 16 Mi  (Gaussian, tile) records the queues of a lane hold; an overflowing frame grows them and is rendered again
                                *        (= sgs_set_record_capacity) */

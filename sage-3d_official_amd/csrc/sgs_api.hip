@@ -91,14 +91,14 @@ struct Lane {
     bool busy = false;                       // has pipelined work that no synchronisation has collected yet
 };
 
-constexpr int kMaxLanes = 8;
+constexpr int kMaxLanes = 16;
 
 struct sgs_ctx {
     int device = 0;
     std::string err;
     Lane lanes[kMaxLanes];
     int n_lanes = 3, next_lane = 0;          // sgs_tuning.lanes: lanes that SGS_FLAG_PIPELINED single frames rotate over
-    int group = 4, group_lanes = 2;          // sgs_tuning.group x .group_lanes <= kMaxLanes: sgs_render_batch* issues `group` frames per
+    int group = 8, group_lanes = 2;          // sgs_tuning.group x .group_lanes <= kMaxLanes: sgs_render_batch* issues `group` frames per
                                              // set of launches (blockIdx.y = frame), groups rotating over `group_lanes` streams
     int last_lane = 0;
     int exp_grid = SGS_EXP_GRID;             // level-2 binning workgroups per launch (settled by A/B: r03, r04)
@@ -741,7 +741,7 @@ int sgs_destroy(sgs_ctx* ctx) {
 
 void sgs_tuning_default(sgs_tuning* out) {
     if (!out) return;
-    out->lanes = 3; out->group = 4; out->group_lanes = 2; out->morton = 1; out->record_capacity = 16ll << 20;
+    out->lanes = 3; out->group = 8; out->group_lanes = 2; out->morton = 1; out->record_capacity = 16ll << 20;
     out->fine_tile_pixels = 640 * 480; out->fine_tile_growth = 2.2;
 }
 
@@ -1159,16 +1159,22 @@ int sgs_render_batch_strided(sgs_ctx* ctx, const sgs_scene* scene, const sgs_cam
                 SGS_HIP(ctx, hipStreamWaitEvent(ctx->lanes[gl].stream, ctx->lanes[0].fork, 0));
             }
         }
-        // The chunk's frames are dealt to the group streams in EQUAL shares, each share cut into groups of <= F: 20 frames on
-        // two streams are 4,4,2 + 4,4,2, not 4,4,4 + 4,4 (the stream with the extra group finished it alone, without a
-        // neighbour's kernels to overlap with).
-        const int n_streams = lanes ? std::min(GL, (cn + F - 1) / F) : 1;
-        int left[kMaxLanes];                            // frames each stream still has to issue
-        for (int sidx = 0; sidx < n_streams; ++sidx) left[sidx] = cn / n_streams + (sidx < cn % n_streams ? 1 : 0);
+        // The chunk's frames are dealt to the group streams in EQUAL shares (the stream with an extra group finished it alone, without a
+        // neighbour's kernels to overlap with; more than four frames are worth a second stream), each share cut into EQUAL groups of <= F:
+        // 20 frames on two streams are 5,5 + 5,5 under F = 8 (not 8,2 + 8,2: the frames of a group share their reads of the scene and their
+        // launches, a group of two shares little).
+        const int n_streams = lanes ? std::min(GL, (cn + 3) / 4) : 1;
+        int left[kMaxLanes], todo[kMaxLanes];           // frames / groups each stream still has to issue
+        for (int sidx = 0; sidx < n_streams; ++sidx) {
+            left[sidx] = cn / n_streams + (sidx < cn % n_streams ? 1 : 0);
+            todo[sidx] = (left[sidx] + F - 1) / F;
+        }
         for (int i = 0, g = 0; i < cn; ++g) {
             const int sidx = g % n_streams;
-            int nf = std::min(F, left[sidx]);
-            if (nf <= 0) continue;
+            if (left[sidx] <= 0) continue;
+            if (todo[sidx] <= 0) todo[sidx] = (left[sidx] + F - 1) / F;       // (a group that ended early, below, left frames behind)
+            int nf = (left[sidx] + todo[sidx] - 1) / todo[sidx];
+            --todo[sidx];
             // (the frames of a group share one set of launches, hence one grid of tiles: a group ends where the fine-tile shift changes)
             for (int f = 1; f < nf; ++f) if (zs[(size_t)(c0 + i + f)] != zs[(size_t)(c0 + i)]) { nf = f; break; }
             left[sidx] -= nf;

@@ -38,7 +38,7 @@ Bands may be of any height either way and there is no padding.  Which shape is f
 repo (no multi-GPU node was available to its builder): `bench.py --gpus N` times both and says so in `collective`.  A 1080p fp32 frame is 24.9 MB (3.1 MB per rank at 8
 ranks): latency-, not bandwidth-bound — so a sweep ships the bands of B frames per group, asynchronously, double-
 buffered against the rendering of the next batch (`ShardedRenderer.render_batch`; 32 frames by default: the library
-renders a batch in groups of four frames per launch on two streams, and the pipeline drains at the end of every call —
+renders a batch in groups of eight frames per launch on two streams, and the pipeline drains at the end of every call —
 measured on one GPU with every rank's band replayed, slowest of 8 ranks: 0.084 ms/frame at 8 frames per call, 0.077 at
 16, 0.070 at 32).
 

@@ -97,9 +97,9 @@ for libname in LIBS:
     else:
         tag = libname
         r = Renderer(dev, record_capacity=96 << 20, lib=_capi.Lib(os.path.join(ROOT, "build", "variants", libname if libname.endswith(".so") else libname + ".so")))
-    GROUP = next((int(a[6:]) for a in args if a.startswith("group=")), 0)
+    GROUP = next((int(a[6:]) for a in args if a.startswith("group=")), 0); GL = next((int(a[3:]) for a in args if a.startswith("gl=")), 2)
     if GROUP:
-        r.set_tuning(group=GROUP, group_lanes=2 if 2 * GROUP <= 8 else 1)
+        r.set_tuning(group=GROUP, group_lanes=GL)
         tag = f"{tag} group={GROUP}"
     for mode in modes:
         if mode == "packed":

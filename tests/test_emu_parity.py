@@ -400,7 +400,7 @@ def test_tuning_surface(drv):
     lib, ctx = drv.lib, drv.ctx
     t = _capi.SgsTuning()
     lib.sgs_tuning_default(C.byref(t))
-    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth) == (3, 4, 2, 1, 16 << 20, 640 * 480, 2.2)
+    assert (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth) == (3, 8, 2, 1, 16 << 20, 640 * 480, 2.2)
     scene = pc.random_scene(900, 41, 1, scale=(0.05, 0.3))
     cam = onp.Camera(96, 64, 70.0, 70.0, 48.0, 32.0, np.eye(4, dtype=np.float32))
     drv.upload(*scene)
@@ -410,7 +410,7 @@ def test_tuning_surface(drv):
     want16, st16 = drv.render(cam, stats=False, fine=False)
     lib.check(lib.sgs_get_tuning(ctx, C.byref(t)), ctx)
     keep = (t.lanes, t.group, t.group_lanes, t.morton, t.record_capacity, t.fine_tile_pixels, t.fine_tile_growth)
-    for bad in ((0, 4, 2), (9, 4, 2), (3, 9, 1), (3, 4, 3), (3, 0, 1)):
+    for bad in ((0, 4, 2), (17, 4, 2), (3, 9, 1), (3, 8, 3), (3, 0, 1)):
         u = _capi.SgsTuning(bad[0], bad[1], bad[2], 1, 1 << 20, 640 * 480, 2.2)
         assert lib.sgs_set_tuning(ctx, C.byref(u)) == -1 and b"sgs_tuning" in lib.sgs_last_error(ctx)
     u = _capi.SgsTuning(3, 4, 2, 1, 0, 640 * 480, 2.2)

@@ -1028,14 +1028,14 @@ def test_frames_do_not_depend_on_the_tuning(drv):
     cams = scenes.room_cameras(sc, 800, 600, n_positions=2, n_yaw=5, seed=6)
     g = scenes.to_gaussians(sc, "cuda:0")
     scene = drv.r.upload(g)
-    assert drv.r.tuning() == {"lanes": 3, "group": 4, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"],
+    assert drv.r.tuning() == {"lanes": 3, "group": 8, "group_lanes": 2, "morton": 1, "record_capacity": drv.r.tuning()["record_capacity"],
                               "fine_tile_pixels": 640 * 480, "fine_tile_growth": 2.2}
     want, stats = [], []
     for c in cams:
         want.append(drv.r.render(c, scene).clone()); stats.append((drv.r.last_stats["n_visible"], drv.r.last_stats["d_total"]))
     scene.free()
     for kw in (dict(lanes=1, group=1, group_lanes=1), dict(lanes=8, group=8, group_lanes=1), dict(lanes=2, group=2, group_lanes=4),
-               dict(lanes=5, group=3, group_lanes=2, morton=False)):
+               dict(lanes=5, group=3, group_lanes=2, morton=False), dict(lanes=16, group=4, group_lanes=4)):
         r = Renderer("cuda:0", **kw)
         t = r.tuning()
         assert all(t[k] == int(v) for k, v in kw.items()), (t, kw)
@@ -1049,12 +1049,12 @@ def test_frames_do_not_depend_on_the_tuning(drv):
             assert (outs[i] == want[i]).all() and (batch[i] == want[i]).all(), f"{kw}: frame {i} differs"
             assert (bst[i]["n_visible"], bst[i]["d_total"]) == stats[i]
         # changing it on a live context: the next frames run under the new values
-        r.set_tuning(lanes=3, group=4, group_lanes=2)
+        r.set_tuning(lanes=3, group=8, group_lanes=2)
         assert (r.render_batch(cams, s2)[0] == want[0]).all()
         s2.free(); r.close()
     # refused, with a message, not clamped
     r = Renderer("cuda:0")
-    for bad in (dict(lanes=0), dict(lanes=9), dict(group=9), dict(group=4, group_lanes=3), dict(record_capacity=-5), dict(fine_tile_pixels=-1),
+    for bad in (dict(lanes=0), dict(lanes=17), dict(group=9), dict(group=8, group_lanes=3), dict(record_capacity=-5), dict(fine_tile_pixels=-1),
                 dict(fine_tile_growth=0.5)):
         with pytest.raises(Exception, match="sgs_tuning"):
             r.set_tuning(**bad)
