@@ -191,7 +191,7 @@ def case_ragged(drv):
         check_against_oracle(drv, scene, cam, what=f"ragged n={n} {w}x{h}")
 
 
-def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
+def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False, thorough_every=1):
     """Seeded random small frames through the full comparison: scene size, resolution (ragged tiles), SH degree, splat
     sizes from sub-pixel to screen-filling, opacities down to the cut-off, cameras inside and outside the cloud (Gaussians
     behind the camera, across the near plane, off screen), non-default thresholds / dilation / background, and a band of
@@ -230,7 +230,8 @@ def case_fuzz(drv, seeds, max_n=700, max_res=(260, 160), wild=False):
             r0 = int(rng.integers(0, gy - 1)); rows = (r0, int(rng.integers(r0 + 1, gy + 1)))
         if seed % 4 == 0:            # default constants and the whole frame: also the depth / coverage outputs (f-4)
             cfg, rows = None, (0, -1)
-        check_against_oracle(drv, scene, cam, cfg, rows, what=f"fuzz seed {seed} (n={n} {w}x{h} deg {deg} rows {rows})")
+        check_against_oracle(drv, scene, cam, cfg, rows, what=f"fuzz seed {seed} (n={n} {w}x{h} deg {deg} rows {rows})",
+                             thorough=seed % thorough_every == 0)
         if seed % 5 == 1 and rows == (0, -1):      # interleaved tile-row shards reproduce the frame's rows bit for bit
             full, st_full = drv.render(cam, cfg)
             stride = int(rng.integers(2, 5))
@@ -591,7 +592,7 @@ def case_determinism(drv, n=4000):
     assert (d1 == d2).all() and sd1 == sd2 and ((d1 == f1).all() or (d1 == a).all() or sd1["n_tiles"] not in (st["n_tiles"], st1["n_tiles"]))
 
 
-def case_batch_shares_scene_reads(drv, n=4000, res=(160, 112)):
+def case_batch_shares_scene_reads(drv, n=4000, res=(160, 112), quick=False):
     """sgs_render_batch*: the full frames of a group are projected by ONE launch whose waves take the group's work list — (chunk, frame)
     pairs, chunk-major (k_chunk_cull_group / k_preprocess_shared: the frames that want a chunk run side by side, the group reads the scene
     once).  That must not show: every frame of a batch equals the frame rendered alone, bit for bit — for nearly identical views (every
@@ -608,7 +609,7 @@ def case_batch_shares_scene_reads(drv, n=4000, res=(160, 112)):
     near = [cam_at(10.0 + 2.0 * k, 0.02 * k) for k in range(6)]                  # consecutive frames of a path
     far = [cam_at(90.0 * k) for k in range(4)] + [cam_at(45.0), cam_at(225.0)]   # views that share next to nothing
     mixed = near[:4] + far[:4] + near[4:] + far[4:]
-    for cams in (near, far, mixed):
+    for cams in ((mixed,) if quick else (near, far, mixed)):       # (quick — the CPU emulator: the mixed batch holds both kinds of group)
         for fine in (False, True):
             with forced_fine(drv):
                 alone = [drv.render(c, stats=False, fine=fine)[0] for c in cams]
