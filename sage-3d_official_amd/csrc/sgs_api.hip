@@ -445,8 +445,7 @@ void launch_project(const sgs_ctx* ctx, const FrameGroup& G, int nf, hipStream_t
     if (narrow) {
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess<true, true>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess<true, false>), dim3((unsigned)cap, (unsigned)nf), dim3(256), 0, stream, G);
-    }
-    else if (share) {
+    } else if (share) {
         const unsigned grid = (unsigned)((all * nf + SGS_XCDS - 1) / SGS_XCDS + 1) * SGS_XCDS;       // (every XCD's eighth of the list, rounded up)
         if (fine) hipLaunchKernelGGL((sgs::k_preprocess_shared<true>), dim3(grid), dim3(256), 0, stream, G);
         else hipLaunchKernelGGL((sgs::k_preprocess_shared<false>), dim3(grid), dim3(256), 0, stream, G);

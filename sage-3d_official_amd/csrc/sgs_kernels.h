@@ -473,7 +473,7 @@ __global__ __launch_bounds__(SGS_CULL_THREADS) void k_chunk_cull(const FrameGrou
     if (live) S.live_list[s_base + before + lanes_below(m)] = (unsigned)chunk;
 }
 
-// The same for the nf frames of a GROUP whose projection shares its reads of the scene (k_preprocess_shared): one lane per chunk tests it
+// The same for the nf full frames of a GROUP, whose projection shares its reads of the scene (k_preprocess_shared): one lane per chunk tests it
 // against every frame of the group — every frame's live list as above — and the survivors of ANY frame go, chunk-major, into the group's WORK
 // LIST of (chunk << 3 | frame) pairs behind the first frame's live list (FrameStatus.n_work of that frame counts them): the frames that want a
 // chunk are neighbours in it.
@@ -911,7 +911,7 @@ __global__ __launch_bounds__(256) void k_preprocess(const FrameGroup G) {
     }
 }
 
-// The projection of a frame GROUP (full frames) whose views overlap: the frames of a group read the SAME scene — a chunk that is live in
+// The projection of a frame GROUP (full frames): the frames of a group read the SAME scene — a chunk that is live in
 // several of them (a trajectory's consecutive frames: almost all) is 15 KiB of geometry and SH rows per frame, from HBM every time when each
 // frame walks its own live list in its own part of the grid.  Here the waves take the entries of the group's WORK LIST (k_chunk_cull_group:
 // (chunk, frame) pairs, chunk-major), so that the frames that want a chunk run side by side — mostly in one workgroup, always on one XCD:
