@@ -121,8 +121,14 @@ def check_against_oracle(drv, scene, cam, cfg=None, rows=(0, -1), what="", queue
     r = aux["rect"][vis]
     assert ((sp[:, 10] & 0xffff) == r[:, 0]).all() and ((sp[:, 10] >> 16) == r[:, 1]).all() and \
            ((sp[:, 11] & 0xffff) == r[:, 2]).all() and ((sp[:, 11] >> 16) == r[:, 3]).all(), f"{what}: tile rects differ"
-    assert np.abs(f[:, 0:2] - aux["xy"][vis]).max(initial=0) <= 1e-3 * 2 ** -10, f"{what}: mean2D"      # fp32 ulp at ~2k px
-    rel = np.abs(np.stack([f[:, 2], f[:, 3], f[:, 4]], 1) - aux["conic"][vis]) / (np.abs(aux["conic"][vis]) + 1e-12)
+    # mean2D: the oracle's fp64 value rounded to fp32 — bit for bit, but for ONE fp32 ulp where the two fp64 evaluations (a reciprocal and a
+    # product here, a division there) fall on either side of a rounding boundary (gpu_fuzz_trained seed 415: one of 155 k splats, r06zh)
+    dxy = np.abs(f[:, 0:2] - aux["xy"][vis])
+    assert (dxy <= np.maximum(1e-3 * 2 ** -10, np.spacing(np.abs(aux["xy"][vis])))).all(), f"{what}: mean2D {dxy.max():.2e}"
+    # conic: 1e-5 relative, entry by entry — an entry below a millionth of the conic's largest (a numerical zero: the off-diagonal of an
+    # isotropic Gaussian comes out as 1e-17 on both sides, gpu_fuzz_rooms seed 434) is held against that scale instead of against itself
+    cref = aux["conic"][vis]
+    rel = np.abs(np.stack([f[:, 2], f[:, 3], f[:, 4]], 1) - cref) / np.maximum(np.abs(cref), 1e-6 * np.abs(cref).max(axis=1, keepdims=True, initial=0) + 1e-30)
     assert rel.max(initial=0) < 1e-5, f"{what}: conic {rel.max():.2e}"
     assert (f[:, 5] == aux["opacity"][vis]).all(), f"{what}: opacity"
     rgb = np.stack([f[:, 6], f[:, 7], f[:, 8]], 1)
