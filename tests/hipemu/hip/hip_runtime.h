@@ -50,8 +50,44 @@ namespace hipemu {
 
 constexpr size_t kStackBytes = 256 * 1024;
 
+// Fiber switches: on x86-64 a dozen instructions of our own (callee-saved registers and the stack pointer) — glibc's swapcontext / getcontext
+// make an rt_sigprocmask system call per switch, and a lane switches at every collective and every barrier: the system calls were a third of
+// the CPU suite's time.  Elsewhere: ucontext.
+#if defined(__x86_64__)
+#define HIPEMU_ASM_SWITCH 1
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+#else
+#define HIPEMU_ASM_SWITCH 0
+#endif
+
 struct Fiber {
+#if HIPEMU_ASM_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     char* stack = nullptr;
     bool finished = true;
     dim3 tid;
@@ -68,7 +104,11 @@ struct WaveState {
 struct BlockExec {
     std::vector<Fiber> fibers;
     std::vector<WaveState> waves;
+#if HIPEMU_ASM_SWITCH
+    void* sched = nullptr;
+#else
     ucontext_t sched;
+#endif
     int cur = 0, nthreads = 0, alive = 0, bar_arrived = 0;
     unsigned bar_gen = 0;
     dim3 bid, bdim, gdim;
@@ -77,7 +117,11 @@ struct BlockExec {
 
 inline BlockExec*& exec() { static thread_local BlockExec* e = nullptr; return e; }
 
+#if HIPEMU_ASM_SWITCH
+inline void yield() { BlockExec* e = exec(); hipemu_switch(&e->fibers[e->cur].sp, e->sched); }
+#else
 inline void yield() { BlockExec* e = exec(); swapcontext(&e->fibers[e->cur].ctx, &e->sched); }
+#endif
 
 inline void wave_release(WaveState& w) {
     const int p = w.gen & 1;
@@ -113,7 +157,8 @@ inline void fiber_entry() {
     BlockExec* e = exec();
     (*e->body)();
     fiber_exit_bookkeeping(e);
-    swapcontext(&e->fibers[e->cur].ctx, &e->sched);
+    yield();                               // (for good: a finished fiber is never switched to again)
+    abort();
 }
 
 inline void run_block(BlockExec* e, dim3 bid, dim3 bdim, dim3 gdim, const std::function<void()>& body) {
@@ -134,16 +179,28 @@ inline void run_block(BlockExec* e, dim3 bid, dim3 bdim, dim3 gdim, const std::f
         Fiber& f = e->fibers[i];
         f.finished = false; f.tid = dim3((unsigned)i);
         e->waves[i >> 6].alive++;
+#if HIPEMU_ASM_SWITCH
+        // the first switch to the fiber pops six registers and "returns" into fiber_entry with the stack as a call leaves it (rsp = 8 mod 16)
+        void** top = reinterpret_cast<void**>((reinterpret_cast<uintptr_t>(f.stack) + kStackBytes) & ~uintptr_t(15)) - 2;
+        top[0] = reinterpret_cast<void*>(&fiber_entry);
+        for (int k = 1; k <= 6; ++k) top[-k] = nullptr;
+        f.sp = top - 6;
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack; f.ctx.uc_stack.ss_size = kStackBytes; f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
     }
     long spins = 0;
     while (e->alive > 0) {
         for (int i = 0; i < n; ++i) {
             if (e->fibers[i].finished) continue;
             e->cur = i;
+#if HIPEMU_ASM_SWITCH
+            hipemu_switch(&e->sched, e->fibers[i].sp);
+#else
             swapcontext(&e->sched, &e->fibers[i].ctx);
+#endif
         }
         if (++spins > 50000000L) { fprintf(stderr, "hipemu: deadlock (divergent collective/barrier?)\n"); abort(); }
     }

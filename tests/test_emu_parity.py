@@ -21,7 +21,7 @@ def test_config1(drv):
 
 
 def test_sh_degrees(drv):
-    pc.case_sh_degrees(drv, n=600, thorough=False)      # (thorough for the degree-3 scene at its own degree)
+    pc.case_sh_degrees(drv, n=600)
 
 
 def test_ragged_sizes(drv):
@@ -29,13 +29,13 @@ def test_ragged_sizes(drv):
 
 
 def test_seeded_random_frames(drv):
-    pc.case_fuzz(drv, range(8), thorough_every=2)
+    pc.case_fuzz(drv, range(12))
 
 
 def test_seeded_random_frames_with_needles_and_specks(drv):
     """Splats from far below a pixel to needles and pancakes the size of the scene (aspect ratios up to 1e4): what the
     completed-square form of q2 is for (seeds 8019 and 8036 failed the three-term form by 1.6e-3)."""
-    pc.case_fuzz(drv, range(7000, 7006), 400, (200, 120), wild=True, thorough_every=2)
+    pc.case_fuzz(drv, range(7000, 7008), 400, (200, 120), wild=True)
 
 
 def test_non_finite_gaussians_are_invisible_and_harmless(drv):
@@ -90,7 +90,7 @@ def test_full_grid_splat(drv):
 
 def test_wide_band_of_tiles(drv):
     # 129 x 65 = 8385 tiles (more than SGS_WT super-tile counters would be, were they per tile): one window of 33 x 17 super-tiles
-    pc.case_full_grid_splat(drv, res=(2064, 1040), thorough=False)     # (the switch-against-switch renders: test_full_grid_splat)
+    pc.case_full_grid_splat(drv, res=(2064, 1040))
 
 
 def test_depth_and_coverage_outputs(drv):
@@ -102,7 +102,7 @@ def test_fine_tile_decision_follows_the_growth_of_the_record_count(drv):
 
 
 def test_batch_shares_scene_reads(drv):
-    pc.case_batch_shares_scene_reads(drv, n=2500, res=(128, 96), quick=True)
+    pc.case_batch_shares_scene_reads(drv)
 
 
 def test_determinism(drv):
