@@ -29,13 +29,13 @@ def test_ragged_sizes(drv):
 
 
 def test_seeded_random_frames(drv):
-    pc.case_fuzz(drv, range(12))
+    pc.case_fuzz(drv, range(28))
 
 
 def test_seeded_random_frames_with_needles_and_specks(drv):
     """Splats from far below a pixel to needles and pancakes the size of the scene (aspect ratios up to 1e4): what the
     completed-square form of q2 is for (seeds 8019 and 8036 failed the three-term form by 1.6e-3)."""
-    pc.case_fuzz(drv, range(7000, 7008), 400, (200, 120), wild=True)
+    pc.case_fuzz(drv, range(7000, 7020), 400, (200, 120), wild=True)
 
 
 def test_non_finite_gaussians_are_invisible_and_harmless(drv):
