@@ -22,4 +22,10 @@ for i, c in enumerate(cams):
     ok = bool((img == ref).all()) and bool((plain == img).all()) and bool((union == img).all()) and d == st["d_total"] and st["d_total"] <= st_ref["d_total"] and st["n_visible"] == st_ref["n_visible"]
     print(f"cam {i}: N_v={st['n_visible']} D={st['d_total']} (reference binning {st_ref['d_total']}) D_f={st['d_fetched']} deep windows {deep} ms={ {k: round(v, 3) for k, v in st['ms'].items()} } -> {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += 0 if ok else 1
+# ... and the same frames as ONE batch (groups of eight: the group's work list of (chunk, frame) pairs, k_preprocess_shared) equal the frames alone
+alone = [r.render(c, gs).clone() for c in cams]
+batch = r.render_batch(cams, gs)
+nb = sum(0 if bool((batch[i] == alone[i]).all()) else 1 for i in range(len(cams)))
+print(f"batch of {len(cams)}: {nb} frames differ from the frames rendered alone")
+bad += nb
 print(f"{bad} mismatches"); sys.exit(1 if bad else 0)
